@@ -1,0 +1,183 @@
+"""CPU suite: pin the numpy oracle (oracle/) to the golden vectors produced by the reference
+itself (tests/golden/gen_golden.py).  Tolerances: float32 summation-order differences only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, sub_state
+from oracle import ops
+from oracle.autoregressive import ConditionalAutoregressive2D, split_chunks
+from oracle.prior import SimplePrior
+from oracle.sample import get_starts, sample_level
+from oracle.transformer import Transformer, allowed_keys, decode_key_index
+from oracle.vqvae import VQVAE
+
+
+class _OneLayer(Transformer):
+    """A FactoredAttention alone: reuse Transformer._attention with dummy ln/mlp params."""
+
+    def __init__(self, sd, func, n_in, n_ctx, n_head, blocks, prime_len, encoder_dims):
+        z = lambda *s: np.zeros(s, np.float32)
+        full = {"_attn_mods.0.attn." + k: v for k, v in sd.items()}
+        for nm, shp in (("ln_0.weight", (n_in,)), ("ln_0.bias", (n_in,)), ("ln_1.weight", (n_in,)),
+                        ("ln_1.bias", (n_in,)), ("mlp.c_fc.w", (n_in, n_in)), ("mlp.c_fc.b", (n_in,)),
+                        ("mlp.c_proj.w", (n_in, n_in)), ("mlp.c_proj.b", (n_in,))):
+            full["_attn_mods.0." + nm] = z(*shp)
+        super().__init__(full, "", n_in, n_ctx, n_head, 1, blocks=blocks, funcs=[func],
+                         m_attn=sd["c_proj.w"].shape[0] / n_in, encoder_dims=encoder_dims, prime_len=prime_len)
+
+
+@pytest.mark.parametrize("func", [0, 1, 2, 3, 6, 7])
+def test_attention_patterns(func):
+    g = load_golden("attention")
+    sd = sub_state(g, f"f{func}.")
+    x = sd.pop("x"); y_full = sd.pop("y_full"); y_chunks = sd.pop("y_chunks")
+    ekv = sd.pop("encoder_kv", None)
+    L = x.shape[1]
+    att = _OneLayer(sd, func, 32, L, 2, 8, 24 if func == 7 else None, 16 if func == 6 else None)
+    # one full-length chunk == the training-style forward
+    y = att._attention(0, x, 0, False, ekv)
+    assert np.abs(y - y_full).max() < 2e-6
+    # the reference's ragged chunk schedule, incl. q_l == 1 steps
+    att.del_cache()
+    ys, pos = [], 0
+    for c in list(g["chunks"]) + [11] * 100:
+        if pos >= L:
+            break
+        c = int(min(c, L - pos))
+        ys.append(att._attention(0, x[:, pos:pos + c], pos, False, ekv))
+        pos += c
+    assert np.abs(np.concatenate(ys, 1) - y_chunks).max() < 2e-6
+
+
+def test_key_sets_consistent():
+    """decode_key_index (q_l == 1) and allowed_keys (masked prefill) describe the same sets."""
+    for func in (0, 1, 2, 3, 7):
+        for p in range(0, 70):
+            idx = decode_key_index(func, p, 8, 32)
+            m = allowed_keys(func, [p], np.arange(p + 1), 8, 32)[0]
+            want = np.nonzero(m)[0]
+            if func == 7:
+                want = want[want < 32]
+            got = np.array([], int) if idx is None else idx
+            assert np.array_equal(got, want), (func, p)
+
+
+def _ar(g, pfx, **kw):
+    return ConditionalAutoregressive2D(sub_state(g, pfx), "", **kw)
+
+
+def test_autoregressive_sample_fp32():
+    g = load_golden("autoregressive")
+    p = _ar(g, "a.", input_shape=(64,), bins=128, width=64, depth=6, heads=2, attn_order=2, blocks=8,
+            x_cond=True, y_cond=True)
+    z, preds = p.sample(3, g["a.x_cond"], g["a.y_cond"], top_k=1, get_preds=True)
+    assert np.abs(preds - g["a.preds"]).max() < 2e-5
+    assert np.array_equal(z, g["a.z"])
+    z20 = p.sample(3, g["a.x_cond"], g["a.y_cond"], top_k=1, sample_tokens=20)
+    assert np.array_equal(z20, g["a.z20"])
+    lf = p.forward_logits(g["a.z"], g["a.x_cond"], g["a.y_cond"])
+    assert np.abs(lf - g["a.preds_forward"]).max() < 2e-5
+
+
+def test_autoregressive_sample_fp16_emulation():
+    """reference run with fp16=True on CPU vs the oracle's rounding emulation (logit tolerance,
+    SURVEY.md section 7 'hard parts': fp16 moves logits by ~4e-3)."""
+    g = load_golden("autoregressive")
+    p = _ar(g, "a.", input_shape=(64,), bins=128, width=64, depth=6, heads=2, attn_order=2, blocks=8,
+            x_cond=True, y_cond=True)
+    z, preds = p.sample(3, g["a.x_cond"], g["a.y_cond"], top_k=1, get_preds=True, fp16=True)
+    agree = (z == g["a.z16"]).mean()
+    # compare logits while the streams agree
+    first_div = np.argmax((z != g["a.z16"]).any(0)) if (z != g["a.z16"]).any() else z.shape[1]
+    n = max(int(first_div), 1)
+    assert np.abs(preds[:, :n] - g["a.preds16"][:, :n]).max() < 2e-2
+    assert agree > 0.9
+
+
+def test_autoregressive_primed_order12():
+    g = load_golden("autoregressive")
+    p = _ar(g, "b.", input_shape=(120,), bins=80, width=32, depth=48, heads=2, attn_order=12, blocks=8,
+            x_cond=False, y_cond=False, prime_len=24)
+    z, preds = p.primed_sample(2, g["b.x_prime"], top_k=1, get_preds=True, chunk_size=7)
+    assert np.abs(preds - g["b.preds"]).max() < 5e-5
+    assert np.array_equal(z, g["b.z"])
+    z60, preds60 = p.primed_sample(2, g["b.x_prime"], top_k=1, get_preds=True, sample_tokens=60)
+    assert np.abs(preds60 - g["b.preds60"]).max() < 5e-5
+    assert np.array_equal(z60, g["b.z60"])
+
+
+def test_autoregressive_dense_ycond():
+    g = load_golden("autoregressive")
+    p = _ar(g, "c.", input_shape=(40,), bins=96, width=48, depth=3, heads=3, attn_order=0, blocks=None,
+            x_cond=False, y_cond=True)
+    z, preds = p.sample(2, None, g["c.y_cond"], top_k=1, get_preds=True)
+    assert np.abs(preds - g["c.preds"]).max() < 2e-5
+    assert np.array_equal(z, g["c.z"])
+
+
+def test_vqvae_encode_decode(tiny_hps):
+    g = load_golden("vqvae")
+    vq = VQVAE(sub_state(g, "sd."), tiny_hps["tiny_vqvae"])
+    zs = vq.encode(g["x"])
+    for l in range(3):
+        assert (zs[l] == g[f"z{l}"]).mean() > 0.995          # argmin near-ties may flip a code
+        xd = vq.decode([g[f"z{l}"]] + [None] * (2 - l), start_level=l)
+        assert np.abs(xd - g[f"xd{l}"]).max() < 1e-5
+
+
+def _priors(tiny_hps):
+    g = load_golden("priors")
+    vq = tiny_hps["tiny_vqvae"]
+    top_len = vq["sample_length"]
+    hops = np.cumprod([s ** d for s, d in zip(vq["strides_t"], vq["downs_t"])])
+    vq_shapes = [top_len // h for h in hops]
+    out = []
+    for i, nm in enumerate(["tiny_up0", "tiny_up1", "tiny_top"]):
+        hps = tiny_hps[nm]
+        z_shapes = [(zs * hps["n_ctx"] // vq_shapes[hps["level"]],) for zs in vq_shapes]
+        out.append(SimplePrior(sub_state(g, f"p{i}."), hps, z_shapes, vq["l_bins"], vq["downs_t"], vq["strides_t"]))
+    return g, out
+
+
+def test_prior_conditioning_and_sampling(tiny_hps):
+    g, (up0, up1, top) = _priors(tiny_hps)
+    x_cond, y_cond, prime = top.get_cond(None, g["top.y0"])
+    assert np.abs(x_cond - g["top.x_cond"]).max() < 1e-6 and np.abs(y_cond - g["top.y_cond"]).max() < 1e-6
+    z = top.sample(3, z=np.zeros((3, 0), np.int64), y=g["top.y0"], top_k=1, chunk_size=5)
+    assert np.array_equal(z, g["top.z_ancestral"])
+    zp = top.sample(3, z=g["top.z_ancestral"][:, 24:], y=g["top.y24"], top_k=1, chunk_size=5)
+    assert np.array_equal(zp, g["top.z_primed"])
+    zpt = top.sample(3, z=g["top.z_ancestral"][:, :10], y=g["top.y0"], top_k=1, chunk_size=5, sample_tokens=30)
+    assert np.array_equal(zpt, g["top.z_partial30"])
+    for nm, p in (("up1", up1), ("up0", up0)):
+        x_cond, y_cond, _ = p.get_cond([g[f"{nm}.z_cond"]], g[f"{nm}.y"])
+        assert np.abs(x_cond - g[f"{nm}.x_cond"]).max() < 2e-5
+        assert np.abs(y_cond - g[f"{nm}.y_cond"]).max() < 1e-6
+        z, preds = p.prior.sample(3, x_cond, y_cond, None, top_k=1, get_preds=True)
+        assert np.abs(preds - g[f"{nm}.preds"]).max() < 1e-4
+        assert np.array_equal(z, g[f"{nm}.z"])
+        zp = p.sample(3, z=g[f"{nm}.z"][:, :64], z_conds=[g[f"{nm}.z_cond"]], y=g[f"{nm}.y"], top_k=1, chunk_size=32)
+        assert np.array_equal(zp, g[f"{nm}.z_primed"])
+
+
+def test_top_prior_raw_logits(tiny_hps):
+    g, (_, _, top) = _priors(tiny_hps)
+    x_cond, y_cond, prime = top.get_cond(None, g["top.y0"])
+    xc = np.concatenate([np.zeros((3, top.n_tokens, 32), np.float32), x_cond], 1)
+    z, preds = top.prior.primed_sample(3, prime, xc, y_cond, top_k=1, chunk_size=5, get_preds=True)
+    assert np.abs(preds - g["top.raw_preds"]).max() < 5e-5
+    assert np.array_equal(z, g["top.raw_z"])
+
+
+def test_misc_tables():
+    g = load_golden("misc")
+    i = 0
+    while f"starts{i}" in g.files:
+        assert list(g[f"starts{i}"]) == get_starts(*[int(v) for v in g[f"starts{i}.args"]])
+        i += 1
+    i = 0
+    while f"chunks{i}" in g.files:
+        assert list(g[f"chunks{i}"]) == split_chunks(*[int(v) for v in g[f"chunks{i}.args"]])
+        i += 1
+    for k in (1, 5, 97, 200):
+        assert np.array_equal(ops.filter_logits(g["filter.logits"], top_k=k), g[f"filter.top_k{k}"])
