@@ -1,0 +1,195 @@
+/* jukebox_hip.h -- C ABI of libjukebox_hip.so: the MI355X (gfx950) kernels behind the Jukebox
+ * sampling path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless a
+ * comment says "host".  No function allocates or synchronises; all work is enqueued on the
+ * `stream` argument (a hipStream_t passed as void*).  Return value: 0 on success, negative
+ * jb_status otherwise; jb_last_error() (host, thread-local) describes the last failure.
+ *
+ * The reference (openai/jukebox) has no FFI layer for this path -- its boundary is Python
+ *  plus the optional apex pybind module for LayerNorm.  Each entry point
+ * below cites the reference code it replaces; paths are relative to the reference tree.
+ */
+#ifndef JUKEBOX_HIP_H
+#define JUKEBOX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { JB_F32 = 0, JB_F16 = 1 } jb_dtype;
+typedef enum { JB_OK = 0, JB_ERR_ARG = -1, JB_ERR_UNSUPPORTED = -2, JB_ERR_HIP = -3 } jb_status;
+typedef enum { JB_ACT_NONE = 0, JB_ACT_RELU = 1, JB_ACT_QUICK_GELU = 2 } jb_act;
+
+/* attention patterns: jukebox/transformer/factored_attention.py:57-66 */
+typedef enum {
+    JB_ATTN_DENSE = 0, JB_ATTN_BLOCK = 1, JB_ATTN_TRANSPOSE_BLOCK = 2, JB_ATTN_PREV_BLOCK = 3,
+    JB_ATTN_CROSS = 6, JB_ATTN_PRIME = 7
+} jb_attn_func;
+
+const char* jb_last_error(void);
+int jb_version(void);
+
+/* Bytes of the MFMA-fragment-ordered weight image for a K x J matrix of `dtype`
+ * (K padded to 32 (f16) / 16 (f32), J padded to 16). */
+int64_t jb_packed_weight_bytes(int K, int J, int dtype);
+
+/* Re-lay a weight matrix for the MFMA kernels: src element (k, j) is read at
+ * src[k * stride_k + j * stride_j] (elements of src_dtype) and converted to dst_dtype.
+ * Replaces the per-call `self.w.type_as(x)` cast of Conv1D.forward (jukebox/transformer/ops.py:99);
+ * strides let it take Conv1D.w (n_in, n_out), nn.Linear.weight (out, in), and one tap of an
+ * nn.Conv1d (out, in, k) / nn.ConvTranspose1d (in, out, k) weight without a host-side copy. */
+int jb_pack_weight(const void* src, int src_dtype, int64_t stride_k, int64_t stride_j, int K, int J,
+                   void* dst, int dst_dtype, void* stream);
+
+/* LayerNorm forward, fp32 statistics, affine.  Replaces apex `fused_layer_norm_cuda.forward_affine`
+ * (apex/csrc/layer_norm_cuda.cpp:234-238, kernel cuApplyLayerNorm layer_norm_cuda_kernel.cu:279-323) as used by
+ * jukebox/transformer/ops.py:14-24 (input cast to float, result cast back to the input dtype). */
+int jb_layernorm_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta,
+                     int64_t rows, int width, float eps, void* stream);
+
+/* Tiled MFMA GEMM over rows grouped in sequences, with optional input taps (conv1d k=3 dilated,
+ * strided conv k=4, transposed conv phases), fused input ReLU, bias, activation, residual.
+ *   for n < n_seq, t < t_out, j < J:
+ *     acc = sum_tap sum_k pre(A[n*in_seq_stride + (t*in_stride + shift[tap])][k]) * W_tap[k][j]      (rows outside [0,t_in) read as 0)
+ *     v   = act(round(acc + bias[j]));  if res: v = round(res[orow][j] + res_scale * v)
+ *     out[orow][j] = v,   orow = n*out_seq_stride + t*out_stride + out_offset
+ * Replaces t.addmm of Conv1D.forward for q_l > 1 (ops.py:97-101), nn.Conv1d / nn.ConvTranspose1d /
+ * ResConv1DBlock (jukebox/vqvae/encdec.py:17,21,35,40,108; resnet.py:27-44) and nn.Linear x_out
+ * (jukebox/prior/autoregressive.py:229,311) on channels-last rows.
+ * qkv_split: column j belongs to part j / S; part 0 goes to `out`, parts 1/2 go to the k/v caches at row
+ * n*cache_cap + cache_t0 + t when that is < cache_cap (FactoredAttention._append_cache, factored_attention.py:359-373). */
+typedef struct jb_gemm_args {
+    int dtype;                       /* of A, W (packed), out, res, kcache, vcache */
+    const void* A; int64_t lda;
+    const void* W; int64_t tap_stride;   /* packed image of tap i at W + i*tap_stride elements */
+    const float* bias;               /* [J] or NULL */
+    void* out; int64_t ldo;
+    const void* res; int64_t ldr;    /* or NULL */
+    int n_seq, t_in, t_out;
+    int64_t in_seq_stride, out_seq_stride;
+    int K, J;
+    int n_taps, in_stride; int shift[4];
+    int out_stride, out_offset;
+    int pre_relu, act;
+    float res_scale;
+    int qkv_split, S;
+    void* kcache; void* vcache; int cache_cap, cache_t0;
+} jb_gemm_args;
+int jb_gemm(const jb_gemm_args* args /* host */, void* stream);
+
+/* Weight-streaming skinny GEMM for the decode step (n_rows <= 64): out = act(LN?(x) @ W + b) (+ res),
+ * one workgroup per 16 output columns, waves split K.  With ln_gamma != NULL the LayerNorm of
+ * ResAttnBlock (ln_0 / ln_1, jukebox/transformer/transformer.py:62-66) is fused into the operand load.
+ * qkv_split as above with the cache row taken from *t_dev (device int), so the launch is replayable in a hipGraph. */
+typedef struct jb_gemv_args {
+    int dtype;
+    const void* x; int64_t ldx; int n_rows;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const void* W; const float* bias; int K, J;
+    void* out; int64_t ldo;
+    const void* res; int64_t ldr;
+    int act;
+    int qkv_split, S;
+    void* kcache; void* vcache; int cache_cap; const int* t_dev;
+} jb_gemv_args;
+int jb_gemv(const jb_gemv_args* args /* host */, void* stream);
+
+/* Single-query cached attention for the decode step: one workgroup per (sample, head); the key
+ * set is derived on the device from *t_dev and the pattern, softmax in fp32.
+ * Replaces FactoredAttention.forward(sample=True) with q_l == 1: factored_qkv/prime_qkv cache slicing +
+ * block/transpose/prev/prime/dense pattern functions + _attn (factored_attention.py:82-108,123-193,220-271).
+ * q: [n][n_head*d_head] rows of ldq; caches [n][cache_cap][S]; out [n][S]. */
+int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache,
+                   int cache_cap, void* out, int64_t ldo, int n_batch, int n_head, int d_head,
+                   int block_ctx, const int* t_dev, int max_len, void* stream);
+
+/* Chunked-prefill attention (q_l > 1) on MFMA with LDS-staged k/v tiles and online softmax:
+ * queries at positions t0 .. t0+n_q-1 against the caches (already holding those positions).
+ * Replaces FactoredAttention.forward(sample=True) with q_l > 1 -- _pad_to_block_ctx, the masked
+ * pattern functions and get_mask (factored_attention.py:15-28,135-193,240-249,310-323).
+ * q, out: [n][n_q][S]. */
+int jb_attn_prefill(int dtype, int attn_func, const void* q, const void* kcache, const void* vcache, int cache_cap,
+                    void* out, int n_batch, int n_head, int d_head, int block_ctx, int t0, int n_q, void* stream);
+
+/* Token/start embedding + position embedding + conditioning for positions t0..t0+n_t-1
+ * (t0 taken from *t_dev when t_dev != NULL).  ConditionalAutoregressive2D.get_emb,
+ * jukebox/prior/autoregressive.py:177-197.  tokens [n][tok_stride] int64 holds the token of
+ * position t at column t; start [n] rows of start_stride floats (y_cond, or start_token with stride 0);
+ * x_cond [n][*][width] with time stride xc_t_stride (0 when broadcast).  out [n][n_t][width]. */
+int jb_embed(int out_dtype, void* out, const int64_t* tokens, int64_t tok_stride, const float* x_emb,
+             const float* pos_emb, const float* start, int64_t start_stride, const float* x_cond,
+             int64_t xc_n_stride, int64_t xc_t_stride, int n_batch, int width, int t0, const int* t_dev, int n_t,
+             void* stream);
+
+/* xf = float(h) + x_cond[:, t] (add_cond_after_transformer, autoregressive.py:226-227,307-309). */
+int jb_final_add(int h_dtype, const void* h, float* xf, const float* x_cond, int64_t xc_n_stride,
+                 int64_t xc_t_stride, int n_batch, int width, int t0, const int* t_dev, int n_t, void* stream);
+
+/* Temperature, top-k / nucleus filtering and categorical sampling of one token per row, written to
+ * tokens[n][t] (t = *t_dev); optional copy of the raw logits to preds[n][t][bins].
+ * autoregressive.py:233-235 + filter_logits (jukebox/transformer/ops.py:113-142).  Randomness is a
+ * counter-based stream keyed by (seed, sample_base + n, t); top_k == 1 is argmax (lowest index on ties). */
+typedef struct jb_sample_params { float temp; int top_k; float top_p; int sample_base; uint64_t seed; } jb_sample_params;
+int jb_sample_logits(const float* logits, int n_batch, int bins, const jb_sample_params* params /* device */,
+                     int64_t* tokens, int64_t tok_stride, const int* t_dev, float* preds, int64_t preds_n_stride,
+                     void* stream);
+
+/* Codebook gather (BottleneckBlock.dequantise/decode, jukebox/vqvae/bottleneck.py:121-123,138-147),
+ * output channels-last rows [n*T][emb_width] fp32. */
+int jb_vq_gather(const int64_t* codes, const float* codebook, float* out, int64_t n_codes, int emb_width, int bins,
+                 void* stream);
+
+/* Nearest-code search: argmin_j ||x||^2 - 2 x.k_j + ||k_j||^2 given xk = x @ k^T
+ * (BottleneckBlock.quantise, bottleneck.py:112-119). */
+int jb_vq_argmin(const float* x, const float* xk, const float* codebook, int64_t* codes, int64_t rows,
+                 int emb_width, int bins, void* stream);
+
+/* ---- decode engine: one prior's transformer bound to static buffers ------------------------------ */
+typedef struct jb_layer {
+    int attn_func;
+    const void *w_attn, *w_proj, *w_fc, *w_proj2;          /* packed, engine dtype */
+    const float *b_attn, *b_proj, *b_fc, *b_proj2;
+    const float *ln0_g, *ln0_b, *ln1_g, *ln1_b;
+    void *kcache, *vcache;                                 /* [n_batch][cache_cap][n_state], engine dtype */
+    int cache_cap;
+} jb_layer;
+
+typedef struct jb_engine_cfg {
+    int dtype, n_batch, width, n_state, n_head, n_mlp, n_layers;
+    int seq_len, block_ctx, bins;
+    float ln_eps;
+    const float *x_emb, *pos_emb;
+    const float* x_out_packed;                             /* fp32 packed (K = width, J = bins) */
+    const float* start; int64_t start_stride;
+    const float* x_cond; int64_t xc_n_stride, xc_t_stride;
+    int add_cond_after;
+    /* decode-step work buffers */
+    void *x_a, *x_b, *q, *att, *mlp;                        /* engine dtype: [n][W],[n][W],[n][S],[n][S],[n][M] */
+    float *xf, *logits;                                    /* [n][W], [n][bins] */
+    /* prefill work buffers for chunks of <= chunk_cap positions */
+    int chunk_cap;
+    void *c_xa, *c_xb, *c_h, *c_q, *c_att, *c_mlp;          /* [n*chunk_cap][W|W|W|S|S|M] */
+    float* c_xf;                                           /* [n*chunk_cap][W] (only when preds != NULL) */
+    int64_t* tokens; int64_t tok_stride;
+    int* t_dev;
+    float* preds; int64_t preds_n_stride;                  /* optional [n][seq_len][bins] */
+    const jb_sample_params* sample_params;                 /* device */
+} jb_engine_cfg;
+
+/* Transformer.forward(sample=True) + the token loop of ConditionalAutoregressive2D.sample/primed_sample
+ * (jukebox/transformer/transformer.py:169-192, jukebox/prior/autoregressive.py:222-236,289-347). */
+int jb_engine_create(const jb_engine_cfg* cfg /* host */, const jb_layer* layers /* host array */, void** handle);
+int jb_engine_destroy(void* handle);
+/* Prefill positions t0..t0+n_t-1 (tokens already in cfg.tokens): fills the k/v caches, leaves *t_dev = t0+n_t. */
+int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
+/* Run n_steps decode steps starting at position t0 (sets *t_dev = t0 first).  use_graph != 0 captures one step
+ * into a hipGraph on first use and replays it. */
+int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
+/* Number of kernel launches in one decode step (for launch-overhead accounting). */
+int jb_engine_launches_per_step(void* handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,123 @@
+"""ctypes binding of libjukebox_hip.so (the C ABI declared in include/jukebox_hip.h).
+
+The product path has no CPU fallback: if the shared object is missing or a symbol cannot be
+resolved, `lib()` raises.  Build it with `python -m jukebox_amd.csrc.build` or
+`__graft_entry__.build()`.
+"""
+import ctypes as C
+import os
+
+F32, F16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_QUICK_GELU = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libjukebox_hip.so")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("A", vp), ("lda", i64), ("W", vp), ("tap_stride", i64), ("bias", vp),
+                ("out", vp), ("ldo", i64), ("res", vp), ("ldr", i64),
+                ("n_seq", i32), ("t_in", i32), ("t_out", i32), ("in_seq_stride", i64), ("out_seq_stride", i64),
+                ("K", i32), ("J", i32), ("n_taps", i32), ("in_stride", i32), ("shift", i32 * 4),
+                ("out_stride", i32), ("out_offset", i32), ("pre_relu", i32), ("act", i32), ("res_scale", f32),
+                ("qkv_split", i32), ("S", i32), ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("cache_t0", i32)]
+
+
+class GemvArgs(C.Structure):
+    _fields_ = [("dtype", i32), ("x", vp), ("ldx", i64), ("n_rows", i32),
+                ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
+                ("W", vp), ("bias", vp), ("K", i32), ("J", i32), ("out", vp), ("ldo", i64),
+                ("res", vp), ("ldr", i64), ("act", i32), ("qkv_split", i32), ("S", i32),
+                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp)]
+
+
+class SampleParams(C.Structure):
+    _fields_ = [("temp", f32), ("top_k", i32), ("top_p", f32), ("sample_base", i32), ("seed", C.c_uint64)]
+
+
+class Layer(C.Structure):
+    _fields_ = [("attn_func", i32), ("w_attn", vp), ("w_proj", vp), ("w_fc", vp), ("w_proj2", vp),
+                ("b_attn", vp), ("b_proj", vp), ("b_fc", vp), ("b_proj2", vp),
+                ("ln0_g", vp), ("ln0_b", vp), ("ln1_g", vp), ("ln1_b", vp),
+                ("kcache", vp), ("vcache", vp), ("cache_cap", i32)]
+
+
+class EngineCfg(C.Structure):
+    _fields_ = [("dtype", i32), ("n_batch", i32), ("width", i32), ("n_state", i32), ("n_head", i32), ("n_mlp", i32),
+                ("n_layers", i32), ("seq_len", i32), ("block_ctx", i32), ("bins", i32), ("ln_eps", f32),
+                ("x_emb", vp), ("pos_emb", vp), ("x_out_packed", vp), ("start", vp), ("start_stride", i64),
+                ("x_cond", vp), ("xc_n_stride", i64), ("xc_t_stride", i64), ("add_cond_after", i32),
+                ("x_a", vp), ("x_b", vp), ("q", vp), ("att", vp), ("mlp", vp), ("xf", vp), ("logits", vp),
+                ("chunk_cap", i32), ("c_xa", vp), ("c_xb", vp), ("c_h", vp), ("c_q", vp), ("c_att", vp),
+                ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
+                ("preds", vp), ("preds_n_stride", i64), ("sample_params", vp)]
+
+
+_SIGS = {
+    "jb_last_error": (C.c_char_p, []),
+    "jb_version": (i32, []),
+    "jb_packed_weight_bytes": (i64, [i32, i32, i32]),
+    "jb_pack_weight": (i32, [vp, i32, i64, i64, i32, i32, vp, i32, vp]),
+    "jb_layernorm_fwd": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, f32, vp]),
+    "jb_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "jb_gemv": (i32, [C.POINTER(GemvArgs), vp]),
+    "jb_attn_decode": (i32, [i32, i32, vp, i64, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
+    "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "jb_embed": (i32, [i32, vp, vp, i64, vp, vp, vp, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
+    "jb_final_add": (i32, [i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
+    "jb_sample_logits": (i32, [vp, i32, i32, vp, vp, i64, vp, vp, i64, vp]),
+    "jb_vq_gather": (i32, [vp, vp, vp, i64, i32, i32, vp]),
+    "jb_vq_argmin": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
+    "jb_engine_create": (i32, [C.POINTER(EngineCfg), C.POINTER(Layer), C.POINTER(vp)]),
+    "jb_engine_destroy": (i32, [vp]),
+    "jb_engine_prefill": (i32, [vp, i32, i32, vp]),
+    "jb_engine_decode": (i32, [vp, i32, i32, i32, vp]),
+    "jb_engine_launches_per_step": (i32, [vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+class JukeboxHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library with argument types set.  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JukeboxHipError(f"{LIB_PATH} is missing: build the HIP extension first "
+                                  "(python -m jukebox_amd.csrc.build); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)          # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise JukeboxHipError(f"libjukebox_hip status {rc}: {lib().jb_last_error().decode()}")
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float16:
+        return F16
+    if torch_dtype == torch.float32:
+        return F32
+    raise JukeboxHipError(f"unsupported dtype {torch_dtype}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,418 @@
+// Pattern-aware cached attention for gfx950.
+//
+// Cache layout in HBM: per layer K and V are [sample][position][n_state] rows of the engine dtype,
+// full length (cache_cap = sequence length; prime layers cache_cap = rounded prime length).  The
+// reference trims its caches per pattern (factored_attention.py:328-353) to save V100 memory; with
+// 288 GB the full-length cache lets every pattern be a closed-form index set over one array
+// (SURVEY.md Appendix B): a contiguous tail (dense / block / prev / prime) or a stride-block_ctx
+// gather (transpose).
+#include "common.h"
+
+// key set of the single query at position t: positions start + i*stride, i < count
+struct KeySet { int start, stride, count; };
+
+__device__ __forceinline__ KeySet decode_key_set(int func, int t, int bc, int cap) {
+    KeySet k{0, 1, 0};
+    switch (func) {
+        case JB_ATTN_DENSE: k.count = t + 1; break;
+        case JB_ATTN_BLOCK: k.start = (t / bc) * bc; k.count = t - k.start + 1; break;
+        case JB_ATTN_TRANSPOSE_BLOCK: k.start = t % bc; k.stride = bc; k.count = t / bc + 1; break;
+        case JB_ATTN_PREV_BLOCK: {
+            int blk = t / bc;
+            if (blk > 0) { k.start = (blk - 1) * bc; k.count = bc; }   // block 0: zero rows -> output 0
+            break;
+        }
+        case JB_ATTN_PRIME: k.count = min(t + 1, cap); break;
+        case JB_ATTN_CROSS: k.count = cap; break;
+    }
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode (q_l == 1).  One workgroup per (sample, head).  Phase 1: each wave takes whole key rows
+// (a row is d_head * sizeof(T) <= 1-2 KiB, i.e. one or two fully coalesced wave loads), dots them
+// with the query held in registers and wave-reduces; scores go to LDS.  Softmax over the LDS row
+// in fp32.  Phase 2: waves stride over the keys accumulating p_i * v_i into per-lane channel
+// slices, then the per-wave partial outputs are summed in a fixed order through LDS.
+// HBM/L2-bound GEMV per sample: MFMA has no reuse to exploit here (one query row), so this runs on
+// the vector ALU with fully coalesced row loads; the prefill kernel below is the MFMA one.
+template <typename T, int NCH>
+__global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ldq, const T* __restrict__ kc,
+                                   const T* __restrict__ vc, int cap, T* __restrict__ out, int64_t ldo, int n_head,
+                                   int d, int bc, const int* __restrict__ t_dev, int max_len) {
+    constexpr int E = Frag<T>::E;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nw = blockDim.x >> 6;
+    float* s_p = smem;                       // [max_len] scores -> probabilities
+    float* s_red = smem + max_len;           // [nw] block-reduction scratch (+1 result slot)
+    float* s_o = s_red + 32;                 // [nw][d] partial outputs
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x, h = blockIdx.y;
+    const int S = n_head * d;
+    const int t = *t_dev;
+    const KeySet ks = decode_key_set(func, t, bc, cap);
+    T* o = out + (int64_t)n * ldo + h * d;
+    if (ks.count == 0) {
+        for (int i = threadIdx.x; i < d; i += blockDim.x) o[i] = (T)0;
+        return;
+    }
+    const float scale = 1.0f / sqrtf(sqrtf((float)d));
+    const float scale2 = scale * scale;
+
+    // query slice of this lane: channels (ch*64 + lane)*E .. +E
+    float qf[NCH][E];
+    const T* qrow = q + (int64_t)n * ldq + h * d;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            int i = (ch * 64 + lane) * E + e;
+            qf[ch][e] = i < d ? (float)qrow[i] : 0.f;
+        }
+    const bool vec = (d % E == 0) && (S % E == 0);
+    const T* kbase = kc + ((int64_t)n * cap) * S + h * d;
+    const T* vbase = vc + ((int64_t)n * cap) * S + h * d;
+
+    for (int i = wave; i < ks.count; i += nw) {
+        const T* kr = kbase + (int64_t)(ks.start + i * ks.stride) * S;
+        float part = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            int c0 = (ch * 64 + lane) * E;
+            if (vec && c0 + E <= d) {
+                typename Frag<T>::vec kv = *reinterpret_cast<const typename Frag<T>::vec*>(kr + c0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) part += qf[ch][e] * (float)kv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (c0 + e < d) part += qf[ch][e] * (float)kr[c0 + e];
+            }
+        }
+        part = jb_wave_sum(part);
+        // reference: w = matmul(q, k) (half result), w.mul_(scale*scale) (half), then .float()
+        if (lane == 0) s_p[i] = jb_round<T>(jb_round<T>(part) * scale2);
+    }
+    __syncthreads();
+
+    // softmax over s_p[0..count) in fp32
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < ks.count; i += blockDim.x) m = fmaxf(m, s_p[i]);
+    m = jb_wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, s_red[w]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < ks.count; i += blockDim.x) {
+        float e = expf(s_p[i] - m);
+        s_p[i] = e;
+        sum += e;
+    }
+    sum = jb_wave_sum(sum);
+    if (lane == 0) s_red[wave] = sum;
+    __syncthreads();
+    sum = 0.f;
+    for (int w = 0; w < nw; ++w) sum += s_red[w];
+    const float inv = 1.0f / sum;
+    __syncthreads();
+
+    // out = sum_i round(p_i) * v_i, fp32 accumulation
+    float of[NCH][E];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int e = 0; e < E; ++e) of[ch][e] = 0.f;
+    for (int i = wave; i < ks.count; i += nw) {
+        const T* vr = vbase + (int64_t)(ks.start + i * ks.stride) * S;
+        const float pi = jb_round<T>(s_p[i] * inv);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            int c0 = (ch * 64 + lane) * E;
+            if (vec && c0 + E <= d) {
+                typename Frag<T>::vec vv = *reinterpret_cast<const typename Frag<T>::vec*>(vr + c0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) of[ch][e] += pi * (float)vv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (c0 + e < d) of[ch][e] += pi * (float)vr[c0 + e];
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            int i = (ch * 64 + lane) * E + e;
+            if (i < d) s_o[wave * d + i] = of[ch][e];
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += s_o[w * d + i];
+        o[i] = (T)a;
+    }
+}
+
+extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache,
+                              const void* vcache, int cache_cap, void* out, int64_t ldo, int n_batch, int n_head,
+                              int d_head, int block_ctx, const int* t_dev, int max_len, void* stream) {
+    JB_REQUIRE(q && kcache && vcache && out && t_dev, "null pointer");
+    JB_REQUIRE(dtype == JB_F32 || dtype == JB_F16, "bad dtype");
+    JB_REQUIRE(n_batch > 0 && n_head > 0 && d_head > 0 && max_len > 0, "bad dims");
+    JB_REQUIRE(attn_func == 0 || attn_func == 7 || attn_func == 6 || block_ctx > 0, "block_ctx required");
+    const int E = dtype == JB_F16 ? 8 : 4;
+    const int nch = (d_head + 64 * E - 1) / (64 * E);
+    if (nch > 2) JB_UNSUPPORTED("d_head too large for the decode attention kernel");
+    // long (dense) rows get 16 waves to keep more row loads in flight; short patterns 4
+    const int threads = (attn_func == JB_ATTN_DENSE && max_len > 1024) ? 1024 : 256;
+    const int nw = threads / 64;
+    size_t lds = (size_t)(max_len + 32 + nw * d_head) * sizeof(float);
+    if (lds > 160 * 1024) JB_UNSUPPORTED("sequence too long for the LDS score row");
+    dim3 grid(n_batch, n_head);
+    hipStream_t s = (hipStream_t)stream;
+#define JB_LAUNCH_DEC(T, NCH)                                                                                   \
+    do {                                                                                                        \
+        if (lds > 64 * 1024)                                                                                    \
+            JB_HIP(hipFuncSetAttribute((const void*)attn_decode_kernel<T, NCH>,                                 \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        attn_decode_kernel<T, NCH><<<grid, threads, lds, s>>>(attn_func, (const T*)q, ldq, (const T*)kcache,    \
+                                                              (const T*)vcache, cache_cap, (T*)out, ldo, n_head, \
+                                                              d_head, block_ctx, t_dev, max_len);               \
+    } while (0)
+    if (dtype == JB_F16) { if (nch == 1) JB_LAUNCH_DEC(f16, 1); else JB_LAUNCH_DEC(f16, 2); }
+    else { if (nch == 1) JB_LAUNCH_DEC(float, 1); else JB_LAUNCH_DEC(float, 2); }
+#undef JB_LAUNCH_DEC
+    JB_CHECK_LAUNCH();
+    return JB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefill (q_l > 1): one wave per tile of 16 queries, flash-style online softmax over KT-key steps.
+//
+//   S^T = K Q^T   on MFMA with A = K tile [16 keys x d] (LDS-staged), B = Q^T (LDS-staged):
+//                 lane l then holds, for query col l&15, the scores of keys (l>>4)*4 + r -- so the
+//                 row reductions of the softmax are 3 in-lane ops + 2 cross-lane shuffles.
+//   O^T += V^T P^T on MFMA with A = V^T [16 channels x KT keys] read from the LDS-staged V tile and
+//                 B = P^T, whose fragment is exactly the registers the lane already holds once the
+//                 MFMA k-slot <-> key assignment is chosen as slot (g, e) <-> key g*4 + (e&3) + 16*(e>>2).
+//
+// Query tiles: 16 consecutive positions (dense / block / prev / prime) or 16 consecutive members of one
+// residue class mod block_ctx (transpose); the per-element mask is the closed-form rule of the pattern.
+template <typename T, int ND16>
+__global__ __launch_bounds__(64) void attn_prefill_kernel(int func, const T* __restrict__ q, const T* __restrict__ kc,
+                                                          const T* __restrict__ vc, int cap, T* __restrict__ out,
+                                                          int n_head, int d, int bc, int t0, int nq, int tiles_per_class) {
+    using V = typename Frag<T>::vec;
+    constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
+    constexpr int DP = ND16 * 16;            // padded head dim
+    constexpr int LDR = DP + E;              // LDS row stride (elements), breaks the power-of-two stride
+    constexpr int NG = KT / 16;              // 16-key score groups per step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sQ = reinterpret_cast<T*>(smem_raw);  // [16][LDR]
+    T* sK = sQ + 16 * LDR;                   // [KT][LDR]
+    T* sV = sK + KT * LDR;                   // [KT][LDR]
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int tile = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+    const int S = n_head * d;
+
+    // ---- which queries / keys does this tile cover -------------------------------------------
+    int qpos0, qstep, nvalid;                // query r sits at position qpos0 + r*qstep, r < nvalid
+    int kstart, kstep, nkeys;                // candidate key u sits at position kstart + u*kstep
+    if (func == JB_ATTN_TRANSPOSE_BLOCK) {
+        int cls = tile / tiles_per_class, it = tile % tiles_per_class;
+        int first = t0 + ((cls - t0 % bc) + bc) % bc;        // first position >= t0 in class cls
+        qpos0 = first + it * 16 * bc; qstep = bc;
+        int last = t0 + nq - 1;
+        nvalid = qpos0 > last ? 0 : min(16, (last - qpos0) / bc + 1);
+        kstart = cls; kstep = bc;
+        nkeys = nvalid > 0 ? (qpos0 + (nvalid - 1) * bc) / bc + 1 : 0;
+    } else {
+        qpos0 = t0 + tile * 16; qstep = 1;
+        nvalid = min(16, t0 + nq - qpos0);
+        int pmax = qpos0 + nvalid - 1;
+        kstep = 1;
+        if (func == JB_ATTN_DENSE) { kstart = 0; nkeys = pmax + 1; }
+        else if (func == JB_ATTN_BLOCK) { kstart = (qpos0 / bc) * bc; nkeys = pmax - kstart + 1; }
+        else if (func == JB_ATTN_PREV_BLOCK) {
+            int b0 = qpos0 / bc, b1 = pmax / bc;
+            kstart = max(b0 - 1, 0) * bc;
+            nkeys = b1 * bc - kstart;       // keys up to the end of block b1-1; <= 0 when b1 == 0
+        } else if (func == JB_ATTN_PRIME) { kstart = 0; nkeys = min(pmax + 1, cap); }
+        else { kstart = 0; nkeys = cap; }   // cross attention: every encoder position
+    }
+    if (nvalid <= 0) return;
+    const int my_q = qpos0 + c * qstep;      // position of this lane's query column (may be invalid)
+    const bool q_ok = c < nvalid;
+
+    // ---- stage the query tile -----------------------------------------------------------------
+    const int dvec = d / E;                  // 16-byte chunks per row (vector path requires d % E == 0)
+    const bool vec = (d % E == 0) && (S % E == 0);
+    for (int r = 0; r < 16; ++r) {
+        const bool rok = r < nvalid;
+        const T* src = q + ((int64_t)n * nq + (qpos0 + r * qstep - t0)) * S + h * d;
+        for (int i = lane; i < DP; i += 64) sQ[r * LDR + i] = (rok && i < d) ? src[i] : (T)0;
+    }
+    (void)dvec; (void)vec;
+
+    f32x4 oacc[ND16];
+#pragma unroll
+    for (int i = 0; i < ND16; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float scale = 1.0f / sqrtf(sqrtf((float)d));
+    const float scale2 = scale * scale;
+    const T* kbase = kc + ((int64_t)n * cap) * S + h * d;
+    const T* vbase = vc + ((int64_t)n * cap) * S + h * d;
+
+    for (int u0 = 0; u0 < nkeys; u0 += KT) {
+        __syncthreads();                      // previous step's LDS reads done (single wave: cheap)
+        // ---- stage K and V tiles: KT rows of d channels, coalesced along the row --------------
+        for (int r = 0; r < KT; ++r) {
+            const int u = u0 + r;
+            const bool rok = u < nkeys;
+            const int64_t pos = kstart + (int64_t)u * kstep;
+            const T* ks = kbase + pos * S;
+            const T* vs = vbase + pos * S;
+            for (int i = lane; i < DP; i += 64) {
+                const bool ok = rok && i < d;
+                sK[r * LDR + i] = ok ? ks[i] : (T)0;
+                sV[r * LDR + i] = ok ? vs[i] : (T)0;
+            }
+        }
+        __syncthreads();
+
+        // ---- scores: S^T[key][q] for NG groups of 16 keys --------------------------------------
+        f32x4 sc[NG];
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) sc[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dk = 0; dk < DP; dk += KT) {
+            if (dk >= d) break;
+            V qfrag;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                int ch = dk + g * E + e;
+                qfrag[e] = ch < DP ? sQ[c * LDR + ch] : (T)0;
+            }
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                V kfrag;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    int ch = dk + g * E + e;
+                    kfrag[e] = ch < DP ? sK[(gi * 16 + c) * LDR + ch] : (T)0;
+                }
+                sc[gi] = jb_mfma(kfrag, qfrag, sc[gi]);
+            }
+        }
+        // ---- mask + online softmax (lane: query column c, keys gi*16 + g*4 + r) ------------------
+        float pv[NG][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = u0 + gi * 16 + g * 4 + r;
+                const int j = kstart + u * kstep;
+                bool ok = q_ok && u < nkeys;
+                if (ok) {
+                    switch (func) {
+                        case JB_ATTN_DENSE: case JB_ATTN_PRIME: case JB_ATTN_TRANSPOSE_BLOCK: ok = j <= my_q; break;
+                        case JB_ATTN_BLOCK: ok = j <= my_q && (j / bc) == (my_q / bc); break;
+                        case JB_ATTN_PREV_BLOCK: ok = (j / bc) == (my_q / bc) - 1; break;
+                        default: break;
+                    }
+                }
+                float sv = jb_round<T>(jb_round<T>(sc[gi][r]) * scale2);
+                pv[gi][r] = ok ? sv : -INFINITY;
+                mx = fmaxf(mx, pv[gi][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_new == -INFINITY) ? 1.0f : expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pe = (pv[gi][r] == -INFINITY) ? 0.f : expf(pv[gi][r] - m_new);
+                pv[gi][r] = pe;
+                psum += pe;
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        V pfrag;                              // B operand: slot (g, e) <-> key g*4 + (e&3) + 16*(e>>2)
+#pragma unroll
+        for (int e = 0; e < E; ++e) pfrag[e] = (T)pv[e >> 2][e & 3];
+#pragma unroll
+        for (int i = 0; i < ND16; ++i) {
+            oacc[i] *= alpha;
+            V vfrag;                          // A operand: channel row i*16 + c, same slot <-> key map
+#pragma unroll
+            for (int e = 0; e < E; ++e) vfrag[e] = sV[(g * 4 + (e & 3) + 16 * (e >> 2)) * LDR + i * 16 + c];
+            oacc[i] = jb_mfma(vfrag, pfrag, oacc[i]);
+        }
+    }
+
+    // ---- normalise and store: lane holds query c, channels i*16 + g*4 + r ---------------------------
+    if (!q_ok) return;
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;   // no admissible key (prev-block in block 0) -> 0
+    T* orow = out + ((int64_t)n * nq + (my_q - t0)) * S + h * d;
+#pragma unroll
+    for (int i = 0; i < ND16; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int ch = i * 16 + g * 4 + r;
+            if (ch < d) orow[ch] = (T)(oacc[i][r] * inv);
+        }
+}
+
+extern "C" int jb_attn_prefill(int dtype, int attn_func, const void* q, const void* kcache, const void* vcache,
+                               int cache_cap, void* out, int n_batch, int n_head, int d_head, int block_ctx, int t0,
+                               int n_q, void* stream) {
+    JB_REQUIRE(q && kcache && vcache && out, "null pointer");
+    JB_REQUIRE(dtype == JB_F32 || dtype == JB_F16, "bad dtype");
+    JB_REQUIRE(n_batch > 0 && n_head > 0 && d_head > 0 && n_q > 0 && t0 >= 0, "bad dims");
+    JB_REQUIRE(attn_func == 0 || attn_func == 7 || attn_func == 6 || block_ctx > 0, "block_ctx required");
+    int tiles, tpc = 1;
+    if (attn_func == JB_ATTN_TRANSPOSE_BLOCK) {
+        int per_class = (n_q + block_ctx - 1) / block_ctx;     // max members of one residue class in the chunk
+        tpc = (per_class + 15) / 16;
+        tiles = block_ctx * tpc;
+    } else {
+        tiles = (n_q + 15) / 16;
+    }
+    const int nd16 = (d_head + 15) / 16;
+    const int esz = dtype == JB_F16 ? 2 : 4, E = dtype == JB_F16 ? 8 : 4, KT = dtype == JB_F16 ? 32 : 16;
+    dim3 grid(tiles, n_head, n_batch);
+    hipStream_t s = (hipStream_t)stream;
+#define JB_LAUNCH_PF(T, ND)                                                                                         \
+    do {                                                                                                            \
+        size_t lds = (size_t)(16 + 2 * KT) * (ND * 16 + E) * esz;                                                   \
+        if (lds > 64 * 1024)                                                                                        \
+            JB_HIP(hipFuncSetAttribute((const void*)attn_prefill_kernel<T, ND>,                                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+        attn_prefill_kernel<T, ND><<<grid, 64, lds, s>>>(attn_func, (const T*)q, (const T*)kcache, (const T*)vcache, \
+                                                         cache_cap, (T*)out, n_head, d_head, block_ctx, t0, n_q, tpc); \
+    } while (0)
+#define JB_DISPATCH_PF(T)                                         \
+    do {                                                          \
+        if (nd16 <= 1) JB_LAUNCH_PF(T, 1);                        \
+        else if (nd16 <= 2) JB_LAUNCH_PF(T, 2);                   \
+        else if (nd16 <= 4) JB_LAUNCH_PF(T, 4);                   \
+        else if (nd16 <= 8) JB_LAUNCH_PF(T, 8);                   \
+        else if (nd16 <= 10) JB_LAUNCH_PF(T, 10);                 \
+        else if (nd16 <= 16) JB_LAUNCH_PF(T, 16);                 \
+        else if (nd16 <= 30) JB_LAUNCH_PF(T, 30);                 \
+        else JB_UNSUPPORTED("d_head > 480");                      \
+    } while (0)
+    if (dtype == JB_F16) JB_DISPATCH_PF(f16); else JB_DISPATCH_PF(float);
+#undef JB_DISPATCH_PF
+#undef JB_LAUNCH_PF
+    JB_CHECK_LAUNCH();
+    return JB_OK;
+}

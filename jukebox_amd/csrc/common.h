@@ -1,0 +1,116 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA fragments, half rounding).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/jukebox_hip.h"
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define JB_WAVE 64
+
+// ---- host-side error plumbing --------------------------------------------------------------
+void jb_set_error(const std::string& msg);
+#define JB_REQUIRE(cond, msg)                                              \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            jb_set_error(std::string(__func__) + ": " + (msg));            \
+            return JB_ERR_ARG;                                             \
+        }                                                                  \
+    } while (0)
+#define JB_UNSUPPORTED(msg)                                                \
+    do {                                                                   \
+        jb_set_error(std::string(__func__) + ": " + (msg));                \
+        return JB_ERR_UNSUPPORTED;                                         \
+    } while (0)
+#define JB_CHECK_LAUNCH()                                                  \
+    do {                                                                   \
+        hipError_t e__ = hipGetLastError();                                \
+        if (e__ != hipSuccess) {                                           \
+            jb_set_error(std::string(__func__) + ": " + hipGetErrorString(e__)); \
+            return JB_ERR_HIP;                                             \
+        }                                                                  \
+    } while (0)
+#define JB_HIP(call)                                                       \
+    do {                                                                   \
+        hipError_t e__ = (call);                                           \
+        if (e__ != hipSuccess) {                                           \
+            jb_set_error(std::string(__func__) + ": " #call ": " + hipGetErrorString(e__)); \
+            return JB_ERR_HIP;                                             \
+        }                                                                  \
+    } while (0)
+
+static inline int jb_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- per-dtype MFMA fragment description ---------------------------------------------------
+// One MFMA "k-tile" holds KT contraction elements; lane l owns E consecutive ones starting at
+// (l >> 4) * E, for row/col (l & 15) of its operand.  f16: v_mfma_f32_16x16x32_f16 (one
+// instruction per k-tile).  f32: four v_mfma_f32_16x16x4_f32, element e of the fragment feeding
+// the e-th instruction -- exact fp32 (an fmaf chain), used for the parity mode and the conv stacks.
+template <typename T> struct Frag;
+template <> struct Frag<f16> {
+    typedef f16x8 vec;
+    static constexpr int E = 8, KT = 32;
+};
+template <> struct Frag<float> {
+    typedef f32x4 vec;
+    static constexpr int E = 4, KT = 16;
+};
+
+__device__ __forceinline__ f32x4 jb_mfma(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 jb_mfma(f32x4 a, f32x4 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+}
+
+template <typename T> __device__ __forceinline__ typename Frag<T>::vec jb_zero_frag() {
+    typename Frag<T>::vec v;
+#pragma unroll
+    for (int e = 0; e < Frag<T>::E; ++e) v[e] = (T)0;
+    return v;
+}
+
+// Round an fp32 value to the storage type and back (models "this tensor is half in the reference").
+template <typename T> __device__ __forceinline__ float jb_round(float x);
+template <> __device__ __forceinline__ float jb_round<float>(float x) { return x; }
+template <> __device__ __forceinline__ float jb_round<f16>(float x) { return (float)(f16)x; }
+
+__device__ __forceinline__ float jb_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// quick_gelu (jukebox/transformer/ops.py:33-35): x * sigmoid(1.702 x); each op rounds in half mode.
+template <typename T> __device__ __forceinline__ float jb_quick_gelu(float x) {
+    float u = jb_round<T>(1.702f * x);
+    float s = jb_round<T>(1.0f / (1.0f + expf(-u)));
+    return jb_round<T>(x * s);
+}
+
+template <typename T> __device__ __forceinline__ float jb_apply_act(float v, int act) {
+    if (act == JB_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == JB_ACT_QUICK_GELU) return jb_quick_gelu<T>(v);
+    return v;
+}
+
+__device__ __forceinline__ float jb_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float jb_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float jb_load_any(const void* p, int dtype, int64_t i) {
+    return dtype == JB_F16 ? (float)((const f16*)p)[i] : ((const float*)p)[i];
+}

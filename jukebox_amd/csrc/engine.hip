@@ -1,0 +1,210 @@
+// Decode engine: one prior's transformer bound to static device buffers.
+//
+// Drives Transformer.forward(sample=True) (jukebox/transformer/transformer.py:169-192) and the token loops of
+// ConditionalAutoregressive2D.sample / primed_sample (jukebox/prior/autoregressive.py:222-236,289-347):
+//   decode step  = embed -> L x [LN0+c_attn(+k/v append) | attention | c_proj+res | LN1+c_fc+gelu | c_proj+res]
+//                  -> (+cond) -> logits -> sample -> t += 1          (5 L + 5 launches, one hipGraph)
+//   prefill      = the same per layer on a chunk of positions with the tiled GEMM and the MFMA attention.
+// The position t lives in device memory (*t_dev) so that the captured graph is replayable for every step.
+#include <vector>
+
+#include "common.h"
+
+struct JbEngine {
+    jb_engine_cfg cfg;
+    std::vector<jb_layer> layers;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_stream = nullptr;
+    int launches_per_step = 0;
+};
+
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+__global__ void inc_int_kernel(int* p) { *p += 1; }
+
+static size_t esize(int dtype) { return dtype == JB_F16 ? 2 : 4; }
+
+extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers, void** handle) {
+    JB_REQUIRE(cfg && layers && handle, "null pointer");
+    JB_REQUIRE(cfg->dtype == JB_F32 || cfg->dtype == JB_F16, "bad dtype");
+    JB_REQUIRE(cfg->n_batch >= 1 && cfg->n_batch <= 64, "n_batch must be 1..64");
+    JB_REQUIRE(cfg->width > 0 && cfg->n_state > 0 && cfg->n_head > 0 && cfg->n_mlp > 0 && cfg->n_layers > 0, "bad dims");
+    JB_REQUIRE(cfg->n_state % cfg->n_head == 0, "n_state must divide by n_head");
+    JB_REQUIRE(cfg->seq_len > 0 && cfg->bins > 0, "bad seq_len / bins");
+    JB_REQUIRE(cfg->x_emb && cfg->pos_emb && cfg->x_out_packed && cfg->start, "missing embedding tables");
+    JB_REQUIRE(cfg->x_a && cfg->x_b && cfg->q && cfg->att && cfg->mlp && cfg->xf && cfg->logits, "missing decode buffers");
+    JB_REQUIRE(cfg->tokens && cfg->t_dev && cfg->sample_params, "missing token / counter / sampler buffers");
+    for (int l = 0; l < cfg->n_layers; ++l) {
+        const jb_layer& L = layers[l];
+        JB_REQUIRE(L.attn_func == 0 || L.attn_func == 1 || L.attn_func == 2 || L.attn_func == 3 || L.attn_func == 7,
+                   "unsupported attn_func (cross attention is SURVEY 8f item 3)");
+        JB_REQUIRE(L.attn_func == 0 || L.attn_func == 7 || cfg->block_ctx > 0, "block_ctx required");
+        JB_REQUIRE(L.w_attn && L.w_proj && L.w_fc && L.w_proj2 && L.b_attn && L.b_proj && L.b_fc && L.b_proj2 &&
+                       L.ln0_g && L.ln0_b && L.ln1_g && L.ln1_b && L.kcache && L.vcache && L.cache_cap > 0,
+                   "incomplete layer descriptor");
+    }
+    JbEngine* e = new JbEngine();
+    e->cfg = *cfg;
+    e->layers.assign(layers, layers + cfg->n_layers);
+    *handle = e;
+    return JB_OK;
+}
+
+extern "C" int jb_engine_destroy(void* handle) {
+    if (!handle) return JB_OK;
+    JbEngine* e = (JbEngine*)handle;
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    delete e;
+    return JB_OK;
+}
+
+extern "C" int jb_engine_launches_per_step(void* handle) {
+    if (!handle) return 0;
+    return 5 * ((JbEngine*)handle)->cfg.n_layers + 5;
+}
+
+#define JB_TRY(call)                \
+    do {                            \
+        int rc__ = (call);          \
+        if (rc__ != JB_OK) return rc__; \
+    } while (0)
+
+// One decode step at position *t_dev; everything position-dependent is read on the device.
+static int enqueue_step(JbEngine* e, hipStream_t s) {
+    const jb_engine_cfg& c = e->cfg;
+    const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
+    JB_TRY(jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
+                    c.xc_n_stride, c.xc_t_stride, N, W, 0, c.t_dev, 1, s));
+    for (int l = 0; l < c.n_layers; ++l) {
+        const jb_layer& L = e->layers[l];
+        jb_gemv_args g = {};
+        g.dtype = c.dtype;
+        // a7/a8/a9: ln_0 + c_attn, k/v appended at *t_dev
+        g.x = c.x_a; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln0_g; g.ln_beta = L.ln0_b; g.ln_eps = c.ln_eps;
+        g.W = L.w_attn; g.bias = L.b_attn; g.K = W; g.J = 3 * S; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
+        g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
+        JB_TRY(jb_gemv(&g, s));
+        JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
+                              c.block_ctx, c.t_dev, c.seq_len, s));
+        // attn.c_proj + residual: x_b = x_a + a
+        g = {};
+        g.dtype = c.dtype; g.x = c.att; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
+        g.out = c.x_b; g.ldo = W; g.res = c.x_a; g.ldr = W;
+        JB_TRY(jb_gemv(&g, s));
+        // ln_1 + mlp.c_fc + quick_gelu
+        g = {};
+        g.dtype = c.dtype; g.x = c.x_b; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln1_g; g.ln_beta = L.ln1_b; g.ln_eps = c.ln_eps;
+        g.W = L.w_fc; g.bias = L.b_fc; g.K = W; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
+        JB_TRY(jb_gemv(&g, s));
+        // mlp.c_proj + residual: x_a = x_b + m   (h = x + a + m, transformer.py:82-83)
+        g = {};
+        g.dtype = c.dtype; g.x = c.mlp; g.ldx = M; g.n_rows = N; g.W = L.w_proj2; g.bias = L.b_proj2; g.K = M; g.J = W;
+        g.out = c.x_a; g.ldo = W; g.res = c.x_b; g.ldr = W;
+        JB_TRY(jb_gemv(&g, s));
+    }
+    JB_TRY(jb_final_add(c.dtype, c.x_a, c.xf, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride, c.xc_t_stride, N, W,
+                        0, c.t_dev, 1, s));
+    jb_gemv_args g = {};
+    g.dtype = JB_F32; g.x = c.xf; g.ldx = W; g.n_rows = N; g.W = c.x_out_packed; g.K = W; g.J = c.bins;
+    g.out = c.logits; g.ldo = c.bins;
+    JB_TRY(jb_gemv(&g, s));
+    JB_TRY(jb_sample_logits(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds,
+                            c.preds_n_stride, s));
+    inc_int_kernel<<<1, 1, 0, s>>>(c.t_dev);
+    JB_CHECK_LAUNCH();
+    return JB_OK;
+}
+
+extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream) {
+    JB_REQUIRE(handle, "null engine");
+    JbEngine* e = (JbEngine*)handle;
+    JB_REQUIRE(t0 >= 0 && n_steps >= 0 && t0 + n_steps <= e->cfg.seq_len, "step range outside the sequence");
+    hipStream_t s = (hipStream_t)stream;
+    set_int_kernel<<<1, 1, 0, s>>>(e->cfg.t_dev, t0);
+    JB_CHECK_LAUNCH();
+    if (n_steps == 0) return JB_OK;
+    if (!use_graph) {
+        for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
+        return JB_OK;
+    }
+    if (!e->graph_exec || e->graph_stream != s) {
+        if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+        // hipFuncSetAttribute calls (large dynamic LDS) are not capturable: issue one eager step first so every
+        // kernel is configured, then restore the counter and capture.
+        JB_TRY(enqueue_step(e, s));
+        set_int_kernel<<<1, 1, 0, s>>>(e->cfg.t_dev, t0);
+        JB_CHECK_LAUNCH();
+        JB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_step(e, s);
+        hipGraph_t gph = nullptr;
+        hipError_t ce = hipStreamEndCapture(s, &gph);
+        if (rc != JB_OK) { if (gph) (void)hipGraphDestroy(gph); return rc; }
+        if (ce != hipSuccess) { jb_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return JB_ERR_HIP; }
+        e->graph = gph;
+        JB_HIP(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        e->graph_stream = s;
+    }
+    for (int i = 0; i < n_steps; ++i) JB_HIP(hipGraphLaunch(e->graph_exec, s));
+    return JB_OK;
+}
+
+// Chunked prefill of positions t0 .. t0+n_t-1 (primed_sample, autoregressive.py:284-318), in sub-chunks of
+// at most chunk_cap positions; outputs are discarded unless preds is set (get_preds).
+extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
+    JB_REQUIRE(handle, "null engine");
+    JbEngine* e = (JbEngine*)handle;
+    const jb_engine_cfg& c = e->cfg;
+    JB_REQUIRE(t0 >= 0 && n_t > 0 && t0 + n_t <= c.seq_len, "chunk outside the sequence");
+    JB_REQUIRE(c.chunk_cap > 0 && c.c_xa && c.c_xb && c.c_h && c.c_q && c.c_att && c.c_mlp, "prefill buffers missing");
+    JB_REQUIRE(!c.preds || c.c_xf, "c_xf required when preds is set");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
+    for (int off = 0; off < n_t; off += c.chunk_cap) {
+        const int C = (n_t - off < c.chunk_cap) ? n_t - off : c.chunk_cap;
+        const int p0 = t0 + off;
+        const int64_t rows = (int64_t)N * C;
+        JB_TRY(jb_embed(c.dtype, c.c_xa, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
+                        c.xc_n_stride, c.xc_t_stride, N, W, p0, nullptr, C, s));
+        auto base = [&](jb_gemm_args& g, const void* A, int64_t lda, int K, const void* Wp, const float* b, int J,
+                        void* out, int64_t ldo) {
+            g = {};
+            g.dtype = c.dtype; g.A = A; g.lda = lda; g.W = Wp; g.bias = b; g.out = out; g.ldo = ldo;
+            g.n_seq = N; g.t_in = C; g.t_out = C; g.in_seq_stride = C; g.out_seq_stride = C; g.K = K; g.J = J;
+            g.n_taps = 1; g.in_stride = 1; g.out_stride = 1; g.res_scale = 1.0f;
+        };
+        for (int l = 0; l < c.n_layers; ++l) {
+            const jb_layer& L = e->layers[l];
+            jb_gemm_args g;
+            JB_TRY(jb_layernorm_fwd(c.c_xa, c.dtype, c.c_h, c.dtype, L.ln0_g, L.ln0_b, rows, W, c.ln_eps, s));
+            base(g, c.c_h, W, W, L.w_attn, L.b_attn, 3 * S, c.c_q, S);
+            g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.cache_t0 = p0;
+            JB_TRY(jb_gemm(&g, s));
+            JB_TRY(jb_attn_prefill(c.dtype, L.attn_func, c.c_q, L.kcache, L.vcache, L.cache_cap, c.c_att, N, H, d,
+                                   c.block_ctx, p0, C, s));
+            base(g, c.c_att, S, S, L.w_proj, L.b_proj, W, c.c_xb, W);
+            g.res = c.c_xa; g.ldr = W;
+            JB_TRY(jb_gemm(&g, s));
+            JB_TRY(jb_layernorm_fwd(c.c_xb, c.dtype, c.c_h, c.dtype, L.ln1_g, L.ln1_b, rows, W, c.ln_eps, s));
+            base(g, c.c_h, W, W, L.w_fc, L.b_fc, M, c.c_mlp, M);
+            g.act = JB_ACT_QUICK_GELU;
+            JB_TRY(jb_gemm(&g, s));
+            base(g, c.c_mlp, M, M, L.w_proj2, L.b_proj2, W, c.c_xa, W);
+            g.res = c.c_xb; g.ldr = W;
+            JB_TRY(jb_gemm(&g, s));
+        }
+        if (c.preds) {
+            JB_TRY(jb_final_add(c.dtype, c.c_xa, c.c_xf, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride,
+                                c.xc_t_stride, N, W, p0, nullptr, C, s));
+            jb_gemm_args g;
+            base(g, c.c_xf, W, W, c.x_out_packed, nullptr, c.bins, c.preds, c.bins);
+            g.dtype = JB_F32;
+            g.out_seq_stride = c.preds_n_stride / c.bins; g.out_offset = p0;
+            JB_TRY(jb_gemm(&g, s));
+        }
+    }
+    set_int_kernel<<<1, 1, 0, s>>>(c.t_dev, t0 + n_t);
+    JB_CHECK_LAUNCH();
+    return JB_OK;
+}

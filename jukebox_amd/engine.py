@@ -1,0 +1,175 @@
+"""Host-side binding of one autoregressive prior to the HIP decode engine (jb_engine_*).
+
+Plumbing only: torch allocates the device buffers (weights in MFMA order, k/v caches sized for
+288 GB HBM, work buffers) and passes raw pointers to the C ABI; every FLOP of the token loop runs
+in libjukebox_hip.so.  Mirrors the state that the reference keeps inside
+Transformer / FactoredAttention while sampling (jukebox/transformer/factored_attention.py:75-76,
+355-381): `sample_t` is the device counter `t_dev`, the per-layer `cache` dict is the static
+(N, seq_len, n_state) k/v arrays.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import hip_ops as H
+
+# transformer.py:110-126 (reference) -- attn_order -> attn_func per layer
+_ORDERS = {
+    0: lambda d: 0, 1: lambda d: [1, 2][d % 2], 2: lambda d: [1, 2, 3][d % 3], 3: lambda d: [1, 4][d % 2],
+    4: lambda d: [1, 5][d % 2], 5: lambda d: [1, 4, 1, 1][d % 4], 6: lambda d: [1, 2, 3, 6][d % 4],
+    7: lambda d: [*[1, 2, 3] * 5, 6][d % 16], 8: lambda d: [1, 2, 3, 1, 2, 3, 1, 2, 3, 6][d % 10],
+    9: lambda d: [1, 2, 3, 0][d % 4],
+    10: lambda d: [*[1, 2, 3, 1, 2, 3, 1, 2, 3], *[1, 2, 3, 1, 2, 3, 1, 2, 3, 6] * 7][d % 79],
+    11: lambda d: [6, 6, 0][d % 3] if d % 16 == 15 else [1, 2, 3][d % 3],
+    12: lambda d: [7, 7, 0][d % 3] if d % 16 == 15 else [1, 2, 3][d % 3],
+}
+
+
+def attn_funcs(attn_order, depth):
+    return [_ORDERS[attn_order](d) for d in range(depth)]
+
+
+class PriorEngine:
+    """One ConditionalAutoregressive2D bound to device buffers for a fixed batch size.
+
+    sd: mapping reference-name -> GPU tensor for the keys under `prefix`
+        (x_emb.weight, pos_emb.pos_emb, [start_token], transformer._attn_mods.*, x_out.weight).
+    """
+
+    def __init__(self, sd, prefix, *, n_batch, seq_len, bins, width, depth, heads, attn_order, blocks=None,
+                 m_attn=0.25, m_mlp=1.0, prime_len=None, y_cond=False, add_cond_after=True, fp16=True,
+                 chunk_cap=256, want_preds=False, device="cuda"):
+        L.lib()
+        self.device = torch.device(device)
+        self.N, self.T, self.bins, self.W = n_batch, seq_len, bins, width
+        self.S, self.M, self.H, self.depth = int(m_attn * width), int(m_mlp * width), heads, depth
+        self.dtype = torch.float16 if fp16 else torch.float32
+        self.code = L.F16 if fp16 else L.F32
+        self.block_ctx = seq_len // blocks if blocks else 0
+        self.prime_cap = (prime_len // blocks + 1) * blocks if prime_len else 0
+        self.funcs = attn_funcs(attn_order, depth)
+        self.y_cond, self.add_cond_after = y_cond, add_cond_after
+        self.chunk_cap = min(chunk_cap, seq_len)
+        dev, dt = self.device, self.dtype
+        g = lambda name: sd[prefix + name].to(dev).contiguous()
+        f32 = lambda name: g(name).float().contiguous()
+
+        self.x_emb = f32("x_emb.weight")
+        self.pos_emb = f32("pos_emb.pos_emb")
+        self.start_token = None if y_cond else f32("start_token")
+        self.x_out = H.pack_linear_w(f32("x_out.weight"), torch.float32)
+        self._keep = []          # tensors referenced by raw pointer from the engine
+        self.layers_c = (L.Layer * depth)()
+        N, T, S, W, M = self.N, self.T, self.S, self.W, self.M
+        self.kcaches, self.vcaches = [], []
+        for d in range(depth):
+            p = f"transformer._attn_mods.{d}."
+            func = self.funcs[d]
+            if func not in (0, 1, 2, 3, 7):
+                raise L.JukeboxHipError(f"attn_func {func} is not supported by the engine yet")
+            ws = [H.pack_conv1d_w(g(p + n), dt) for n in ("attn.c_attn.w", "attn.c_proj.w", "mlp.c_fc.w", "mlp.c_proj.w")]
+            bs = [f32(p + n) for n in ("attn.c_attn.b", "attn.c_proj.b", "mlp.c_fc.b", "mlp.c_proj.b")]
+            lns = [f32(p + n) for n in ("ln_0.weight", "ln_0.bias", "ln_1.weight", "ln_1.bias")]
+            cap = self.prime_cap if func == 7 else T
+            kc = torch.zeros((N, cap, S), dtype=dt, device=dev)
+            vc = torch.zeros((N, cap, S), dtype=dt, device=dev)
+            self.kcaches.append(kc)
+            self.vcaches.append(vc)
+            self._keep += ws + bs + lns
+            lc = self.layers_c[d]
+            lc.attn_func = func
+            lc.w_attn, lc.w_proj, lc.w_fc, lc.w_proj2 = (w.ptr for w in ws)
+            lc.b_attn, lc.b_proj, lc.b_fc, lc.b_proj2 = (b.data_ptr() for b in bs)
+            lc.ln0_g, lc.ln0_b, lc.ln1_g, lc.ln1_b = (t.data_ptr() for t in lns)
+            lc.kcache, lc.vcache, lc.cache_cap = kc.data_ptr(), vc.data_ptr(), cap
+
+        e = lambda *shape, dtype=dt: torch.zeros(shape, dtype=dtype, device=dev)
+        Cc = self.chunk_cap
+        self.buf = dict(x_a=e(N, W), x_b=e(N, W), q=e(N, S), att=e(N, S), mlp=e(N, M),
+                        xf=e(N, W, dtype=torch.float32), logits=e(N, bins, dtype=torch.float32),
+                        c_xa=e(N * Cc, W), c_xb=e(N * Cc, W), c_h=e(N * Cc, W), c_q=e(N * Cc, S), c_att=e(N * Cc, S),
+                        c_mlp=e(N * Cc, M))
+        self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.preds = e(N, T, bins, dtype=torch.float32) if want_preds else None
+        if want_preds:
+            self.buf["c_xf"] = e(N * Cc, W, dtype=torch.float32)
+        self.sample_params = H.make_sample_params(device=dev)
+        self.x_cond = None
+        self.start = None
+        self.handle = None
+
+    # -- conditioning / sampler state ------------------------------------------------------------------
+    def set_cond(self, x_cond, y_cond):
+        """x_cond: (N, T, W) / (N, 1, W) fp32 or None; y_cond: (N, 1, W) when the model is y-conditioned."""
+        if x_cond is not None:
+            x_cond = x_cond.to(self.device).float().contiguous()
+            assert x_cond.shape[0] == self.N and x_cond.shape[2] == self.W and x_cond.shape[1] in (1, self.T)
+        self.x_cond = x_cond
+        if self.y_cond:
+            assert y_cond is not None and tuple(y_cond.shape) == (self.N, 1, self.W)
+            self.start = y_cond.to(self.device).float().reshape(self.N, self.W).contiguous()
+            self.start_stride = self.W
+        else:
+            self.start = self.start_token.reshape(self.W).contiguous()
+            self.start_stride = 0
+        self._create()
+
+    def set_sampling(self, temp=1.0, top_k=0, top_p=0.0, seed=0, sample_base=0):
+        new = H.make_sample_params(temp, top_k, top_p, seed, sample_base, device=self.device)
+        self.sample_params.copy_(new)          # same device address: captured graphs stay valid
+
+    def _create(self):
+        self.close()
+        c = L.EngineCfg()
+        c.dtype, c.n_batch, c.width, c.n_state, c.n_head, c.n_mlp = self.code, self.N, self.W, self.S, self.H, self.M
+        c.n_layers, c.seq_len, c.block_ctx, c.bins, c.ln_eps = self.depth, self.T, self.block_ctx, self.bins, 1e-5
+        c.x_emb, c.pos_emb, c.x_out_packed = self.x_emb.data_ptr(), self.pos_emb.data_ptr(), self.x_out.ptr
+        c.start, c.start_stride = self.start.data_ptr(), self.start_stride
+        if self.x_cond is not None:
+            c.x_cond = self.x_cond.data_ptr()
+            c.xc_n_stride = self.x_cond.stride(0)
+            c.xc_t_stride = self.x_cond.stride(1) if self.x_cond.shape[1] > 1 else 0
+        c.add_cond_after = int(self.add_cond_after)
+        b = self.buf
+        for k in ("x_a", "x_b", "q", "att", "mlp", "xf", "logits", "c_xa", "c_xb", "c_h", "c_q", "c_att", "c_mlp"):
+            setattr(c, k, b[k].data_ptr())
+        c.chunk_cap = self.chunk_cap
+        c.c_xf = b["c_xf"].data_ptr() if "c_xf" in b else None
+        c.tokens, c.tok_stride, c.t_dev = self.tokens.data_ptr(), self.tokens.stride(0), self.t_dev.data_ptr()
+        if self.preds is not None:
+            c.preds, c.preds_n_stride = self.preds.data_ptr(), self.preds.stride(0)
+        c.sample_params = self.sample_params.data_ptr()
+        h = C.c_void_p()
+        L.check(L.lib().jb_engine_create(C.byref(c), self.layers_c, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            L.lib().jb_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the two hot loops ---------------------------------------------------------------------------------
+    def prefill(self, t0, n_t):
+        L.check(L.lib().jb_engine_prefill(self.handle, t0, n_t, L.stream()))
+
+    def decode(self, t0, n_steps, use_graph=True):
+        L.check(L.lib().jb_engine_decode(self.handle, t0, n_steps, int(use_graph), L.stream()))
+
+    @property
+    def launches_per_step(self):
+        return L.lib().jb_engine_launches_per_step(self.handle)
+
+    def cache_bytes(self):
+        return sum(k.numel() * k.element_size() * 2 for k in self.kcaches)
+
+    def weight_bytes(self):
+        return sum(t.data.numel() * t.data.element_size() if isinstance(t, H.PackedWeight) else 0 for t in self._keep) \
+            + self.x_out.data.numel() * 4

@@ -1,0 +1,194 @@
+"""Thin tensor-level wrappers over the C ABI (include/jukebox_hip.h).
+
+torch supplies device memory and the current HIP stream only; every computation below happens
+in libjukebox_hip.so.  Tensors must live on the GPU and be contiguous; there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _chk_cuda(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or not t.is_contiguous()):
+            raise L.JukeboxHipError("expected contiguous GPU tensors")
+
+
+class PackedWeight:
+    """A K x J matrix in MFMA fragment order (see csrc/gemm.hip) plus its logical dims.
+    `taps` > 1 holds the per-tap matrices of a (transposed) convolution back to back."""
+
+    def __init__(self, data, K, J, dtype, taps=1):
+        self.data, self.K, self.J, self.dtype, self.taps = data, K, J, dtype, taps
+        self.tap_stride = data.numel() // taps
+
+    @property
+    def ptr(self):
+        return self.data.data_ptr()
+
+
+def pack_weight(w, K, J, stride_k, stride_j, dtype, out=None, offset_elems=0):
+    """Pack logical matrix M[k, j] = w.flatten()[offset + k*stride_k + j*stride_j] into `dtype`."""
+    _chk_cuda(w)
+    code = L.dtype_code(dtype)
+    nbytes = L.lib().jb_packed_weight_bytes(K, J, code)
+    if out is None:
+        out = torch.empty(nbytes // (2 if code == L.F16 else 4), dtype=dtype, device=w.device)
+    src = w.data_ptr() + offset_elems * w.element_size()
+    L.check(L.lib().jb_pack_weight(src, L.dtype_code(w.dtype), stride_k, stride_j, K, J, out.data_ptr(), code, L.stream()))
+    return out
+
+
+def pack_conv1d_w(w, dtype):
+    """Conv1D.w (n_in, n_out) (jukebox/transformer/ops.py:89-95)."""
+    K, J = w.shape
+    return PackedWeight(pack_weight(w, K, J, J, 1, dtype), K, J, dtype)
+
+
+def pack_linear_w(w, dtype):
+    """nn.Linear.weight (out, in): logical [k=in][j=out]."""
+    J, K = w.shape
+    return PackedWeight(pack_weight(w, K, J, 1, K, dtype), K, J, dtype)
+
+
+def pack_conv_taps(w, dtype, transposed=False):
+    """nn.Conv1d weight (Cout, Cin, k) or nn.ConvTranspose1d weight (Cin, Cout, k): one K=Cin x J=Cout
+    matrix per tap."""
+    w = w.contiguous()
+    if transposed:
+        Cin, Cout, k = w.shape
+        sk, sj = Cout * k, k
+    else:
+        Cout, Cin, k = w.shape
+        sk, sj = k, Cin * k
+    code = L.dtype_code(dtype)
+    per = L.lib().jb_packed_weight_bytes(Cin, Cout, code) // (2 if code == L.F16 else 4)
+    out = torch.empty(per * k, dtype=dtype, device=w.device)
+    for tap in range(k):
+        pack_weight(w, Cin, Cout, sk, sj, dtype, out=out[tap * per:(tap + 1) * per], offset_elems=tap)
+    return PackedWeight(out, Cin, Cout, dtype, taps=k)
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
+    """ops.LayerNorm.forward (jukebox/transformer/ops.py:14-24)."""
+    _chk_cuda(x, gamma, beta)
+    W = x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    L.check(L.lib().jb_layernorm_fwd(x.data_ptr(), L.dtype_code(x.dtype), y.data_ptr(), L.dtype_code(y.dtype),
+                                     gamma.data_ptr(), beta.data_ptr(), x.numel() // W, W, eps, L.stream()))
+    return y
+
+
+def gemm(A, pw, bias=None, out=None, res=None, n_seq=1, t_in=None, t_out=None, shifts=(0,), in_stride=1,
+         out_stride=1, out_offset=0, out_rows_per_seq=None, pre_relu=False, act=L.ACT_NONE, res_scale=1.0):
+    """Sequence/tap GEMM (see jb_gemm).  A: (n_seq*t_in, lda>=K); returns (n_seq*out_rows_per_seq, J)."""
+    _chk_cuda(A, bias, out, res)
+    rows_in = A.shape[0]
+    t_in = t_in if t_in is not None else rows_in // n_seq
+    t_out = t_out if t_out is not None else t_in
+    orps = out_rows_per_seq if out_rows_per_seq is not None else t_out * out_stride
+    if out is None:
+        out = torch.empty((n_seq * orps, pw.J), dtype=A.dtype, device=A.device)
+    a = L.GemmArgs()
+    a.dtype = L.dtype_code(A.dtype)
+    a.A, a.lda = A.data_ptr(), A.stride(0)
+    a.W, a.tap_stride = pw.ptr, pw.tap_stride
+    a.bias = L.ptr(bias)
+    a.out, a.ldo = out.data_ptr(), out.stride(0)
+    a.res, a.ldr = L.ptr(res), (res.stride(0) if res is not None else 0)
+    a.n_seq, a.t_in, a.t_out = n_seq, t_in, t_out
+    a.in_seq_stride, a.out_seq_stride = t_in, orps
+    a.K, a.J = pw.K, pw.J
+    if len(shifts) != pw.taps:
+        raise L.JukeboxHipError(f"{len(shifts)} shifts for a weight with {pw.taps} taps")
+    a.n_taps, a.in_stride = len(shifts), in_stride
+    for i, s in enumerate(shifts):
+        a.shift[i] = s
+    a.out_stride, a.out_offset = out_stride, out_offset
+    a.pre_relu, a.act, a.res_scale = int(pre_relu), act, res_scale
+    L.check(L.lib().jb_gemm(C.byref(a), L.stream()))
+    return out
+
+
+def tap_view(pw, taps):
+    """PackedWeight holding only the listed taps (must be equally spaced) -- for transposed-conv phases."""
+    step = taps[1] - taps[0] if len(taps) > 1 else 1
+    assert all(taps[i] == taps[0] + i * step for i in range(len(taps)))
+    base = pw.data[taps[0] * pw.tap_stride:]
+    v = PackedWeight(base, pw.K, pw.J, pw.dtype, taps=1)
+    v.tap_stride = pw.tap_stride * step
+    v.taps = len(taps)
+    return v
+
+
+def gemv(x, pw, bias=None, ln=None, res=None, act=L.ACT_NONE, out=None, eps=1e-5):
+    """Decode-step skinny GEMM (see jb_gemv).  x: (n_rows<=64, K)."""
+    _chk_cuda(x, bias, res, out)
+    if out is None:
+        out = torch.empty((x.shape[0], pw.J), dtype=x.dtype, device=x.device)
+    a = L.GemvArgs()
+    a.dtype = L.dtype_code(x.dtype)
+    a.x, a.ldx, a.n_rows = x.data_ptr(), x.stride(0), x.shape[0]
+    if ln is not None:
+        a.ln_gamma, a.ln_beta, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), eps
+    a.W, a.bias, a.K, a.J = pw.ptr, L.ptr(bias), pw.K, pw.J
+    a.out, a.ldo = out.data_ptr(), out.stride(0)
+    a.res, a.ldr = L.ptr(res), (res.stride(0) if res is not None else 0)
+    a.act = act
+    L.check(L.lib().jb_gemv(C.byref(a), L.stream()))
+    return out
+
+
+def attn_decode(func, q, kcache, vcache, n_head, block_ctx, t_dev, max_len):
+    """q (N, S); caches (N, cap, S); returns (N, S)."""
+    _chk_cuda(q, kcache, vcache, t_dev)
+    N, S = q.shape
+    out = torch.empty_like(q)
+    L.check(L.lib().jb_attn_decode(L.dtype_code(q.dtype), func, q.data_ptr(), q.stride(0), kcache.data_ptr(),
+                                   vcache.data_ptr(), kcache.shape[1], out.data_ptr(), out.stride(0), N, n_head,
+                                   S // n_head, block_ctx or 0, t_dev.data_ptr(), max_len, L.stream()))
+    return out
+
+
+def attn_prefill(func, q, kcache, vcache, n_head, block_ctx, t0):
+    """q (N, n_q, S) for positions t0..t0+n_q-1; caches (N, cap, S) already hold them."""
+    _chk_cuda(q, kcache, vcache)
+    N, nq, S = q.shape
+    out = torch.empty_like(q)
+    L.check(L.lib().jb_attn_prefill(L.dtype_code(q.dtype), func, q.data_ptr(), kcache.data_ptr(), vcache.data_ptr(),
+                                    kcache.shape[1], out.data_ptr(), N, n_head, S // n_head, block_ctx or 0, t0, nq,
+                                    L.stream()))
+    return out
+
+
+def vq_gather(codes, codebook):
+    """(N, T) int64 -> (N, T, emb) fp32 (BottleneckBlock.decode, channels-last)."""
+    _chk_cuda(codes, codebook)
+    out = torch.empty((*codes.shape, codebook.shape[1]), dtype=torch.float32, device=codes.device)
+    L.check(L.lib().jb_vq_gather(codes.data_ptr(), codebook.data_ptr(), out.data_ptr(), codes.numel(),
+                                 codebook.shape[1], codebook.shape[0], L.stream()))
+    return out
+
+
+def vq_argmin(x, xk, codebook):
+    _chk_cuda(x, xk, codebook)
+    codes = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    L.check(L.lib().jb_vq_argmin(x.data_ptr(), xk.data_ptr(), codebook.data_ptr(), codes.data_ptr(), x.shape[0],
+                                 x.shape[1], codebook.shape[0], L.stream()))
+    return codes
+
+
+def sample_logits(logits, params_dev, tokens, t_dev, preds=None):
+    _chk_cuda(logits, tokens, t_dev, preds)
+    L.check(L.lib().jb_sample_logits(logits.data_ptr(), logits.shape[0], logits.shape[1], params_dev.data_ptr(),
+                                     tokens.data_ptr(), tokens.stride(0), t_dev.data_ptr(), L.ptr(preds),
+                                     preds.stride(0) if preds is not None else 0, L.stream()))
+
+
+def make_sample_params(temp=1.0, top_k=0, top_p=0.0, seed=0, sample_base=0, device="cuda"):
+    """Device copy of jb_sample_params."""
+    p = L.SampleParams(temp, top_k, top_p, sample_base, seed)
+    raw = bytes(p)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)

@@ -1,0 +1,59 @@
+"""CPU suite: the C-ABI shared library loads and exports every symbol include/jukebox_hip.h declares
+(no compute calls -- there is no GPU here), and the argument-validation paths report errors."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from jukebox_amd.csrc.build import build
+    return build()
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "jukebox_hip.h")).read()
+    declared = set(re.findall(r"\b(jb_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"jb_status"}
+    lib = C.CDLL(built)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    from jukebox_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+
+
+def test_binding_loads_and_validates_arguments(built):
+    from jukebox_amd import _lib as L
+    lib = L.lib()
+    assert lib.jb_version() == 1
+    assert lib.jb_packed_weight_bytes(2048, 1536, L.F16) == 2048 * 1536 * 2
+    assert lib.jb_packed_weight_bytes(70, 50, L.F32) == 80 * 64 * 4       # K padded to 16, J to 16
+    # null pointers are rejected before any launch, with a message
+    rc = lib.jb_layernorm_fwd(None, 0, None, 0, None, None, 4, 8, 1e-5, None)
+    assert rc == -1 and b"null" in lib.jb_last_error()
+    a = L.GemvArgs()
+    assert lib.jb_gemv(C.byref(a), None) == -1
+    with pytest.raises(L.JukeboxHipError):
+        L.check(lib.jb_engine_decode(None, 0, 1, 0, None))
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors vs sizes the C compiler computes (guards against silent field drift)."""
+    import subprocess, tempfile, textwrap
+    from jukebox_amd import _lib as L
+    src = textwrap.dedent("""
+        #include <stdio.h>
+        #include "jukebox_hip.h"
+        int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(jb_gemm_args), sizeof(jb_gemv_args),
+                                sizeof(jb_sample_params), sizeof(jb_layer), sizeof(jb_engine_cfg)); return 0; }
+    """)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    assert sizes == [C.sizeof(L.GemmArgs), C.sizeof(L.GemvArgs), C.sizeof(L.SampleParams), C.sizeof(L.Layer),
+                     C.sizeof(L.EngineCfg)]

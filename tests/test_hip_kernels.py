@@ -1,0 +1,315 @@
+"""GPU suite, kernel level: every C-ABI entry point against a numpy restatement on seeded inputs.
+Tolerances: fp32 paths 2e-5 relative to the output scale (summation order only); fp16 paths are
+checked against fp32 math on the half-rounded operands with the half-output rounding bound."""
+import math
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as O  # noqa: E402
+from oracle.transformer import allowed_keys, decode_key_index  # noqa: E402
+from oracle.vqvae import conv1d_nct, conv_transpose1d_nct  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from jukebox_amd import hip_ops
+    from jukebox_amd import _lib
+    _lib.lib()          # fail loudly if the extension is missing
+    return hip_ops
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def h16(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def relerr(got, want):
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+
+
+DT = [("f32", torch.float32, 2e-5), ("f16", torch.float16, 3e-3)]
+
+
+@pytest.mark.parametrize("name,dt,tol", DT)
+@pytest.mark.parametrize("M,K,J", [(300, 70, 50), (16, 32, 16), (1000, 257, 130), (5, 3, 1)])
+def test_gemm_plain(H, name, dt, tol, M, K, J):
+    rng = np.random.default_rng(M + K + J)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, J)).astype(np.float32)
+    b = rng.standard_normal(J).astype(np.float32)
+    if dt == torch.float16:
+        A, W, bq = h16(A), h16(W), h16(b)
+    else:
+        bq = b
+    pw = H.pack_conv1d_w(dev(W), dt)
+    out = H.gemm(dev(A, dt), pw, bias=dev(b)).float().cpu().numpy()
+    want = A @ W + bq
+    assert relerr(out, want) < tol
+
+
+@pytest.mark.parametrize("name,dt,tol", DT)
+def test_gemm_epilogues(H, name, dt, tol):
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(1)
+    M, K, J = 200, 64, 48
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (0.2 * rng.standard_normal((K, J))).astype(np.float32)
+    b = rng.standard_normal(J).astype(np.float32)
+    R = rng.standard_normal((M, J)).astype(np.float32)
+    f16 = dt == torch.float16
+    if f16:
+        A, W, R = h16(A), h16(W), h16(R)
+    r = (lambda x: h16(x)) if f16 else (lambda x: x)
+    pw = H.pack_conv1d_w(dev(W), dt)
+    # quick_gelu
+    got = H.gemm(dev(A, dt), pw, bias=dev(b), act=L.ACT_QUICK_GELU).float().cpu().numpy()
+    want = O.quick_gelu(r(A @ W + r(b)), fp16=f16)
+    assert relerr(got, want) < tol
+    # residual (res_scale 1 and 0.25), input relu
+    got = H.gemm(dev(A, dt), pw, bias=dev(b), res=dev(R, dt), pre_relu=True).float().cpu().numpy()
+    want = r(R + r(np.maximum(A, 0) @ W + r(b)))
+    assert relerr(got, want) < tol
+    got = H.gemm(dev(A, dt), pw, bias=dev(b), res=dev(R, dt), res_scale=0.25, act=L.ACT_RELU).float().cpu().numpy()
+    want = r(R + r(0.25 * np.maximum(r(A @ W + r(b)), 0)))
+    assert relerr(got, want) < tol
+
+
+def test_conv_stack_ops_fp32(H):
+    """Dilated k=3 conv, strided k=4 conv and transposed conv on channels-last rows vs torch-free numpy NCT."""
+    rng = np.random.default_rng(2)
+    N, Ci, Co, T = 3, 24, 40, 200
+    x = rng.standard_normal((N, Ci, T)).astype(np.float32)
+    xr = dev(np.transpose(x, (0, 2, 1)).reshape(N * T, Ci))
+    for dil in (1, 3, 27, 243):
+        w = (0.2 * rng.standard_normal((Co, Ci, 3))).astype(np.float32)
+        b = rng.standard_normal(Co).astype(np.float32)
+        want = conv1d_nct(x, w, b, 1, dil, dil)
+        pw = H.pack_conv_taps(dev(w), torch.float32)
+        got = H.gemm(xr, pw, bias=dev(b), n_seq=N, t_in=T, shifts=(-dil, 0, dil)).cpu().numpy()
+        got = np.transpose(got.reshape(N, T, Co), (0, 2, 1))
+        assert relerr(got, want) < 2e-5, dil
+    # strided conv k=4 s=2 p=1 (EncoderConvBlock)
+    w = (0.2 * rng.standard_normal((Co, Ci, 4))).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    want = conv1d_nct(x, w, b, 2, 1, 1)
+    pw = H.pack_conv_taps(dev(w), torch.float32)
+    got = H.gemm(xr, pw, bias=dev(b), n_seq=N, t_in=T, t_out=T // 2, in_stride=2, shifts=(-1, 0, 1, 2)).cpu().numpy()
+    got = np.transpose(got.reshape(N, T // 2, Co), (0, 2, 1))
+    assert relerr(got, want) < 2e-5
+    # transposed conv k=4 s=2 p=1 (DecoderConvBock): even outputs taps (1,3) at shifts (0,-1); odd taps (0,2) at (+1,0)
+    w = (0.2 * rng.standard_normal((Ci, Co, 4))).astype(np.float32)
+    want = conv_transpose1d_nct(x, w, b, 2, 1)
+    pw = H.pack_conv_taps(dev(w), torch.float32, transposed=True)
+    out = torch.empty((N * 2 * T, Co), dtype=torch.float32, device="cuda")
+    H.gemm(xr, H.tap_view(pw, [1, 3]), bias=dev(b), out=out, n_seq=N, t_in=T, t_out=T, shifts=(0, -1),
+           out_stride=2, out_offset=0, out_rows_per_seq=2 * T)
+    H.gemm(xr, H.tap_view(pw, [0, 2]), bias=dev(b), out=out, n_seq=N, t_in=T, t_out=T, shifts=(1, 0),
+           out_stride=2, out_offset=1, out_rows_per_seq=2 * T)
+    got = np.transpose(out.cpu().numpy().reshape(N, 2 * T, Co), (0, 2, 1))
+    assert relerr(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("name,dt,tol", DT)
+@pytest.mark.parametrize("rows,K,J", [(16, 256, 96), (3, 100, 50), (40, 64, 16), (64, 512, 130)])
+def test_gemv_ln_epilogues(H, name, dt, tol, rows, K, J):
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(rows + K)
+    f16 = dt == torch.float16
+    r = (lambda x: h16(x)) if f16 else (lambda x: x)
+    x = r(rng.standard_normal((rows, K)).astype(np.float32) * 2 + 0.5)
+    W = r((0.1 * rng.standard_normal((K, J))).astype(np.float32))
+    b = rng.standard_normal(J).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    R = r(rng.standard_normal((rows, J)).astype(np.float32))
+    pw = H.pack_conv1d_w(dev(W), dt)
+    # plain + bias
+    got = H.gemv(dev(x, dt), pw, bias=dev(b)).float().cpu().numpy()
+    assert relerr(got, r(x @ W + r(b))) < tol
+    # LN + gelu
+    got = H.gemv(dev(x, dt), pw, bias=dev(b), ln=(dev(g), dev(be)), act=L.ACT_QUICK_GELU).float().cpu().numpy()
+    xn = r(O.layer_norm(x, g, be))
+    want = O.quick_gelu(r(xn @ W + r(b)), fp16=f16)
+    assert relerr(got, want) < tol
+    # residual
+    got = H.gemv(dev(x, dt), pw, bias=dev(b), res=dev(R, dt)).float().cpu().numpy()
+    assert relerr(got, r(R + r(x @ W + r(b)))) < tol
+
+
+@pytest.mark.parametrize("name,dt,tol", DT)
+def test_gemv_qkv_append(H, name, dt, tol):
+    import ctypes as C
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(5)
+    N, K, S, cap, t = 5, 64, 24, 9, 6
+    f16 = dt == torch.float16
+    r = (lambda x: h16(x)) if f16 else (lambda x: x)
+    x = r(rng.standard_normal((N, K)).astype(np.float32))
+    W = r((0.1 * rng.standard_normal((K, 3 * S))).astype(np.float32))
+    b = rng.standard_normal(3 * S).astype(np.float32)
+    pw = H.pack_conv1d_w(dev(W), dt)
+    q = torch.zeros((N, S), dtype=dt, device="cuda")
+    kc = torch.zeros((N, cap, S), dtype=dt, device="cuda")
+    vc = torch.zeros((N, cap, S), dtype=dt, device="cuda")
+    for tt in (t, cap + 3):                     # second call: beyond the cache capacity -> no k/v write
+        t_dev = torch.tensor([tt], dtype=torch.int32, device="cuda")
+        xd, bd = dev(x, dt), dev(b)
+        a = L.GemvArgs()
+        a.dtype = L.dtype_code(dt)
+        a.x, a.ldx, a.n_rows = xd.data_ptr(), K, N
+        a.W, a.bias, a.K, a.J = pw.ptr, bd.data_ptr(), K, 3 * S
+        a.out, a.ldo = q.data_ptr(), S
+        a.qkv_split, a.S, a.kcache, a.vcache, a.cache_cap, a.t_dev = 1, S, kc.data_ptr(), vc.data_ptr(), cap, t_dev.data_ptr()
+        L.check(L.lib().jb_gemv(C.byref(a), L.stream()))
+        torch.cuda.synchronize()
+    want = r(x @ W + r(b))
+    assert relerr(q.float().cpu().numpy(), want[:, :S]) < tol
+    kcn, vcn = kc.float().cpu().numpy(), vc.float().cpu().numpy()
+    assert relerr(kcn[:, t], want[:, S:2 * S]) < tol and relerr(vcn[:, t], want[:, 2 * S:]) < tol
+    mask = np.ones(cap, bool); mask[t] = False
+    assert np.all(kcn[:, mask] == 0) and np.all(vcn[:, mask] == 0)
+
+
+@pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.float16, torch.float16),
+                                       (torch.float32, torch.float16)])
+def test_layernorm(H, din, dout):
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((37, 200)) * 3 + 1).astype(np.float32)
+    if din == torch.float16:
+        x = h16(x)
+    g = (1 + 0.1 * rng.standard_normal(200)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(200)).astype(np.float32)
+    got = H.layernorm(dev(x, din), dev(g), dev(b), out_dtype=dout).float().cpu().numpy()
+    want = O.layer_norm(x, g, b)
+    assert relerr(got, want) < (2e-3 if dout == torch.float16 else 1e-5)
+
+
+def _np_attention(func, q, K, V, H_, bc, prime_r, qpos, fp16):
+    """numpy reference: per query position, softmax over the closed-form key set."""
+    N, nq, S = q.shape
+    d = S // H_
+    out = np.zeros_like(q)
+    sc2 = (1.0 / math.sqrt(math.sqrt(d))) ** 2
+    r = (lambda x: h16(x)) if fp16 else (lambda x: x)
+    for i, p in enumerate(qpos):
+        idx = decode_key_index(func, p, bc, prime_r)
+        if idx is None:
+            continue
+        for h in range(H_):
+            qs = q[:, i, h * d:(h + 1) * d]
+            ks, vs = K[:, idx, h * d:(h + 1) * d], V[:, idx, h * d:(h + 1) * d]
+            w = r(r(np.einsum("nd,nkd->nk", qs, ks)) * np.float32(sc2))
+            pr = r(O.softmax(w, -1))
+            out[:, i, h * d:(h + 1) * d] = r(np.einsum("nk,nkd->nd", pr, vs))
+    return out
+
+
+@pytest.mark.parametrize("name,dt,tol", [("f32", torch.float32, 1e-5), ("f16", torch.float16, 4e-3)])
+@pytest.mark.parametrize("func", [0, 1, 2, 3, 7])
+@pytest.mark.parametrize("H_,d", [(2, 16), (1, 120), (2, 256)])
+def test_attn_decode(H, name, dt, tol, func, H_, d):
+    rng = np.random.default_rng(func * 10 + d)
+    N, T, bc, prime_r = 3, 96, 8, 24
+    S = H_ * d
+    fp16 = dt == torch.float16
+    r = (lambda x: h16(x)) if fp16 else (lambda x: x)
+    cap = prime_r if func == 7 else T
+    K = r(rng.standard_normal((N, cap, S)).astype(np.float32))
+    V = r(rng.standard_normal((N, cap, S)).astype(np.float32))
+    kc, vc = dev(K, dt), dev(V, dt)
+    for t in (0, 1, 7, 8, 9, 23, 24, 40, 95):
+        q = r(rng.standard_normal((N, 1, S)).astype(np.float32))
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        got = H.attn_decode(func, dev(q[:, 0], dt), kc, vc, H_, bc, t_dev, T).float().cpu().numpy()
+        want = _np_attention(func, q, K, V, H_, bc, prime_r, [t], fp16)[:, 0]
+        assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (func, t)
+
+
+@pytest.mark.parametrize("name,dt,tol", [("f32", torch.float32, 2e-5), ("f16", torch.float16, 6e-3)])
+@pytest.mark.parametrize("func", [0, 1, 2, 3, 7])
+@pytest.mark.parametrize("H_,d", [(2, 16), (1, 120), (2, 64)])
+def test_attn_prefill(H, name, dt, tol, func, H_, d):
+    rng = np.random.default_rng(func * 10 + d + 1)
+    N, T, bc, prime_r = 2, 120, 8, 24
+    S = H_ * d
+    fp16 = dt == torch.float16
+    r = (lambda x: h16(x)) if fp16 else (lambda x: x)
+    cap = prime_r if func == 7 else T
+    K = r(rng.standard_normal((N, cap, S)).astype(np.float32))
+    V = r(rng.standard_normal((N, cap, S)).astype(np.float32))
+    kc, vc = dev(K, dt), dev(V, dt)
+    for t0, nq in ((0, 40), (0, 1), (5, 7), (13, 50), (64, 56), (37, 83)):
+        q = r(rng.standard_normal((N, nq, S)).astype(np.float32))
+        got = H.attn_prefill(func, dev(q, dt), kc, vc, H_, bc, t0).float().cpu().numpy()
+        # online softmax rounds unnormalised probabilities in half mode: compare against fp32 math on the
+        # half operands with a half-precision tolerance
+        want = _np_attention(func, q, K, V, H_, bc, prime_r, list(range(t0, t0 + nq)), False)
+        assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (func, t0, nq)
+
+
+def test_sampler(H):
+    rng = np.random.default_rng(11)
+    N, bins, T = 64, 97, 8
+    logits = rng.standard_normal((N, bins)).astype(np.float32) * 2
+    logits[0, 3] = logits[0, 5] = logits[0].max() + 1        # tie -> lowest index
+    ld = dev(logits)
+    tokens = torch.zeros((N, T), dtype=torch.int64, device="cuda")
+    t_dev = torch.tensor([2], dtype=torch.int32, device="cuda")
+    preds = torch.zeros((N, T, bins), dtype=torch.float32, device="cuda")
+    # greedy
+    H.sample_logits(ld, H.make_sample_params(temp=0.7, top_k=1), tokens, t_dev, preds)
+    got = tokens[:, 2].cpu().numpy()
+    assert np.array_equal(got, logits.argmax(1)) and got[0] == 3
+    assert np.array_equal(preds[:, 2].cpu().numpy(), logits)
+    # top-k support
+    for seed in range(5):
+        H.sample_logits(ld, H.make_sample_params(temp=1.0, top_k=5, seed=seed), tokens, t_dev)
+        got = tokens[:, 2].cpu().numpy()
+        kth = np.sort(logits, 1)[:, -5]
+        assert np.all(logits[np.arange(N), got] >= kth)
+    # nucleus support
+    for seed in range(5):
+        H.sample_logits(ld, H.make_sample_params(temp=1.0, top_p=0.6, seed=seed), tokens, t_dev)
+        got = tokens[:, 2].cpu().numpy()
+        filt = O.filter_logits(logits, top_p=0.6)
+        assert np.all(np.isfinite(filt[np.arange(N), got]))
+    # categorical frequencies: identical rows, different sample ids -> softmax(logits / temp)
+    row = rng.standard_normal(16).astype(np.float32)
+    ld2 = dev(np.tile(row, (64, 1)))
+    counts = np.zeros(16)
+    for seed in range(200):
+        H.sample_logits(ld2, H.make_sample_params(temp=0.9, seed=seed), tokens, t_dev)
+        counts += np.bincount(tokens[:, 2].cpu().numpy(), minlength=16)
+    p = O.softmax(row / np.float32(0.9))
+    n = counts.sum()
+    z = (counts - n * p) / np.sqrt(n * p * (1 - p) + 1e-9)
+    assert np.abs(z).max() < 5.0, z
+
+
+def test_vq(H):
+    rng = np.random.default_rng(12)
+    bins, emb, M = 64, 16, 1000
+    cb = rng.standard_normal((bins, emb)).astype(np.float32)
+    codes = rng.integers(0, bins, (4, 250))
+    got = H.vq_gather(dev(codes), dev(cb)).cpu().numpy()
+    assert np.array_equal(got, cb[codes])
+    x = rng.standard_normal((M, emb)).astype(np.float32)
+    pw = H.pack_linear_w(dev(cb), torch.float32)          # logical [k=emb][j=bins] = cb^T
+    xk = H.gemm(dev(x), pw)
+    got = H.vq_argmin(dev(x), xk, dev(cb)).cpu().numpy()
+    dist = (x ** 2).sum(-1, keepdims=True) - 2 * x @ cb.T + (cb ** 2).sum(-1)[None]
+    want = dist.argmin(-1)
+    agree = got == want
+    # disagreements only at near-ties of the distance
+    srt = np.sort(dist, 1)
+    assert agree.mean() > 0.99 and np.all((srt[~agree, 1] - srt[~agree, 0]) < 1e-4)
