@@ -89,6 +89,9 @@ def lib():
     """Load (once) and return the shared library with argument types set.  Raises if it is absent."""
     global _lib
     if _lib is None:
+        # torch-ROCm bundles its own HIP runtime: import it first so that this process has exactly one
+        # libamdhip64 (loading the system copy first leaves the second runtime without a device).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise JukeboxHipError(f"{LIB_PATH} is missing: build the HIP extension first "
                                   "(python -m jukebox_amd.csrc.build); there is no CPU fallback")

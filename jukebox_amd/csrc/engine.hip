@@ -15,7 +15,7 @@ struct JbEngine {
     std::vector<jb_layer> layers;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    hipStream_t graph_stream = nullptr;
+    hipStream_t capture_stream = nullptr;   // the legacy default stream cannot be captured: record on a private one
     int launches_per_step = 0;
 };
 
@@ -55,6 +55,7 @@ extern "C" int jb_engine_destroy(void* handle) {
     JbEngine* e = (JbEngine*)handle;
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
+    if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
     delete e;
     return JB_OK;
 }
@@ -128,23 +129,24 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
         for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
         return JB_OK;
     }
-    if (!e->graph_exec || e->graph_stream != s) {
-        if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
-        // hipFuncSetAttribute calls (large dynamic LDS) are not capturable: issue one eager step first so every
-        // kernel is configured, then restore the counter and capture.
+    if (!e->graph_exec) {
+        // One eager step first, so that every kernel's dynamic-LDS attribute is configured outside of capture;
+        // it computes position t0, which the first replay recomputes identically (the sampler's random stream is
+        // keyed by position), so the counter is simply restored.  Then one step is recorded on a private stream
+        // -- recording executes nothing -- and replayed on the caller's stream.
         JB_TRY(enqueue_step(e, s));
         set_int_kernel<<<1, 1, 0, s>>>(e->cfg.t_dev, t0);
         JB_CHECK_LAUNCH();
-        JB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue_step(e, s);
+        if (!e->capture_stream) JB_HIP(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+        hipStream_t cs = e->capture_stream;
+        JB_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_step(e, cs);
         hipGraph_t gph = nullptr;
-        hipError_t ce = hipStreamEndCapture(s, &gph);
+        hipError_t ce = hipStreamEndCapture(cs, &gph);
         if (rc != JB_OK) { if (gph) (void)hipGraphDestroy(gph); return rc; }
         if (ce != hipSuccess) { jb_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return JB_ERR_HIP; }
         e->graph = gph;
         JB_HIP(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
-        e->graph_stream = s;
     }
     for (int i = 0; i < n_steps; ++i) JB_HIP(hipGraphLaunch(e->graph_exec, s));
     return JB_OK;
