@@ -29,24 +29,27 @@ __device__ __forceinline__ KeySet decode_key_set(int func, int t, int bc, int ca
 }
 
 // ------------------------------------------------------------------------------------------------
-// Decode (q_l == 1).  One workgroup per (sample, head).  Phase 1: each wave takes whole key rows
-// (a row is d_head * sizeof(T) <= 1-2 KiB, i.e. one or two fully coalesced wave loads), dots them
-// with the query held in registers and wave-reduces; scores go to LDS.  Softmax over the LDS row
-// in fp32.  Phase 2: waves stride over the keys accumulating p_i * v_i into per-lane channel
-// slices, then the per-wave partial outputs are summed in a fixed order through LDS.
-// HBM/L2-bound GEMV per sample: MFMA has no reuse to exploit here (one query row), so this runs on
-// the vector ALU with fully coalesced row loads; the prefill kernel below is the MFMA one.
+// Decode (q_l == 1).  One workgroup per (sample, head), one dependent memory round trip: wave w takes
+// keys w, w+nw, ... and requests KB key rows AND their value rows together (a row is d_head * sizeof(T)
+// <= 1-2 KiB, one or two fully coalesced wave loads), dots the keys with the query held in registers,
+// and folds them into a per-wave online softmax (running max, sum and output slice).  The per-wave
+// states are then merged in a fixed order through LDS.  HBM/L2-bound GEMV per sample: MFMA has no
+// reuse to exploit with a single query row, so this runs on the vector ALU; the prefill kernel below
+// is the MFMA one.  In half mode the probabilities are rounded to half before multiplying the values
+// (factored_attention.py:98) relative to the running maximum.
 template <typename T, int NCH>
 __global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ldq, const T* __restrict__ kc,
                                    const T* __restrict__ vc, int cap, T* __restrict__ out, int64_t ldo, int n_head,
-                                   int d, int bc, const int* __restrict__ t_dev, int max_len) {
+                                   int d, int bc, const int* __restrict__ t_dev) {
+    using V = typename Frag<T>::vec;
     constexpr int E = Frag<T>::E;
+    constexpr int KB = 4;                    // key/value row pairs in flight per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
-    float* s_p = smem;                       // [max_len] scores -> probabilities
-    float* s_red = smem + max_len;           // [nw] block-reduction scratch (+1 result slot)
-    float* s_o = s_red + 32;                 // [nw][d] partial outputs
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s_ml = smem;                      // [nw][2] running max / sum per wave
+    float* s_o = smem + 2 * nw;              // [nw][d] partial outputs
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.x, h = blockIdx.y;
     const int S = n_head * d;
     const int t = *t_dev;
@@ -58,89 +61,78 @@ __global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ld
     }
     const float scale = 1.0f / sqrtf(sqrtf((float)d));
     const float scale2 = scale * scale;
+    const bool vec = (d % E == 0) && (S % E == 0) && (ldq % E == 0);
 
-    // query slice of this lane: channels (ch*64 + lane)*E .. +E
     float qf[NCH][E];
     const T* qrow = q + (int64_t)n * ldq + h * d;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c0 = (ch * 64 + lane) * E;
+        V qv = vec ? keep_frag<T>(c0 < d, ld_frag<T>(qrow + min(c0, d - E))) : load_row_frag<T>(qrow, true, c0, d, false);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            int i = (ch * 64 + lane) * E + e;
-            qf[ch][e] = i < d ? (float)qrow[i] : 0.f;
-        }
-    const bool vec = (d % E == 0) && (S % E == 0);
+        for (int e = 0; e < E; ++e) qf[ch][e] = (float)qv[e];
+    }
     const T* kbase = kc + ((int64_t)n * cap) * S + h * d;
     const T* vbase = vc + ((int64_t)n * cap) * S + h * d;
 
-    for (int i = wave; i < ks.count; i += nw) {
-        const T* kr = kbase + (int64_t)(ks.start + i * ks.stride) * S;
-        float part = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            int c0 = (ch * 64 + lane) * E;
-            if (vec && c0 + E <= d) {
-                typename Frag<T>::vec kv = *reinterpret_cast<const typename Frag<T>::vec*>(kr + c0);
-#pragma unroll
-                for (int e = 0; e < E; ++e) part += qf[ch][e] * (float)kv[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e)
-                    if (c0 + e < d) part += qf[ch][e] * (float)kr[c0 + e];
-            }
-        }
-        part = jb_wave_sum(part);
-        // reference: w = matmul(q, k) (half result), w.mul_(scale*scale) (half), then .float()
-        if (lane == 0) s_p[i] = jb_round<T>(jb_round<T>(part) * scale2);
-    }
-    __syncthreads();
-
-    // softmax over s_p[0..count) in fp32
-    float m = -INFINITY;
-    for (int i = threadIdx.x; i < ks.count; i += blockDim.x) m = fmaxf(m, s_p[i]);
-    m = jb_wave_max(m);
-    if (lane == 0) s_red[wave] = m;
-    __syncthreads();
-    m = s_red[0];
-    for (int w = 1; w < nw; ++w) m = fmaxf(m, s_red[w]);
-    __syncthreads();
-    float sum = 0.f;
-    for (int i = threadIdx.x; i < ks.count; i += blockDim.x) {
-        float e = expf(s_p[i] - m);
-        s_p[i] = e;
-        sum += e;
-    }
-    sum = jb_wave_sum(sum);
-    if (lane == 0) s_red[wave] = sum;
-    __syncthreads();
-    sum = 0.f;
-    for (int w = 0; w < nw; ++w) sum += s_red[w];
-    const float inv = 1.0f / sum;
-    __syncthreads();
-
-    // out = sum_i round(p_i) * v_i, fp32 accumulation
+    float m_w = -INFINITY, l_w = 0.f;
     float of[NCH][E];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
         for (int e = 0; e < E; ++e) of[ch][e] = 0.f;
-    for (int i = wave; i < ks.count; i += nw) {
-        const T* vr = vbase + (int64_t)(ks.start + i * ks.stride) * S;
-        const float pi = jb_round<T>(s_p[i] * inv);
+
+    for (int i0 = wave; i0 < ks.count; i0 += nw * KB) {
+        V kv[KB][NCH], vv[KB][NCH];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            int c0 = (ch * 64 + lane) * E;
-            if (vec && c0 + E <= d) {
-                typename Frag<T>::vec vv = *reinterpret_cast<const typename Frag<T>::vec*>(vr + c0);
+        for (int b = 0; b < KB; ++b) {
+            const int i = i0 + b * nw;
+            const bool ok = i < ks.count;
+            const int64_t roff = (int64_t)(ks.start + (ok ? i : 0) * ks.stride) * S;
 #pragma unroll
-                for (int e = 0; e < E; ++e) of[ch][e] += pi * (float)vv[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e)
-                    if (c0 + e < d) of[ch][e] += pi * (float)vr[c0 + e];
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c0 = (ch * 64 + lane) * E;
+                if (vec) {   // uniform: unconditional loads at clamped offsets (rows past count / lanes past d are unused)
+                    const int cc = min(c0, d - E);
+                    kv[b][ch] = ld_frag<T>(kbase + roff + cc);
+                    vv[b][ch] = ld_frag<T>(vbase + roff + cc);
+                } else {
+                    kv[b][ch] = load_row_frag<T>(kbase + roff, ok, c0, d, false);
+                    vv[b][ch] = load_row_frag<T>(vbase + roff, ok, c0, d, false);
+                }
             }
         }
+        float part[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            part[b] = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int e = 0; e < E; ++e) part[b] += qf[ch][e] * (float)kv[b][ch][e];
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1)
+#pragma unroll
+            for (int b = 0; b < KB; ++b) part[b] += __shfl_xor(part[b], o2, 64);
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            if (i0 + b * nw >= ks.count) break;
+            // reference: w = matmul(q, k) (half result), w.mul_(scale*scale) (half), then .float()
+            const float sc = jb_round<T>(jb_round<T>(part[b]) * scale2);
+            const float m_new = fmaxf(m_w, sc);
+            const float alpha = expf(m_w - m_new);          // exp(-inf) = 0 on the first key
+            const float pe = expf(sc - m_new);
+            l_w = l_w * alpha + pe;
+            const float pr = jb_round<T>(pe);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int e = 0; e < E; ++e) of[ch][e] = of[ch][e] * alpha + pr * (float)vv[b][ch][e];
+            m_w = m_new;
+        }
     }
+    if (lane == 0) { s_ml[2 * wave] = m_w; s_ml[2 * wave + 1] = l_w; }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -149,10 +141,15 @@ __global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ld
             if (i < d) s_o[wave * d + i] = of[ch][e];
         }
     __syncthreads();
+    float m = -INFINITY;
+    for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);
+    float lsum = 0.f;
+    for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] * expf(s_ml[2 * w] - m);
+    const float inv = 1.0f / lsum;
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
         float a = 0.f;
-        for (int w = 0; w < nw; ++w) a += s_o[w * d + i];
-        o[i] = (T)a;
+        for (int w = 0; w < nw; ++w) a += s_o[w * d + i] * expf(s_ml[2 * w] - m);
+        o[i] = (T)(a * inv);
     }
 }
 
@@ -167,20 +164,17 @@ extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t l
     const int nch = (d_head + 64 * E - 1) / (64 * E);
     if (nch > 2) JB_UNSUPPORTED("d_head too large for the decode attention kernel");
     // long (dense) rows get 16 waves to keep more row loads in flight; short patterns 4
-    const int threads = (attn_func == JB_ATTN_DENSE && max_len > 1024) ? 1024 : 256;
+    const int threads = (attn_func == JB_ATTN_DENSE && max_len > 1024) ? 1024 : 512;
     const int nw = threads / 64;
-    size_t lds = (size_t)(max_len + 32 + nw * d_head) * sizeof(float);
-    if (lds > 160 * 1024) JB_UNSUPPORTED("sequence too long for the LDS score row");
+    size_t lds = (size_t)(2 * nw + nw * d_head) * sizeof(float);
+    (void)max_len;
     dim3 grid(n_batch, n_head);
     hipStream_t s = (hipStream_t)stream;
 #define JB_LAUNCH_DEC(T, NCH)                                                                                   \
     do {                                                                                                        \
-        if (lds > 64 * 1024)                                                                                    \
-            JB_HIP(hipFuncSetAttribute((const void*)attn_decode_kernel<T, NCH>,                                 \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
         attn_decode_kernel<T, NCH><<<grid, threads, lds, s>>>(attn_func, (const T*)q, ldq, (const T*)kcache,    \
                                                               (const T*)vcache, cache_cap, (T*)out, ldo, n_head, \
-                                                              d_head, block_ctx, t_dev, max_len);               \
+                                                              d_head, block_ctx, t_dev);                        \
     } while (0)
     if (dtype == JB_F16) { if (nch == 1) JB_LAUNCH_DEC(f16, 1); else JB_LAUNCH_DEC(f16, 2); }
     else { if (nch == 1) JB_LAUNCH_DEC(float, 1); else JB_LAUNCH_DEC(float, 2); }

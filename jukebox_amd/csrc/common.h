@@ -80,6 +80,36 @@ template <typename T> __device__ __forceinline__ typename Frag<T>::vec jb_zero_f
     return v;
 }
 
+// Operand fragment of one activation row: E consecutive channels from k0.
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::vec load_row_frag(const T* __restrict__ row, bool valid, int k0, int K, bool vec) {
+    constexpr int E = Frag<T>::E;
+    typename Frag<T>::vec v = jb_zero_frag<T>();
+    if (valid) {
+        if (vec && k0 + E <= K) {
+            v = *reinterpret_cast<const typename Frag<T>::vec*>(row + k0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (k0 + e < K) v[e] = row[k0 + e];
+        }
+    }
+    return v;
+}
+
+// Branch-free variants for the fast paths: unconditional 16-byte load (caller clamps the address) and a
+// per-element select.  A guarded load compiles to a branch plus s_waitcnt, which serialises cold loads.
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::vec ld_frag(const T* __restrict__ p) {
+    return *reinterpret_cast<const typename Frag<T>::vec*>(p);
+}
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::vec keep_frag(bool keep, typename Frag<T>::vec v) {
+#pragma unroll
+    for (int e = 0; e < Frag<T>::E; ++e) v[e] = keep ? v[e] : (T)0;
+    return v;
+}
+
 // Round an fp32 value to the storage type and back (models "this tensor is half in the reference").
 template <typename T> __device__ __forceinline__ float jb_round(float x);
 template <> __device__ __forceinline__ float jb_round<float>(float x) { return x; }

@@ -58,6 +58,15 @@ __global__ void embed_kernel(T* __restrict__ out, const int64_t* __restrict__ to
     const float* pe = pos_emb + (int64_t)t * W;
     const float* cd = x_cond ? x_cond + (int64_t)n * xc_n + (int64_t)t * xc_t : nullptr;
     T* o = out + ((int64_t)n * n_t + c) * W;
+    if ((W & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < W; i += blockDim.x * 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + i) + *reinterpret_cast<const f32x4*>(pe + i);
+            if (cd) v += *reinterpret_cast<const f32x4*>(cd + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[i + u] = (T)v[u];
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
         float v = src[i] + pe[i];
         if (cd) v += cd[i];

@@ -59,23 +59,6 @@ extern "C" int jb_pack_weight(const void* src, int src_dtype, int64_t stride_k, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Operand fragment of one activation row: E consecutive channels from k0.
-template <typename T>
-__device__ __forceinline__ typename Frag<T>::vec load_row_frag(const T* __restrict__ row, bool valid, int k0, int K, bool vec) {
-    constexpr int E = Frag<T>::E;
-    typename Frag<T>::vec v = jb_zero_frag<T>();
-    if (valid) {
-        if (vec && k0 + E <= K) {
-            v = *reinterpret_cast<const typename Frag<T>::vec*>(row + k0);
-        } else {
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if (k0 + e < K) v[e] = row[k0 + e];
-        }
-    }
-    return v;
-}
-
 // Shared epilogue: bias -> round -> activation -> residual -> store (incl. the q / k-cache / v-cache split).
 struct EpiParams {
     const float* bias;
@@ -89,7 +72,8 @@ struct EpiParams {
 
 // vals[r] is the accumulator of column jb + r of output row `orow`; cache_row < 0 disables the k/v write.
 template <typename T>
-__device__ __forceinline__ void epilogue_store(const EpiParams& p, f32x4 acc, int64_t orow, int jb, int64_t cache_row) {
+__device__ __forceinline__ void epilogue_store(const EpiParams& p, f32x4 acc, int64_t orow, int jb, int64_t cache_row,
+                                               const float* bias_pre = nullptr, const float* res_pre = nullptr) {
     float v[4];
     bool ok[4];
 #pragma unroll
@@ -98,11 +82,11 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& p, f32x4 acc, in
         ok[r] = j < p.J;
         float x = acc[r];
         if (ok[r]) {
-            if (p.bias) x += jb_round<T>(p.bias[j]);
+            if (p.bias) x += jb_round<T>(bias_pre ? bias_pre[r] : p.bias[j]);
             x = jb_round<T>(x);
             x = jb_apply_act<T>(x, p.act);
             if (p.res) {
-                float rr = (float)((const T*)p.res)[orow * p.ldr + j];
+                float rr = res_pre ? res_pre[r] : (float)((const T*)p.res)[orow * p.ldr + j];
                 x = (p.res_scale == 1.0f) ? jb_round<T>(rr + x) : jb_round<T>(rr + jb_round<T>(p.res_scale * x));
             }
         }
@@ -157,7 +141,7 @@ struct GemmParams {
 
 // Block = 4 waves; wave w owns 64 rows (4 m-tiles) x 64 columns (4 j-tiles) of the 256 x 64 block tile.
 // Weight fragments are shared by the 4 waves through L1/L2; activations are private to a wave.
-template <typename T>
+template <typename T, bool FAST>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     using V = typename Frag<T>::vec;
     constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
@@ -200,13 +184,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
                 int jtg = jt_base + jt;
-                wf[jt] = jb_zero_frag<T>();
-                if (jtg < p.njt) wf[jt] = *reinterpret_cast<const V*>(wtap + ((int64_t)jtg * p.nkt + kt) * (64 * E));
+                if (FAST) {
+                    wf[jt] = ld_frag<T>(wtap + ((int64_t)min(jtg, p.njt - 1) * p.nkt + kt) * (64 * E));
+                } else {
+                    wf[jt] = jb_zero_frag<T>();
+                    if (jtg < p.njt) wf[jt] = *reinterpret_cast<const V*>(wtap + ((int64_t)jtg * p.nkt + kt) * (64 * E));
+                }
             }
             const int k0 = kt * KT + g * E;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                af[mt] = load_row_frag<T>(arow[mt], aval[mt], k0, p.K, p.vec_a);
+                if (FAST) af[mt] = keep_frag<T>(aval[mt], ld_frag<T>(arow[mt] + k0));
+                else af[mt] = load_row_frag<T>(arow[mt], aval[mt], k0, p.K, p.vec_a);
                 if (p.pre_relu) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) af[mt][e] = af[mt][e] > (T)0 ? af[mt][e] : (T)0;
@@ -266,10 +255,14 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     p.epi.cache_cap = a->cache_cap;
     p.epi.vec_out = !a->qkv_split && (a->ldo % 4 == 0) && aligned_to(a->out, 4 * esz);
     dim3 grid((unsigned)((p.m_total + 255) / 256), (unsigned)((p.njt + 3) / 4));
-    if (a->dtype == JB_F16)
-        gemm_kernel<f16><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else
-        gemm_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    const int KT = a->dtype == JB_F16 ? 32 : 16;
+    const bool fast = p.vec_a && (a->K % KT == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == JB_F16) {
+        if (fast) gemm_kernel<f16, true><<<grid, 256, 0, st>>>(p); else gemm_kernel<f16, false><<<grid, 256, 0, st>>>(p);
+    } else {
+        if (fast) gemm_kernel<float, true><<<grid, 256, 0, st>>>(p); else gemm_kernel<float, false><<<grid, 256, 0, st>>>(p);
+    }
     JB_CHECK_LAUNCH();
     return JB_OK;
 }
@@ -279,124 +272,401 @@ struct GemvParams {
     const void* x; int64_t ldx; int n_rows;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     const void* W; int K, nkt;
-    int vec_x;
+    int vec_x, lds_pitch, fast;
+    long long* dbg;
     const int* t_dev;
     EpiParams epi;
 };
 
 // Decode-step GEMM: n_rows <= 16*MT activation rows against a K x J weight matrix that is read from
-// HBM exactly once per launch.  One workgroup per 16-column tile; its 4 waves split the k-tiles, each
+// HBM exactly once per launch.  One workgroup per 16-column tile; its NW waves split the k-tiles, each
 // streaming 1 KiB weight fragments straight into MFMA operands (non-temporal: a weight byte is used
-// once per step), then the four partial 16x16 tiles are summed in a fixed order through LDS
-// (deterministic; no atomics).  LayerNorm of the activation rows is recomputed per workgroup from
-// L2 (the rows are <= 64 x W) and applied while building the B operand.
-template <typename T, int MT>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvParams p) {
+// once per step) in batches of WB loads issued back to back.  The kernel is latency-bound -- a whole
+// projection is about one bandwidth-delay product and L2 is cold after every kernel boundary -- so it
+// is organised as ONE dependent memory round trip: weights, activation rows, residual and bias are
+// all requested up front; with LayerNorm (LNS) the rows are staged once into LDS, normalised there
+// (fp32 statistics, two passes over LDS) and the B operands are read back with ds_read_b128.
+// The NW partial 16x16 tiles are summed in a fixed order through LDS (deterministic; no atomics).
+template <typename T>
+__device__ __forceinline__ float frag_sum(typename Frag<T>::vec v) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < Frag<T>::E; ++e) s += (float)v[e];
+    return s;
+}
+
+#ifdef JB_TIMING
+#define JB_STAMP(i) do { if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) { p.dbg[2 * (i)] = clock64(); p.dbg[2 * (i) + 1] = wall_clock64(); } } while (0)
+#else
+#define JB_STAMP(i) do { } while (0)
+#endif
+
+template <typename T, int MT, int NW, bool LNS, bool FAST, int NV>
+__global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     using V = typename Frag<T>::vec;
     constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
-    __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
-    __shared__ f32x4 s_acc[4][MT][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int WB = MT <= 2 ? 8 : 4;   // weight (and activation) fragments in flight per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    f32x4* s_acc = reinterpret_cast<f32x4*>(s_dyn);                 // [NW][MT][64]
+    T* s_x = reinterpret_cast<T*>(s_dyn + NW * MT * 64 * sizeof(f32x4));   // [16*MT][pitch] (LNS only)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform -> scalar branches
     const int g = lane >> 4, c = lane & 15;
     const int jt = blockIdx.x;
     const T* x = (const T*)p.x;
-    const bool ln = p.ln_gamma != nullptr;
+    const int pitch = p.lds_pitch;        // elements, multiple of E
 
-    // issue the first weight loads before the LayerNorm statistics so they overlap
-    const int kt0 = (wave * p.nkt) / 4, kt1 = ((wave + 1) * p.nkt) / 4;
+    const int kt0 = (wave * p.nkt) / NW, kt1 = ((wave + 1) * p.nkt) / NW;
     const T* wbase = (const T*)p.W + ((int64_t)jt * p.nkt) * (64 * E) + (int64_t)lane * E;
 
-    if (ln) {
-        for (int r = wave; r < p.n_rows; r += 4) {
-            const T* xr = x + (int64_t)r * p.ldx;
-            float s = 0.f;
-            for (int k = lane; k < p.K; k += 64) s += (float)xr[k];
-            s = jb_wave_sum(s);
-            const float mean = s / (float)p.K;
-            float q = 0.f;
-            for (int k = lane; k < p.K; k += 64) {
-                float d = (float)xr[k] - mean;
-                q += d * d;
+    JB_STAMP(0);
+    // ---- everything this workgroup needs from memory is requested here ----
+    V wf[WB];
+#pragma unroll
+    for (int i = 0; i < WB; ++i) {
+        if (FAST) {   // clamped, unconditional: tiles past kt1 are loaded but never multiplied
+            wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)min(kt0 + i, p.nkt - 1) * (64 * E)));
+        } else {
+            wf[i] = jb_zero_frag<T>();
+            if (kt0 + i < kt1) wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)(kt0 + i) * (64 * E)));
+        }
+    }
+    int t = 0;
+    float rpre[MT][4], bpre[4];
+    const int jb = jt * 16 + g * 4;
+    if (FAST || wave == 0) {
+        if (p.epi.qkv_split) t = *p.t_dev;
+        if (FAST) {   // J % 4 == 0, aligned: one vector load each, clamped rows, no per-element branches
+            const int jc = min(jb, p.epi.J - 4);
+            if (p.epi.bias) {
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(p.epi.bias + jc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bpre[r] = b4[r];
             }
-            q = jb_wave_sum(q);
-            if (lane == 0) {
-                s_mean[r] = mean;
-                s_rstd[r] = 1.0f / sqrtf(q / (float)p.K + p.ln_eps);
+            if (p.epi.res) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const T* rp = (const T*)p.epi.res + (int64_t)min(mt * 16 + c, p.n_rows - 1) * p.epi.ldr + jc;
+                    if constexpr (sizeof(T) == 2) {
+                        f16x4 r4 = *reinterpret_cast<const f16x4*>(rp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rpre[mt][r] = (float)r4[r];
+                    } else {
+                        f32x4 r4 = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rpre[mt][r] = r4[r];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bpre[r] = (p.epi.bias && jb + r < p.epi.J) ? p.epi.bias[jb + r] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = mt * 16 + c;
+                    rpre[mt][r] = (p.epi.res && row < p.n_rows && jb + r < p.epi.J)
+                                      ? (float)((const T*)p.epi.res)[(int64_t)row * p.epi.ldr + jb + r] : 0.f;
+                }
+        }
+    }
+
+    if constexpr (LNS && FAST && NV > 0) {
+        // Register path: a wave owns whole rows (r0 = wave, r1 = wave + NW, next round +2NW ...).  Lane l holds
+        // vectors l, l+64, ... of each row (NV per row), so the fp32 mean / variance come from registers with two
+        // wave reductions, gamma/beta are read as vectors from L2, and the normalised row is written to LDS once.
+        constexpr int RW = NV <= 4 ? 2 : 1;                 // rows in flight per wave
+        const int nvec = p.K / E;                           // whole vectors per row (K % KT == 0)
+        for (int rb = wave; rb < p.n_rows; rb += RW * NW) {
+            V xv[RW][NV];
+            float gm[NV][E], bt[NV][E];
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                const int r = min(rb + j * NW, p.n_rows - 1);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) xv[j][i] = ld_frag<T>(x + (int64_t)r * p.ldx + (int64_t)min(lane + 64 * i, nvec - 1) * E);
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k0 = min(lane + 64 * i, nvec - 1) * E;
+#pragma unroll
+                for (int e4 = 0; e4 < E; e4 += 4) {
+                    f32x4 g4 = *reinterpret_cast<const f32x4*>(p.ln_gamma + k0 + e4);
+                    f32x4 b4 = *reinterpret_cast<const f32x4*>(p.ln_beta + k0 + e4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { gm[i][e4 + u] = g4[u]; bt[i][e4 + u] = b4[u]; }
+                }
+            }
+            float sm[RW], sq[RW], mean[RW], rstd[RW];
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                sm[j] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) sm[j] += (lane + 64 * i < nvec) ? frag_sum<T>(xv[j][i]) : 0.f;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int j = 0; j < RW; ++j) sm[j] += __shfl_xor(sm[j], o, 64);
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                mean[j] = sm[j] / (float)p.K;
+                sq[j] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    float q = 0.f;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { float d = (float)xv[j][i][e] - mean[j]; q += d * d; }
+                    sq[j] += (lane + 64 * i < nvec) ? q : 0.f;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int j = 0; j < RW; ++j) sq[j] += __shfl_xor(sq[j], o, 64);
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                rstd[j] = 1.0f / sqrtf(sq[j] / (float)p.K + p.ln_eps);
+                const int r = rb + j * NW;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    V y;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) y[e] = (T)(((float)xv[j][i][e] - mean[j]) * rstd[j] * gm[i][e] + bt[i][e]);
+                    if (r < p.n_rows && lane + 64 * i < nvec) *reinterpret_cast<V*>(s_x + (int64_t)r * pitch + (int64_t)(lane + 64 * i) * E) = y;
+                }
             }
         }
         __syncthreads();
+    } else if constexpr (LNS) {
+        // (1) all threads: raw rows + gamma/beta -> LDS, XB independent 16-byte requests per thread per round
+        constexpr int XB = 8;
+        const int vpr = pitch / E;                          // vectors per row
+        const int total = p.n_rows * vpr;
+        for (int base = threadIdx.x; base < total; base += NW * 64 * XB) {
+            V tmp[XB];
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                int idx = base + u * NW * 64;
+                int r = idx / vpr, k0 = (idx - r * vpr) * E;
+                if (FAST) {   // K % KT == 0: every vector below K is whole; the pad vector (k0 == K) becomes zero
+                    int rc = min(r, p.n_rows - 1);
+                    tmp[u] = keep_frag<T>(k0 < p.K, ld_frag<T>(x + (int64_t)rc * p.ldx + min(k0, p.K - E)));
+                } else {
+                    tmp[u] = load_row_frag<T>(x + (int64_t)r * p.ldx, idx < total, k0, p.K, p.vec_x);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                int idx = base + u * NW * 64;
+                if (idx < total) {
+                    int r = idx / vpr, k0 = (idx - r * vpr) * E;
+                    *reinterpret_cast<V*>(s_x + (int64_t)r * pitch + k0) = tmp[u];
+                }
+            }
+        }
+        JB_STAMP(1);
+        float* s_g = reinterpret_cast<float*>(s_x + (int64_t)16 * MT * pitch);   // [pitch] gamma, then [pitch] beta
+        float* s_b = s_g + pitch;
+        for (int k = threadIdx.x; k < pitch; k += NW * 64) {
+            s_g[k] = k < p.K ? p.ln_gamma[k] : 0.f;
+            s_b[k] = k < p.K ? p.ln_beta[k] : 0.f;
+        }
+        __syncthreads();
+        JB_STAMP(2);
+        // (2) rows r0 = wave (+2NW, ...) and r1 = r0 + NW together: fp32 mean / variance and normalisation, all
+        //     from LDS with 16-byte reads (gamma/beta as f32x4: a scalar read at this lane stride is 8-way conflicted)
+        for (int r0 = wave; r0 < p.n_rows; r0 += 2 * NW) {
+            const bool two = r0 + NW < p.n_rows;
+            T* sa = s_x + (int64_t)r0 * pitch;
+            T* sb = s_x + (int64_t)(two ? r0 + NW : r0) * pitch;
+            float s0 = 0.f, s1 = 0.f;
+            for (int k0 = lane * E; k0 < pitch; k0 += 64 * E) {
+                s0 += frag_sum<T>(*reinterpret_cast<const V*>(sa + k0));
+                s1 += frag_sum<T>(*reinterpret_cast<const V*>(sb + k0));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+            const float mean0 = s0 / (float)p.K, mean1 = s1 / (float)p.K;
+            float q0 = 0.f, q1 = 0.f;
+            for (int k0 = lane * E; k0 < pitch; k0 += 64 * E) {
+                V va = *reinterpret_cast<const V*>(sa + k0), vb = *reinterpret_cast<const V*>(sb + k0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const float w = (FAST ? k0 < p.K : k0 + e < p.K) ? 1.f : 0.f;
+                    float da = (float)va[e] - mean0, db = (float)vb[e] - mean1;
+                    q0 += w * da * da;
+                    q1 += w * db * db;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { q0 += __shfl_xor(q0, o, 64); q1 += __shfl_xor(q1, o, 64); }
+            const float rstd0 = 1.0f / sqrtf(q0 / (float)p.K + p.ln_eps), rstd1 = 1.0f / sqrtf(q1 / (float)p.K + p.ln_eps);
+            for (int k0 = lane * E; k0 < pitch; k0 += 64 * E) {
+                V va = *reinterpret_cast<const V*>(sa + k0), vb = *reinterpret_cast<const V*>(sb + k0);
+                float gm[E], bt[E];
+#pragma unroll
+                for (int e4 = 0; e4 < E; e4 += 4) {
+                    f32x4 g4 = *reinterpret_cast<const f32x4*>(s_g + k0 + e4);
+                    f32x4 b4 = *reinterpret_cast<const f32x4*>(s_b + k0 + e4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { gm[e4 + u] = g4[u]; bt[e4 + u] = b4[u]; }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool in = FAST ? (k0 < p.K) : (k0 + e < p.K);
+                    va[e] = in ? (T)(((float)va[e] - mean0) * rstd0 * gm[e] + bt[e]) : (T)0;
+                    vb[e] = in ? (T)(((float)vb[e] - mean1) * rstd1 * gm[e] + bt[e]) : (T)0;
+                }
+                *reinterpret_cast<V*>(sa + k0) = va;
+                if (two) *reinterpret_cast<V*>(sb + k0) = vb;
+            }
+        }
+        JB_STAMP(3);
+        __syncthreads();
+        JB_STAMP(4);
     }
 
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mean[MT], rstd[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int row = mt * 16 + c;
-        mean[mt] = (ln && row < p.n_rows) ? s_mean[row] : 0.f;
-        rstd[mt] = (ln && row < p.n_rows) ? s_rstd[row] : 0.f;
-    }
 
-#pragma unroll 4
-    for (int kt = kt0; kt < kt1; ++kt) {
-        V wf = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)kt * (64 * E)));
-        const int k0 = kt * KT + g * E;
-        float gam[E], bet[E];
-        if (ln) {
+    for (int kb = kt0; kb < kt1; kb += WB) {
+        if (kb != kt0) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                int k = k0 + e;
-                gam[e] = k < p.K ? p.ln_gamma[k] : 0.f;
-                bet[e] = k < p.K ? p.ln_beta[k] : 0.f;
+            for (int i = 0; i < WB; ++i) {
+                if (FAST) wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)min(kb + i, p.nkt - 1) * (64 * E)));
+                else if (kb + i < kt1) wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)(kb + i) * (64 * E)));
             }
         }
+        if (FAST) {
+            // all activation fragments of the batch are requested before the first MFMA; tiles past kt1 are
+            // neutralised by zeroing their weight fragment (no branch anywhere in the batch)
+            V xf[WB][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int row = mt * 16 + c;
-            V xf = load_row_frag<T>(x + (int64_t)row * p.ldx, row < p.n_rows, k0, p.K, p.vec_x);
-            if (ln) {
+            for (int i = 0; i < WB; ++i) {
+                const int k0 = min(kb + i, p.nkt - 1) * KT + g * E;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    float y = ((float)xf[e] - mean[mt]) * rstd[mt] * gam[e] + bet[e];
-                    xf[e] = (k0 + e < p.K) ? (T)y : (T)0;
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int row = min(mt * 16 + c, p.n_rows - 1);
+                    if (LNS) xf[i][mt] = *reinterpret_cast<const V*>(s_x + (int64_t)row * pitch + k0);
+                    else xf[i][mt] = ld_frag<T>(x + (int64_t)row * p.ldx + k0);
                 }
             }
-            acc[mt] = jb_mfma(wf, xf, acc[mt]);
+#pragma unroll
+            for (int i = 0; i < WB; ++i) {
+                const V w = keep_frag<T>(kb + i < kt1, wf[i]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = jb_mfma(w, xf[i][mt], acc[mt]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < WB; ++i) {
+                if (kb + i >= kt1) break;
+                const int k0 = (kb + i) * KT + g * E;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    int row = mt * 16 + c;
+                    V xf;
+                    if (LNS) {
+                        xf = jb_zero_frag<T>();
+                        if (row < p.n_rows && k0 < pitch) xf = *reinterpret_cast<const V*>(s_x + (int64_t)row * pitch + k0);
+                    } else {
+                        xf = load_row_frag<T>(x + (int64_t)row * p.ldx, row < p.n_rows, k0, p.K, p.vec_x);
+                    }
+                    acc[mt] = jb_mfma(wf[i], xf, acc[mt]);
+                }
+            }
         }
     }
+    JB_STAMP(5);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) s_acc[wave][mt][lane] = acc[mt];
+    for (int mt = 0; mt < MT; ++mt) s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
     __syncthreads();
+    JB_STAMP(6);
     if (wave != 0) return;
 
-    int t = 0;
-    if (p.epi.qkv_split) t = *p.t_dev;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int row = mt * 16 + c;
         if (row >= p.n_rows) continue;
-        f32x4 v = s_acc[0][mt][lane];
-        v += s_acc[1][mt][lane];
-        v += s_acc[2][mt][lane];
-        v += s_acc[3][mt][lane];
-        int jb = jt * 16 + g * 4;
+        f32x4 v = s_acc[mt * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += s_acc[(w * MT + mt) * 64 + lane];
         int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
-        if (jb < p.epi.J) epilogue_store<T>(p.epi, v, row, jb, cache_row);
+        if (jb < p.epi.J) epilogue_store<T>(p.epi, v, row, jb, cache_row, bpre, rpre[mt]);
+    }
+    JB_STAMP(7);
+}
+
+template <typename T, int MT, int NW, bool LNS, bool FAST, int NV>
+static int launch_gemv_fast(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
+    static bool configured = false;
+    if (lds > 64 * 1024 && !configured) {
+        JB_HIP(hipFuncSetAttribute((const void*)gemv_kernel<T, MT, NW, LNS, FAST, NV>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    gemv_kernel<T, MT, NW, LNS, FAST, NV><<<njt, NW * 64, lds, s>>>(p);
+    return JB_OK;
+}
+
+template <typename T, int MT, int NW, bool LNS>
+static int launch_gemv_inst(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
+    if (!p.fast) return launch_gemv_fast<T, MT, NW, LNS, false, 0>(p, njt, lds, s);
+    if (LNS) {
+        // vectors per lane per row on the register LayerNorm path (0 = staged-through-LDS variant)
+        const int nv = (p.K / Frag<T>::E + 63) / 64;
+        if (nv <= 2) return launch_gemv_fast<T, MT, NW, LNS, true, LNS ? 2 : 0>(p, njt, lds, s);
+        if (nv <= 4) return launch_gemv_fast<T, MT, NW, LNS, true, LNS ? 4 : 0>(p, njt, lds, s);
+        if (nv <= 8) return launch_gemv_fast<T, MT, NW, LNS, true, LNS ? 8 : 0>(p, njt, lds, s);
+    }
+    return launch_gemv_fast<T, MT, NW, LNS, true, 0>(p, njt, lds, s);
+}
+
+template <typename T, int NW, bool LNS>
+static int launch_gemv_nw(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
+    int mt = (p.n_rows + 15) / 16;
+    switch (mt) {
+        case 1: return launch_gemv_inst<T, 1, NW, LNS>(p, njt, lds, s);
+        case 2: return launch_gemv_inst<T, 2, NW, LNS>(p, njt, lds, s);
+        case 3: return launch_gemv_inst<T, 3, NW, LNS>(p, njt, lds, s);
+        default: return launch_gemv_inst<T, 4, NW, LNS>(p, njt, lds, s);
     }
 }
 
 template <typename T>
-static int launch_gemv(const GemvParams& p, int njt, hipStream_t s) {
-    int mt = (p.n_rows + 15) / 16;
-    switch (mt) {
-        case 1: gemv_kernel<T, 1><<<njt, 256, 0, s>>>(p); break;
-        case 2: gemv_kernel<T, 2><<<njt, 256, 0, s>>>(p); break;
-        case 3: gemv_kernel<T, 3><<<njt, 256, 0, s>>>(p); break;
-        default: gemv_kernel<T, 4><<<njt, 256, 0, s>>>(p); break;
+static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
+    constexpr int E = Frag<T>::E;
+    const int mt = (p.n_rows + 15) / 16;
+    // 8 waves when every wave still gets >= 4 k-tiles (more bytes in flight per CU), else 4
+    int nw = p.nkt >= 32 ? 8 : 4;
+    if (ln && nw == 8) {   // keep the staged rows + partial tiles within the 160 KiB of LDS
+        size_t pit = ((p.K + E - 1) / E) * E + E;
+        size_t need = (size_t)8 * mt * 64 * sizeof(f32x4) + (size_t)16 * mt * pit * sizeof(T) + 2 * pit * sizeof(float);
+        if (need > 160 * 1024) nw = 4;
     }
-    return 0;
+    size_t lds = (size_t)nw * mt * 64 * sizeof(f32x4);
+    if (ln) {
+        // row pitch: K rounded up to E, plus one 16-byte slot so that the 16 rows of a fragment read
+        // fall into different LDS slots (cdna_hip_programming.md Guideline 4)
+        p.lds_pitch = ((p.K + E - 1) / E) * E + E;
+        lds += (size_t)16 * mt * p.lds_pitch * sizeof(T) + (size_t)2 * p.lds_pitch * sizeof(float);
+        if (lds > 160 * 1024) {
+            jb_set_error("jb_gemv: LayerNorm rows do not fit in LDS (n_rows x K too large)");
+            return JB_ERR_UNSUPPORTED;
+        }
+        return nw == 8 ? launch_gemv_nw<T, 8, true>(p, njt, lds, s) : launch_gemv_nw<T, 4, true>(p, njt, lds, s);
+    }
+    p.lds_pitch = 0;
+    return nw == 8 ? launch_gemv_nw<T, 8, false>(p, njt, lds, s) : launch_gemv_nw<T, 4, false>(p, njt, lds, s);
 }
+
+#ifdef JB_TIMING
+long long* jb_dbg_ptr = nullptr;
+extern "C" void jb_set_dbg(long long* p) { jb_dbg_ptr = p; }
+#endif
 
 extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     JB_REQUIRE(a && a->x && a->W && a->out, "null pointer");
@@ -414,13 +684,26 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     p.W = a->W; p.K = a->K;
     p.vec_x = (a->ldx % E == 0) && aligned_to(a->x, 16);
     p.t_dev = a->t_dev;
+    p.dbg = nullptr;
+#ifdef JB_TIMING
+    p.dbg = jb_dbg_ptr;
+#endif
+    {   // branch-free fast path: whole k-tiles, vector-aligned activations / bias / residual / output
+        const int KT = a->dtype == JB_F16 ? 32 : 16;
+        bool f = p.vec_x && (a->K % KT == 0) && (a->J % 4 == 0) && (a->J >= 4);
+        if (a->bias) f = f && aligned_to(a->bias, 16);
+        if (a->res) f = f && (a->ldr % 4 == 0) && aligned_to(a->res, 4 * esz);
+        if (a->ln_gamma) f = f && (a->K >= E);
+        p.fast = f;
+    }
     p.epi.bias = a->bias; p.epi.out = a->out; p.epi.ldo = a->ldo; p.epi.res = a->res; p.epi.ldr = a->ldr;
     p.epi.J = a->J; p.epi.act = a->act; p.epi.res_scale = 1.0f;
     p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
     p.epi.cache_cap = a->cache_cap;
     p.epi.vec_out = !a->qkv_split && (a->ldo % 4 == 0) && aligned_to(a->out, 4 * esz);
-    if (a->dtype == JB_F16) launch_gemv<f16>(p, njt, (hipStream_t)stream);
-    else launch_gemv<float>(p, njt, (hipStream_t)stream);
+    int rc = a->dtype == JB_F16 ? launch_gemv<f16>(p, njt, a->ln_gamma != nullptr, (hipStream_t)stream)
+                                : launch_gemv<float>(p, njt, a->ln_gamma != nullptr, (hipStream_t)stream);
+    if (rc != JB_OK) return rc;
     JB_CHECK_LAUNCH();
     return JB_OK;
 }

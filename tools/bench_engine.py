@@ -1,0 +1,85 @@
+"""Micro-benchmark of the decode engine at production dimensions with random weights:
+ms per decode step (eager vs hipGraph) and achieved HBM GB/s against the algorithmic bytes of
+SURVEY.md section 8d.  Usage: python tools/bench_engine.py [1b|up|small] [--steps K] [--t0 T] [--fp32]"""
+import argparse
+import time
+
+import torch
+
+from jukebox_amd.engine import PriorEngine, attn_funcs
+
+CFGS = {
+    "1b": dict(seq_len=6528, bins=2127, width=2048, depth=72, heads=2, attn_order=12, blocks=64, prime_len=384, y_cond=True),
+    "up": dict(seq_len=8192, bins=2048, width=1920, depth=72, heads=1, attn_order=2, blocks=128, y_cond=True),
+    "small": dict(seq_len=8192, bins=1024, width=1024, depth=48, heads=1, attn_order=2, blocks=64, y_cond=False),
+}
+
+
+def random_state(cfg, dev, scale=0.02):
+    W, D, B, T = cfg["width"], cfg["depth"], cfg["bins"], cfg["seq_len"]
+    S = W // 4
+    g = torch.Generator(device=dev).manual_seed(0)
+    r = lambda *s, sc=scale: torch.randn(*s, device=dev, generator=g) * sc
+    sd = {"x_emb.weight": r(B, W), "pos_emb.pos_emb": r(T, W, sc=0.01), "start_token": r(1, W, sc=0.01)}
+    sd["x_out.weight"] = sd["x_emb.weight"]
+    for d in range(D):
+        p = f"transformer._attn_mods.{d}."
+        sd[p + "attn.c_attn.w"], sd[p + "attn.c_attn.b"] = r(W, 3 * S), torch.zeros(3 * S, device=dev)
+        sd[p + "attn.c_proj.w"], sd[p + "attn.c_proj.b"] = r(S, W), torch.zeros(W, device=dev)
+        sd[p + "mlp.c_fc.w"], sd[p + "mlp.c_fc.b"] = r(W, W), torch.zeros(W, device=dev)
+        sd[p + "mlp.c_proj.w"], sd[p + "mlp.c_proj.b"] = r(W, W), torch.zeros(W, device=dev)
+        for ln in ("ln_0", "ln_1"):
+            sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(W, device=dev), torch.zeros(W, device=dev)
+    return sd
+
+
+def step_bytes(cfg, N, t, esz):
+    """Algorithmic HBM bytes of one decode step at position t (weights once + k/v rows read + k/v written + logits head)."""
+    W, D, B = cfg["width"], cfg["depth"], cfg["bins"]
+    S, M = W // 4, W
+    bc = cfg["seq_len"] // cfg["blocks"] if cfg.get("blocks") else 0
+    pl = (cfg["prime_len"] // cfg["blocks"] + 1) * cfg["blocks"] if cfg.get("prime_len") else 0
+    per_layer_w = (3 * W * S + S * W + 2 * W * M) * esz
+    kv = 0
+    for f in attn_funcs(cfg["attn_order"], D):
+        ln = {0: t + 1, 1: t % bc + 1 if bc else 0, 2: t // bc + 1 if bc else 0, 3: bc if bc and t >= bc else 0,
+              7: min(t + 1, pl)}[f]
+        kv += ln * S * 2 * esz * N + S * 2 * esz * N
+    return D * per_layer_w + kv + B * W * 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("model", nargs="?", default="up")
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--t0", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--eager", action="store_true")
+    a = ap.parse_args()
+    cfg = CFGS[a.model]
+    dev = torch.device("cuda:0")
+    sd = random_state(cfg, dev)
+    eng = PriorEngine(sd, "", n_batch=a.batch, fp16=not a.fp32, chunk_cap=64, **cfg)
+    y = torch.randn(a.batch, 1, cfg["width"], device=dev) * 0.01 if cfg["y_cond"] else None
+    xc = torch.randn(a.batch, cfg["seq_len"], cfg["width"], device=dev) * 0.01
+    eng.set_cond(xc, y)
+    eng.set_sampling(temp=0.99, seed=1)
+    del sd
+    torch.cuda.synchronize()
+    print(f"model={a.model} N={a.batch} dtype={'f32' if a.fp32 else 'f16'} weights={eng.weight_bytes() / 1e9:.2f} GB "
+          f"kv={eng.cache_bytes() / 1e9:.2f} GB launches/step={eng.launches_per_step}")
+    for use_graph in ([False] if a.eager else [False, True]):
+        eng.decode(a.t0, 8, use_graph=use_graph)      # warm-up (+ capture)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        eng.decode(a.t0, a.steps, use_graph=use_graph)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / a.steps
+        b = step_bytes(cfg, a.batch, a.t0 + a.steps // 2, 4 if a.fp32 else 2)
+        print(f"  graph={use_graph}: {dt * 1e3:.3f} ms/step  algorithmic {b / 1e9:.3f} GB/step -> {b / dt / 1e12:.2f} TB/s "
+              f"({b / dt / 8e12 * 100:.1f}% of 8 TB/s)")
+
+
+if __name__ == "__main__":
+    main()
