@@ -1,0 +1,153 @@
+"""Label vectors `y` for the priors (jukebox/data/labels.py).  y = [total_length, offset, sample_length,
+artist_id, genre_ids..., lyric_tokens...] (int64).
+
+Artist / genre / character vocabularies live in the reference's `jukebox/data/ids/*.txt`, which are data files
+of the reference distribution and are not copied here: `Labeller.get_label` needs `JUKEBOX_IDS_DIR` to point at
+them; `get_y_from_ids` / `get_batch_labels_from_ids` (what the benchmark and the tests use) need nothing."""
+import os
+import re
+
+import numpy as np
+import torch as t
+
+
+def get_relevant_lyric_tokens(full_tokens, n_tokens, total_length, offset, duration, f32=False):
+    """labels.py:7-20: a window of n_tokens lyric characters centred on the audio window's midpoint (left-padded
+    with 0 when the lyrics are short).  f32: the per-window re-labelling (set_y_lyric_tokens) feeds 0-dim int64
+    tensors, so the reference evaluates the midpoint in float32 -- mirrored here for sample-exact windows."""
+    if len(full_tokens) < n_tokens:
+        tokens = [0] * (n_tokens - len(full_tokens)) + full_tokens
+        indices = [-1] * (n_tokens - len(full_tokens)) + list(range(0, len(full_tokens)))
+    else:
+        assert 0 <= offset < total_length
+        if f32:
+            f = np.float32
+            midpoint = int(f(len(full_tokens)) * (f(offset) + f(duration) / f(2.0)) / f(total_length))
+        else:
+            midpoint = int(len(full_tokens) * (offset + duration / 2.0) / total_length)
+        midpoint = min(max(midpoint, n_tokens // 2), len(full_tokens) - n_tokens // 2)
+        tokens = full_tokens[midpoint - n_tokens // 2:midpoint + n_tokens // 2]
+        indices = list(range(midpoint - n_tokens // 2, midpoint + n_tokens // 2))
+    assert len(tokens) == n_tokens and len(indices) == n_tokens
+    return tokens, indices
+
+
+class EmptyLabeller:
+    def get_label(self, artist=None, genre=None, lyrics=None, total_length=None, offset=None):
+        return dict(y=np.array([], dtype=np.int64), info=dict(artist="n/a", genre="n/a", lyrics=[], full_tokens=[]))
+
+    def get_batch_labels(self, metas, device="cpu"):
+        ys = t.zeros((len(metas), 0), dtype=t.long, device=device)
+        return dict(y=ys, info=[self.get_label()["info"] for _ in metas])
+
+
+class TextProcessor:
+    """data/text_processor.py: character vocabulary (v3: 79 symbols incl. <unk>=0)."""
+
+    def __init__(self, v3=False):
+        extra = "" if v3 else "+"
+        vocab = ("ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789.,:;!?-" + extra + "'\"()[] \t\n")
+        self.not_vocab = re.compile("[^A-Za-z0-9.,:;!?\\-" + ("" if v3 else "+") + "'\"()\\[\\] \t\n]+")
+        self.vocab = {c: i + 1 for i, c in enumerate(vocab)}
+        self.vocab["<unk>"] = 0
+        self.n_vocab = len(vocab) + 1
+        self.tokens = {v: k for k, v in self.vocab.items()}
+        self.tokens[0] = ""
+
+    def clean(self, text):
+        text = text.encode("ascii", "ignore").decode()      # the reference uses unidecode (not installed here)
+        text = text.replace("\\", "\n")
+        return self.not_vocab.sub("", text)
+
+    def tokenise(self, text):
+        return [self.vocab[c] for c in text]
+
+    def textise(self, tokens):
+        return "".join(self.tokens[tok] for tok in tokens)
+
+
+class ArtistGenreProcessor:
+    """data/artist_genre_processor.py: name -> id tables read from the reference's ids/*.txt."""
+
+    def __init__(self, v3=False, ids_dir=None):
+        self.v3 = v3
+        ids_dir = ids_dir or os.environ.get("JUKEBOX_IDS_DIR")
+        self.artist_ids, self.genre_ids = {}, {}
+        if ids_dir:
+            ver = "v3" if v3 else "v2"
+            for attr, fn in (("artist_ids", f"{ver}_artist_ids.txt"), ("genre_ids", f"{ver}_genre_ids.txt")):
+                with open(os.path.join(ids_dir, fn), encoding="utf-8") as f:
+                    for line in f:
+                        name, idx = line.strip().split(";")
+                        getattr(self, attr)[name.lower()] = int(idx)
+
+    @staticmethod
+    def _norm(s):
+        s = "".join(c if c.isascii() and c.isalnum() else "_" for c in s.lower())
+        return re.sub(r"_+", "_", s).strip("_")
+
+    def get_artist_id(self, artist):
+        return self.artist_ids.get(artist.lower() if self.v3 else self._norm(artist), 0)
+
+    def get_genre_ids(self, genre):
+        genres = [genre.lower()] if self.v3 else self._norm(genre).split("_")
+        return [self.genre_ids.get(w, 0) for w in genres]
+
+
+class Labeller:
+    def __init__(self, max_genre_words, n_tokens, sample_length, v3=False):
+        self.ag_processor = ArtistGenreProcessor(v3)
+        self.text_processor = TextProcessor(v3)
+        self.n_tokens, self.max_genre_words, self.sample_length = n_tokens, max_genre_words, sample_length
+        self.label_shape = (4 + self.max_genre_words + self.n_tokens,)
+
+    def get_label(self, artist, genre, lyrics, total_length, offset):
+        artist_id = self.ag_processor.get_artist_id(artist)
+        genre_ids = self.ag_processor.get_genre_ids(genre)
+        lyrics = self.text_processor.clean(lyrics)
+        full_tokens = self.text_processor.tokenise(lyrics)
+        tokens, _ = get_relevant_lyric_tokens(full_tokens, self.n_tokens, total_length, offset, self.sample_length)
+        y = self.get_y_from_ids(artist_id, genre_ids, tokens, total_length, offset)
+        return dict(y=y, info=dict(artist=artist, genre=genre, lyrics=lyrics, full_tokens=full_tokens))
+
+    def get_y_from_ids(self, artist_id, genre_ids, lyric_tokens, total_length, offset):
+        assert len(genre_ids) <= self.max_genre_words
+        genre_ids = list(genre_ids) + [-1] * (self.max_genre_words - len(genre_ids))
+        if self.n_tokens > 0:
+            assert len(lyric_tokens) == self.n_tokens
+        else:
+            lyric_tokens = []
+        y = np.array([total_length, offset, self.sample_length, artist_id, *genre_ids, *lyric_tokens], dtype=np.int64)
+        assert y.shape == self.label_shape, f"Expected {self.label_shape}, got {y.shape}"
+        return y
+
+    def get_batch_labels(self, metas, device="cpu"):
+        labels = [self.get_label(**meta) for meta in metas]
+        ys = t.stack([t.from_numpy(l["y"]) for l in labels], dim=0).to(device).long()
+        return dict(y=ys, info=[l["info"] for l in labels])
+
+    def get_batch_labels_from_ids(self, items, device="cpu"):
+        """items: dicts with artist_id, genre_ids, full_tokens, total_length, offset."""
+        ys, infos = [], []
+        for it in items:
+            tokens, _ = get_relevant_lyric_tokens(list(it["full_tokens"]), self.n_tokens, it["total_length"],
+                                                  it["offset"], self.sample_length) if self.n_tokens > 0 else ([], [])
+            ys.append(self.get_y_from_ids(it["artist_id"], it["genre_ids"], tokens, it["total_length"], it["offset"]))
+            infos.append(dict(artist="n/a", genre="n/a", lyrics="", full_tokens=list(it["full_tokens"])))
+        return dict(y=t.from_numpy(np.stack(ys)).to(device).long(), info=infos)
+
+    def set_y_lyric_tokens(self, ys, labels):
+        """labels.py:89-105: re-window the lyric tokens for the (already updated) offset in ys."""
+        info = labels["info"]
+        assert ys.shape[0] == len(info)
+        if self.n_tokens == 0:
+            return None
+        tokens_list, indices_list = [], []
+        for i in range(ys.shape[0]):
+            total_length, offset, duration = int(ys[i, 0]), int(ys[i, 1]), int(ys[i, 2])
+            tokens, indices = get_relevant_lyric_tokens(info[i]["full_tokens"], self.n_tokens, total_length, offset,
+                                                        duration, f32=True)
+            tokens_list.append(tokens)
+            indices_list.append(indices)
+        ys[:, -self.n_tokens:] = t.tensor(tokens_list, dtype=t.long, device=ys.device)
+        return indices_list

@@ -112,6 +112,26 @@ def gemm(A, pw, bias=None, out=None, res=None, n_seq=1, t_in=None, t_out=None, s
     return out
 
 
+def gemm_qkv(h, pw, bias, n_seq, n_q, S, kcache, vcache, t0):
+    """c_attn projection of a chunk with the k/v parts written into the caches at positions t0.. (jb_gemm
+    qkv_split).  h: (n_seq*n_q, K).  Returns q: (n_seq*n_q, S)."""
+    _chk_cuda(h, bias, kcache, vcache)
+    q = torch.empty((n_seq * n_q, S), dtype=h.dtype, device=h.device)
+    a = L.GemmArgs()
+    a.dtype = L.dtype_code(h.dtype)
+    a.A, a.lda = h.data_ptr(), h.stride(0)
+    a.W, a.tap_stride, a.bias = pw.ptr, pw.tap_stride, L.ptr(bias)
+    a.out, a.ldo = q.data_ptr(), S
+    a.n_seq, a.t_in, a.t_out = n_seq, n_q, n_q
+    a.in_seq_stride, a.out_seq_stride = n_q, n_q
+    a.K, a.J = pw.K, pw.J
+    a.n_taps, a.in_stride, a.out_stride, a.res_scale = 1, 1, 1, 1.0
+    a.qkv_split, a.S = 1, S
+    a.kcache, a.vcache, a.cache_cap, a.cache_t0 = kcache.data_ptr(), vcache.data_ptr(), kcache.shape[1], t0
+    L.check(L.lib().jb_gemm(C.byref(a), L.stream()))
+    return q
+
+
 def tap_view(pw, taps):
     """PackedWeight holding only the listed taps (must be equally spaced) -- for transposed-conv phases."""
     step = taps[1] - taps[0] if len(taps) > 1 else 1

@@ -1,0 +1,154 @@
+"""ConditionalAutoregressive2D with the reference's parameter tree and sampling API
+(jukebox/prior/autoregressive.py:48-359).  `sample` / `primed_sample` run the whole token loop inside
+the HIP decode engine (jukebox_amd.engine.PriorEngine): one hipGraph replay per token, chunked MFMA
+prefill for the primed part; nothing is computed in torch."""
+import numpy as np
+import torch as t
+import torch.nn as nn
+
+from ..engine import PriorEngine
+from ..transformer.transformer import Transformer
+
+
+def get_normal(*shape, std=0.01):
+    w = t.empty(shape)
+    nn.init.normal_(w, std=std)
+    return w
+
+
+def split_chunks(length, chunk_size):
+    """autoregressive.py:19-23."""
+    n_passes = (length + chunk_size - 1) // chunk_size
+    chunk_sizes = [*[chunk_size] * (n_passes - 1), (length - 1) % chunk_size + 1]
+    assert sum(chunk_sizes) == length
+    return chunk_sizes
+
+
+class PositionEmbedding(nn.Module):
+    def __init__(self, input_shape, width, init_scale=1.0, pos_init=False):
+        super().__init__()
+        assert not pos_init, "pos_init is not used by any released model"
+        self.input_shape = input_shape
+        self.input_dims = int(np.prod(input_shape))
+        self.pos_emb = nn.Parameter(get_normal(self.input_dims, width, std=0.01 * init_scale))
+
+    def forward(self):
+        return self.pos_emb
+
+
+class ConditionalAutoregressive2D(nn.Module):
+    def __init__(self, input_shape, bins, width=128, depth=2, heads=1, attn_dropout=0.0, resid_dropout=0.0,
+                 emb_dropout=0.0, mask=True, zero_out=False, init_scale=1.0, res_scale=False, pos_init=False,
+                 m_attn=0.25, m_mlp=1, checkpoint_res=0, checkpoint_attn=0, checkpoint_mlp=0, attn_order=0,
+                 blocks=None, spread=None, x_cond=False, y_cond=False, encoder_dims=0, only_encode=False,
+                 merged_decoder=False, prime_len=None):
+        super().__init__()
+        self.input_shape = input_shape
+        self.input_dims = int(np.prod(input_shape))
+        self.encoder_dims, self.bins, self.width, self.depth = encoder_dims, bins, width, depth
+        self.heads, self.attn_order, self.blocks, self.m_attn, self.m_mlp = heads, attn_order, blocks, m_attn, m_mlp
+        assert not res_scale, "res_scale is not used by any released model"
+        self.x_emb = nn.Embedding(bins, width)
+        nn.init.normal_(self.x_emb.weight, std=0.02 * init_scale)
+        self.y_cond, self.x_cond = y_cond, x_cond
+        if not y_cond:
+            self.start_token = nn.Parameter(get_normal(1, width, std=0.01 * init_scale))
+        self.pos_emb = PositionEmbedding(input_shape=input_shape, width=width, init_scale=init_scale, pos_init=pos_init)
+        self.transformer = Transformer(n_in=width, n_ctx=self.input_dims, n_head=heads, n_depth=depth, mask=mask,
+                                       zero_out=zero_out, init_scale=init_scale, res_scale=res_scale, m_attn=m_attn,
+                                       m_mlp=m_mlp, attn_order=attn_order, blocks=blocks, spread=spread,
+                                       encoder_dims=encoder_dims, prime_len=prime_len)
+        self.only_encode, self.prime_len = only_encode, prime_len
+        self.add_cond_after_transformer = not merged_decoder
+        self.share_x_emb_x_out = not merged_decoder
+        if not only_encode:
+            self.x_out = nn.Linear(width, bins, bias=False)
+            if self.share_x_emb_x_out:
+                self.x_out.weight = self.x_emb.weight
+        self._engines = {}
+
+    def _apply(self, fn, *a, **k):
+        self._engines = {}              # device copies are dropped when the module moves (prior.cpu())
+        return super()._apply(fn, *a, **k)
+
+    def preprocess(self, x):
+        return x.view(x.shape[0], -1).long()
+
+    def postprocess(self, x, sample_tokens=None):
+        N = x.shape[0]
+        assert (0 <= x).all() and (x < self.bins).all()
+        if sample_tokens is None or sample_tokens == self.input_dims:
+            return x.view(N, *self.input_shape)
+        return x.view(N, -1)
+
+    # ---- engine binding --------------------------------------------------------------------------------
+    def engine(self, n_samples, fp16, want_preds=False, chunk_cap=512):
+        key = (n_samples, bool(fp16), bool(want_preds))
+        if key not in self._engines:
+            self._engines = {}          # one bound engine at a time (weights are packed per engine)
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            if self.x_emb.weight.device.type != "cuda":
+                raise RuntimeError("move the prior to the GPU before sampling (prior.cuda()); there is no CPU path")
+            self._engines[key] = PriorEngine(sd, "", n_batch=n_samples, seq_len=self.input_dims, bins=self.bins,
+                                             width=self.width, depth=self.depth, heads=self.heads,
+                                             attn_order=self.attn_order, blocks=self.blocks, m_attn=self.m_attn,
+                                             m_mlp=self.m_mlp, prime_len=self.prime_len, y_cond=self.y_cond,
+                                             add_cond_after=self.add_cond_after_transformer, fp16=fp16,
+                                             chunk_cap=chunk_cap, want_preds=want_preds,
+                                             device=self.x_emb.weight.device)
+        return self._engines[key]
+
+    def _check_cond(self, N, x_cond, y_cond):
+        D = self.input_dims
+        if self.y_cond:
+            assert y_cond is not None and tuple(y_cond.shape) == (N, 1, self.width)
+        else:
+            assert y_cond is None
+        if self.x_cond:
+            assert x_cond is not None
+            assert tuple(x_cond.shape) in ((N, D, self.width), (N, 1, self.width)), \
+                f"Got {x_cond.shape}, expected ({N}, {D}/{1}, {self.width})"
+        else:
+            assert x_cond is None
+
+    def _run(self, n_samples, x_prime, x_cond, y_cond, encoder_kv, fp16, temp, top_k, top_p, get_preds, sample_tokens,
+             seed=0, sample_base=0):
+        assert self.training is False
+        assert encoder_kv is None, "separate lyric encoder (cross attention) is not on the HIP path yet"
+        assert top_k == 0 or top_p == 0.0
+        if sample_tokens is None:
+            sample_tokens = self.input_dims
+        self._check_cond(n_samples, x_cond, y_cond)
+        eng = self.engine(n_samples, fp16, want_preds=get_preds)
+        eng.set_cond(x_cond, y_cond)
+        eng.set_sampling(temp=temp, top_k=top_k, top_p=top_p, seed=seed, sample_base=sample_base)
+        n_prime = 0
+        if x_prime is not None:
+            x_prime = self.preprocess(x_prime)
+            assert (0 <= x_prime).all() and (x_prime < self.bins).all()
+            assert x_prime.shape[0] == n_samples
+            n_prime = x_prime.shape[1]
+            assert n_prime < sample_tokens
+            eng.tokens[:, :n_prime] = x_prime
+            eng.prefill(0, n_prime)
+        eng.decode(n_prime, sample_tokens - n_prime)
+        x = eng.tokens[:, :sample_tokens].clone()
+        x = self.postprocess(x, sample_tokens)
+        if get_preds:
+            return x, eng.preds[:, :sample_tokens].clone()
+        return x
+
+    def sample(self, n_samples, x_cond=None, y_cond=None, encoder_kv=None, fp16=False, temp=1.0, top_k=0, top_p=0.0,
+               get_preds=False, sample_tokens=None, seed=0, sample_base=0):
+        """autoregressive.py:199-249."""
+        with t.no_grad():
+            return self._run(n_samples, None, x_cond, y_cond, encoder_kv, fp16, temp, top_k, top_p, get_preds,
+                             sample_tokens, seed, sample_base)
+
+    def primed_sample(self, n_samples, x, x_cond=None, y_cond=None, encoder_kv=None, fp16=False, temp=1.0, top_k=0,
+                      top_p=0.0, get_preds=False, chunk_size=None, sample_tokens=None, seed=0, sample_base=0):
+        """autoregressive.py:251-359.  `chunk_size` is accepted for API compatibility; the engine prefills in its
+        own (larger) chunks -- results are chunk-invariant (the reference's check_chunks, factored_attention.py:457-488)."""
+        with t.no_grad():
+            return self._run(n_samples, x, x_cond, y_cond, encoder_kv, fp16, temp, top_k, top_p, get_preds,
+                             sample_tokens, seed, sample_base)

@@ -1,0 +1,192 @@
+"""SimplePrior with the reference's module tree and sampling API (jukebox/prior/prior.py:27-283): conditioning
+assembly (labels, upper-level codes, lyric prefix with merged vocabulary) around the HIP decode engine.
+Training methods (z_forward / forward) are out of scope."""
+import numpy as np
+import torch as t
+import torch.nn as nn
+
+from ..data.labels import EmptyLabeller, Labeller
+from ..utils import dist_adapter as dist
+from ..utils.dist_utils import print_once
+from ..vqvae.vqvae import calculate_strides
+from .autoregressive import ConditionalAutoregressive2D
+from .conditioners import Conditioner, LabelConditioner
+
+
+class SimplePrior(nn.Module):
+    def __init__(self, z_shapes, l_bins, encoder, decoder, level, downs_t, strides_t, labels, prior_kwargs,
+                 x_cond_kwargs, y_cond_kwargs, prime_kwargs, copy_input, labels_v3=False, merged_decoder=False,
+                 single_enc_dec=False):
+        super().__init__()
+        self.use_tokens = prime_kwargs.pop("use_tokens")
+        self.n_tokens = prime_kwargs.pop("n_tokens")
+        self.prime_loss_fraction = prime_kwargs.pop("prime_loss_fraction")
+        self.copy_input = copy_input
+        if self.copy_input:
+            prime_kwargs["bins"] = l_bins
+        self.z_shapes, self.levels = z_shapes, len(z_shapes)
+        self.z_shape = self.z_shapes[level]
+        self.level = level
+        assert level < self.levels, f"Total levels {self.levels}, got level {level}"
+        self.l_bins = l_bins
+        self.encoder, self.decoder = encoder, decoder          # bound methods of the VQ-VAE (no parameters captured)
+        self.x_cond = level != (self.levels - 1)
+        self.cond_level = level + 1
+        self.y_cond = labels
+        self.single_enc_dec = single_enc_dec
+        if self.x_cond:
+            self.conditioner_blocks = nn.ModuleList()
+            self.conditioner_blocks.append(Conditioner(input_shape=z_shapes[self.cond_level], bins=l_bins,
+                                                       down_t=downs_t[self.cond_level], stride_t=strides_t[self.cond_level],
+                                                       **x_cond_kwargs))
+        if self.y_cond:
+            self.n_time = self.z_shape[0]
+            self.y_emb = LabelConditioner(n_time=self.n_time, include_time_signal=not self.x_cond, **y_cond_kwargs)
+        if single_enc_dec:
+            # merged lyric + VQ vocabulary, one longer sequence (prior.py:90-103)
+            self.prior_shapes = [(self.n_tokens,), prior_kwargs.pop("input_shape")]
+            self.prior_bins = [prime_kwargs["bins"], prior_kwargs.pop("bins")]
+            self.prior_dims = [int(np.prod(shape)) for shape in self.prior_shapes]
+            self.prior_bins_shift = np.cumsum([0, *self.prior_bins])[:-1]
+            self.prior_width = prior_kwargs["width"]
+            self.prime_loss_dims, self.gen_loss_dims = self.prior_dims[0], self.prior_dims[1]
+            self.total_loss_dims = self.prime_loss_dims + self.gen_loss_dims
+            self.prior = ConditionalAutoregressive2D(input_shape=(sum(self.prior_dims),), bins=sum(self.prior_bins),
+                                                     x_cond=(self.x_cond or self.y_cond), y_cond=True,
+                                                     prime_len=self.prime_loss_dims, **prior_kwargs)
+        else:
+            if self.n_tokens != 0 and self.use_tokens:
+                raise NotImplementedError("separate lyric encoder + cross attention (prior_5b_lyrics) is the next widening "
+                                          "step (SURVEY.md section 8f item 3); it has no HIP path yet")
+            self.prime_loss_dims = 0
+            self.gen_loss_dims = int(np.prod(self.z_shape))
+            self.total_loss_dims = self.prime_loss_dims + self.gen_loss_dims
+            self.prior = ConditionalAutoregressive2D(x_cond=(self.x_cond or self.y_cond), y_cond=self.y_cond,
+                                                     encoder_dims=self.prime_loss_dims, merged_decoder=merged_decoder,
+                                                     **prior_kwargs)
+        self.n_ctx = self.gen_loss_dims
+        self.downsamples = calculate_strides(strides_t, downs_t)
+        self.cond_downsample = self.downsamples[level + 1] if level != self.levels - 1 else None
+        self.raw_to_tokens = int(np.prod(self.downsamples[:level + 1]))
+        self.sample_length = self.n_ctx * self.raw_to_tokens
+        if labels:
+            self.labels_v3 = labels_v3
+            self.labeller = Labeller(self.y_emb.max_bow_genre_size, self.n_tokens, self.sample_length, v3=self.labels_v3)
+        else:
+            self.labeller = EmptyLabeller()
+
+    def get_y(self, labels, start, get_indices=False):
+        """prior.py:140-156: per-window label matrix (sample_length of this level, shifted offset, re-windowed lyrics)."""
+        if isinstance(self.labeller, EmptyLabeller):
+            return None
+        y = labels["y"].clone()
+        y[:, 2] = int(self.sample_length)
+        y[:, 1:2] = y[:, 1:2] + int(start * self.raw_to_tokens)
+        indices = self.labeller.set_y_lyric_tokens(y, labels)
+        return (y, indices) if get_indices else y
+
+    def get_z_conds(self, zs, start, end):
+        """prior.py:158-166."""
+        if self.level != self.levels - 1:
+            assert start % self.cond_downsample == end % self.cond_downsample == 0
+            z_cond = zs[self.level + 1][:, start // self.cond_downsample:end // self.cond_downsample]
+            assert z_cond.shape[1] == self.n_ctx // self.cond_downsample
+            return [z_cond]
+        return None
+
+    def prior_preprocess(self, xs, conds):
+        """prior.py:168-185: shift each vocabulary into the merged one, zero-pad missing conditioning."""
+        N = xs[0].shape[0]
+        for i in range(len(xs)):
+            bins, shift = int(self.prior_bins[i]), int(self.prior_bins_shift[i])
+            assert (0 <= xs[i]).all() and (xs[i] < bins).all()
+            xs[i] = (xs[i] + shift).view(N, -1)
+        for i in range(len(conds)):
+            if conds[i] is None:
+                conds[i] = t.zeros((N, self.prior_dims[i], self.prior_width), dtype=t.float, device=xs[0].device)
+            else:
+                assert tuple(conds[i].shape) == (N, self.prior_dims[i], self.prior_width)
+        return t.cat(xs, dim=1), t.cat(conds, dim=1)
+
+    def prior_postprocess(self, z):
+        """prior.py:187-203: drop the lyric part, un-shift, clamp ids sampled from the lyric range to 0."""
+        N = z.shape[0]
+        dims = (self.prior_dims[0], z.shape[1] - self.prior_dims[0])
+        xs = list(t.split(z, dims, dim=1))
+        for i in range(len(xs)):
+            shape = self.prior_shapes[i]
+            bins, shift = int(self.prior_bins[i]), int(self.prior_bins_shift[i])
+            xs[i] = t.clamp((xs[i] - shift).view(N, -1, *shape[1:]), min=0)
+            assert (xs[i] < bins).all()
+        return xs[-1]
+
+    def x_emb(self, z_conds):
+        z_conds = z_conds[:self.cond_level - self.level]
+        assert len(z_conds) == len(self.conditioner_blocks) == self.cond_level - self.level
+        x_cond = None
+        for z_cond, block in reversed(list(zip(z_conds, self.conditioner_blocks))):
+            x_cond = block(z_cond, x_cond)
+        return x_cond
+
+    def encode(self, x, start_level=None, end_level=None, bs_chunks=1):
+        start_level = self.level if start_level is None else start_level
+        end_level = self.levels if end_level is None else end_level
+        with t.no_grad():
+            return self.encoder(x, start_level=start_level, end_level=end_level, bs_chunks=bs_chunks)
+
+    def decode(self, zs, start_level=None, end_level=None, bs_chunks=1):
+        start_level = self.level if start_level is None else start_level
+        end_level = self.levels if end_level is None else end_level
+        assert len(zs) == end_level - start_level
+        with t.no_grad():
+            return self.decoder(zs, start_level=start_level, end_level=end_level, bs_chunks=bs_chunks)
+
+    def get_cond(self, z_conds, y):
+        """prior.py:234-243."""
+        if y is not None:
+            assert y.shape[1] == 4 + self.y_emb.max_bow_genre_size + self.n_tokens
+            n_labels = y.shape[1] - self.n_tokens
+            y, prime = y[:, :n_labels], y[:, n_labels:]
+        else:
+            y, prime = None, None
+        y_cond, y_pos = self.y_emb(y) if self.y_cond else (None, None)
+        x_cond = self.x_emb(z_conds) if self.x_cond else y_pos
+        return x_cond, y_cond, prime
+
+    def sample(self, n_samples, z=None, z_conds=None, y=None, fp16=False, temp=1.0, top_k=0, top_p=0.0, chunk_size=None,
+               sample_tokens=None, seed=0, sample_base=0):
+        """prior.py:245-283.  seed / sample_base (extensions): the random stream of global sample index
+        sample_base + n at position t is a pure function of (seed, index, t), so sharded runs reproduce."""
+        N = n_samples
+        if z is not None:
+            assert z.shape[0] == N, f"Expected shape ({N},**), got shape {z.shape}"
+        if y is not None:
+            assert y.shape[0] == N, f"Expected shape ({N},**), got shape {y.shape}"
+        if z_conds is not None:
+            for z_cond in z_conds:
+                assert z_cond.shape[0] == N, f"Expected shape ({N},**), got shape {z_cond.shape}"
+        no_past_context = z is None or z.shape[1] == 0
+        if dist.get_rank() == 0:
+            name = {True: "Ancestral", False: "Primed"}[no_past_context]
+            print_once(f"{name} sampling {n_samples} samples with temp={temp}, top_k={top_k}, top_p={top_p}")
+        kw = dict(fp16=fp16, temp=temp, top_k=top_k, top_p=top_p, seed=seed, sample_base=sample_base)
+        with t.no_grad():
+            x_cond, y_cond, prime = self.get_cond(z_conds, y)
+            if self.single_enc_dec:
+                if no_past_context:
+                    z, x_cond = self.prior_preprocess([prime], [None, x_cond])
+                else:
+                    z, x_cond = self.prior_preprocess([prime, z], [None, x_cond])
+                if sample_tokens is not None:
+                    sample_tokens += self.n_tokens
+                z = self.prior.primed_sample(n_samples, z, x_cond, y_cond, chunk_size=chunk_size,
+                                             sample_tokens=sample_tokens, **kw)
+                z = self.prior_postprocess(z)
+            elif no_past_context:
+                z = self.prior.sample(n_samples, x_cond, y_cond, None, sample_tokens=sample_tokens, **kw)
+            else:
+                z = self.prior.primed_sample(n_samples, z, x_cond, y_cond, None, chunk_size=chunk_size,
+                                             sample_tokens=sample_tokens, **kw)
+            if sample_tokens is None:
+                assert tuple(z.shape) == (N, *self.z_shape)
+        return z

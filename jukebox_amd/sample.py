@@ -1,0 +1,177 @@
+"""Sampling driver with the reference's control flow (jukebox/sample.py:17-279): windows and hops per level,
+batch splitting, ancestral / continue / upsample / primed modes, per-level decode and `data.pth.tar` dumps.
+
+Extensions for MI355X nodes: `n_samples` is sharded across the ranks of one node (one process per GPU); rank 0
+broadcasts the label matrices (and primed codes) over RCCL, every rank samples its contiguous slice with per-sample
+random streams, and the generated codes are all-gathered once per level.  The reference runs
+the whole job redundantly on every rank with identical seeds (sample.py:110-113)."""
+import os
+
+import torch as t
+
+from .data.labels import EmptyLabeller
+from .hparams import Hyperparams
+from .utils import dist_adapter as dist
+from .utils.dist_utils import broadcast_tensor, gather_shards, print_once, shard_range
+from .utils.sample_utils import get_starts, split_batch
+from .utils.torch_utils import empty_cache
+
+
+def sample_partial_window(zs, labels, sampling_kwargs, level, prior, tokens_to_sample, hps):
+    """sample.py:17-29."""
+    z = zs[level]
+    n_ctx = prior.n_ctx
+    current_tokens = z.shape[1]
+    if current_tokens < n_ctx - tokens_to_sample:
+        sampling_kwargs["sample_tokens"] = current_tokens + tokens_to_sample
+        start = 0
+    else:
+        sampling_kwargs["sample_tokens"] = n_ctx
+        start = current_tokens - n_ctx + tokens_to_sample
+    return sample_single_window(zs, labels, sampling_kwargs, level, prior, start, hps)
+
+
+def sample_single_window(zs, labels, sampling_kwargs, level, prior, start, hps):
+    """sample.py:31-78."""
+    n_samples = hps.n_samples
+    n_ctx = prior.n_ctx
+    end = start + n_ctx
+    z = zs[level][:, start:end]
+    sample_tokens = sampling_kwargs.get("sample_tokens", end - start)
+    conditioning_tokens, new_tokens = z.shape[1], sample_tokens - z.shape[1]
+    print_once(f"Sampling {sample_tokens} tokens for [{start},{start + sample_tokens}]. Conditioning on {conditioning_tokens} tokens")
+    if new_tokens <= 0:
+        return zs
+    z_conds = prior.get_z_conds(zs, start, end)
+    y = prior.get_y(labels, start)
+    empty_cache()
+    kwargs = dict(sampling_kwargs)
+    max_batch_size = kwargs.pop("max_batch_size")
+    sample_base = kwargs.pop("sample_base", 0)
+    z_list = split_batch(z, n_samples, max_batch_size)
+    z_conds_list = split_batch(z_conds, n_samples, max_batch_size)
+    y_list = split_batch(y, n_samples, max_batch_size)
+    z_samples, done = [], 0
+    for z_i, z_conds_i, y_i in zip(z_list, z_conds_list, y_list):
+        z_conds_i = None if z_conds_i is None else [zc.contiguous() for zc in z_conds_i]
+        z_samples.append(prior.sample(n_samples=z_i.shape[0], z=z_i.contiguous(), z_conds=z_conds_i, y=y_i,
+                                      sample_base=sample_base + done, **kwargs))
+        done += z_i.shape[0]
+    z = t.cat(z_samples, dim=0)
+    z_new = z[:, -new_tokens:]
+    zs[level] = t.cat([zs[level], z_new], dim=1)
+    return zs
+
+
+def sample_level(zs, labels, sampling_kwargs, level, prior, total_length, hop_length, hps):
+    """sample.py:81-88."""
+    print_once(f"Sampling level {level}")
+    if total_length >= prior.n_ctx:
+        for start in get_starts(total_length, prior.n_ctx, hop_length):
+            zs = sample_single_window(zs, labels, sampling_kwargs, level, prior, start, hps)
+    else:
+        zs = sample_partial_window(zs, labels, sampling_kwargs, level, prior, total_length, hps)
+    return zs
+
+
+def _shard_labels(labels, lo, hi):
+    return dict(y=labels["y"][lo:hi].contiguous(), info=labels["info"][lo:hi])
+
+
+def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, device="cuda"):
+    """sample.py:91-121 with n_samples sharded over the ranks.  `zs`, `labels` describe ALL hps.n_samples samples
+    (identical on every rank -- see broadcast_conditioning); returns the full zs on every rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(hps.n_samples, rank, world)
+    local_hps = Hyperparams(hps)
+    local_hps.n_samples = hi - lo
+    zs_local = [z[lo:hi].contiguous() for z in zs]
+    xs = {}
+    for level in reversed(sample_levels):
+        prior = priors[level]
+        prior.to(device)                         # sample.py:95 (prior.cuda()); binds the HIP engine lazily
+        empty_cache()
+        assert hps.sample_length % prior.raw_to_tokens == 0, \
+            f"Expected sample_length {hps.sample_length} to be multiple of {prior.raw_to_tokens}"
+        total_length = hps.sample_length // prior.raw_to_tokens
+        hop_length = int(hps.hop_fraction[level] * prior.n_ctx)
+        kw = dict(sampling_kwargs[level])
+        kw["sample_base"] = lo
+        if local_hps.n_samples > 0:
+            zs_local = sample_level(zs_local, _shard_labels(labels[level], lo, hi), kw, level, prior, total_length,
+                                    hop_length, local_hps)
+        prior.cpu()                              # sample.py:104: drops the engine's device copies
+        empty_cache()
+        zs[level] = gather_shards(zs_local[level], hps.n_samples)
+        x_local = prior.decode(zs_local[level:], start_level=level, bs_chunks=max(1, zs_local[level].shape[0]))
+        xs[level] = x_local
+        if save:
+            x = gather_shards(x_local, hps.n_samples)
+            if rank == 0:
+                logdir = f"{hps.name}/level_{level}"
+                os.makedirs(logdir, exist_ok=True)
+                t.save(dict(zs=zs, labels=labels, sampling_kwargs=sampling_kwargs, x=x), f"{logdir}/data.pth.tar")
+                save_wav(logdir, x, hps.sr)
+    _sample.last_audio = xs
+    return zs
+
+
+def save_wav(fname, aud, sr):
+    """utils/audio_utils.py:142-146 (clamp to [-1, 1], one wav per item) via scipy (soundfile is not installed)."""
+    from scipy.io import wavfile
+    aud = t.clamp(aud, -1, 1).cpu().numpy()
+    for i in range(aud.shape[0]):
+        wavfile.write(f"{fname}/item_{i}.wav", sr, aud[i])
+
+
+def broadcast_conditioning(labels, zs=None):
+    """Rank 0's label matrices (and codes, for continue / upsample / primed modes) to every rank over RCCL."""
+    for lab in labels:
+        lab["y"] = broadcast_tensor(lab["y"], 0)
+    if zs is not None:
+        zs = [broadcast_tensor(z, 0) for z in zs]
+    return labels, zs
+
+
+def ancestral_sample(labels, sampling_kwargs, priors, hps, save=True, device="cuda"):
+    """sample.py:124-128."""
+    sample_levels = list(range(len(priors)))
+    zs = [t.zeros(hps.n_samples, 0, dtype=t.long, device=device) for _ in range(len(priors))]
+    return _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=save, device=device)
+
+
+def continue_sample(zs, labels, sampling_kwargs, priors, hps, save=True, device="cuda"):
+    """sample.py:131-134."""
+    return _sample(zs, labels, sampling_kwargs, priors, list(range(len(priors))), hps, save=save, device=device)
+
+
+def upsample(zs, labels, sampling_kwargs, priors, hps, save=True, device="cuda"):
+    """sample.py:137-140."""
+    return _sample(zs, labels, sampling_kwargs, priors, list(range(len(priors) - 1)), hps, save=save, device=device)
+
+
+def primed_sample(x, labels, sampling_kwargs, priors, hps, save=True, device="cuda"):
+    """sample.py:143-147."""
+    zs = priors[-1].encode(x, start_level=0, end_level=len(priors), bs_chunks=x.shape[0])
+    return _sample(zs, labels, sampling_kwargs, priors, list(range(len(priors))), hps, save=save, device=device)
+
+
+def load_codes(codes_file, duration, priors, hps, device="cuda"):
+    """sample.py:164-175: reload `zs` from a level's data.pth.tar, optionally truncated to `duration` samples."""
+    data = t.load(codes_file, map_location="cpu", weights_only=False)
+    zs = [z.to(device) for z in data["zs"]]
+    assert zs[-1].shape[0] == hps.n_samples, f"Expected bs = {hps.n_samples}, got {zs[-1].shape[0]}"
+    if duration is not None:
+        top_raw_to_tokens = priors[-1].raw_to_tokens
+        assert duration % top_raw_to_tokens == 0, f"Cut-off duration {duration} not an exact multiple of top_raw_to_tokens"
+        assert duration // top_raw_to_tokens <= zs[-1].shape[1]
+        zs = [z[:, :duration // prior.raw_to_tokens] for z, prior in zip(zs, priors)]
+    return zs
+
+
+def default_sampling_kwargs(model):
+    """sample.py:231-241."""
+    lower = dict(temp=0.99, fp16=True, chunk_size=32, max_batch_size=16)
+    top = dict(temp=0.99, fp16=True, chunk_size=32, max_batch_size=16) if model == "1b_lyrics" else \
+        dict(temp=0.99, fp16=True, chunk_size=16, max_batch_size=3)
+    return [dict(lower), dict(lower), top]

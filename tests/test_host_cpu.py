@@ -1,0 +1,115 @@
+"""CPU suite: host-side logic -- parameter trees load the reference's state dicts strictly, label windows,
+window plans, sharding helpers, and the 2-rank gloo exchange used by the sharded sampler."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, sub_state
+from jukebox_amd.hparams import Hyperparams, setup_hparams
+
+
+def _tiny_models(tiny_hps):
+    from jukebox_amd.make_models import make_prior, make_vqvae
+    vq_h = Hyperparams(tiny_hps["tiny_vqvae"])
+    vq_h.downs_t, vq_h.strides_t = tuple(vq_h.downs_t), tuple(vq_h.strides_t)
+    vq = make_vqvae(vq_h, "cpu")
+    priors = []
+    for nm in ("tiny_up0", "tiny_up1", "tiny_top"):
+        h = Hyperparams(tiny_hps[nm])
+        h.y_bins = tuple(h.y_bins)
+        priors.append(make_prior(h, vq, "cpu"))
+    return vq, priors
+
+
+def test_state_dicts_load_strict(tiny_hps):
+    """identical module tree / parameter names / shapes."""
+    vq, priors = _tiny_models(tiny_hps)
+    g = load_golden("vqvae")
+    sd = {k: torch.from_numpy(v) for k, v in sub_state(g, "sd.").items()}
+    assert set(sd) == set(vq.state_dict())
+    vq.load_state_dict(sd, strict=True)
+    gp = load_golden("priors")
+    for i, p in enumerate(priors):
+        sd = {k: torch.from_numpy(v) for k, v in sub_state(gp, f"p{i}.").items()
+              if not k.startswith(("labels_y", "full_tokens"))}
+        assert set(sd) == set(p.state_dict()), set(sd) ^ set(p.state_dict())
+        p.load_state_dict(sd, strict=True)
+    top = priors[2]
+    assert top.n_ctx == 48 and top.raw_to_tokens == 64 and top.prior.input_dims == 64 and top.prior.bins == 79 + 64
+    assert priors[0].cond_downsample == 4 and priors[0].raw_to_tokens == 4
+
+
+def test_production_hparams_dimensions():
+    """Appendix A: the released model dimensions come out of the registry."""
+    h = setup_hparams("prior_1b_lyrics", {})
+    assert (h.n_ctx, h.prior_width, h.prior_depth, h.heads, h.attn_order, h.blocks, h.n_tokens) == (6144, 2048, 72, 2, 12, 64, 384)
+    assert h.y_bins == (604, 7898) and h.single_enc_dec and h.labels_v3 and not h.fp16_params
+    u = setup_hparams("upsampler_level_1", {})
+    assert (u.n_ctx, u.prior_width, u.heads, u.cond_width, u.cond_depth, u.cond_dilation_cycle, u.cond_res_scale) == \
+        (8192, 1920, 1, 1024, 16, 8, True)
+    v = setup_hparams("vqvae", {})
+    assert v.downs_t == (3, 2, 2) and v.hvqvae_multipliers == (2, 1, 1) and v.l_bins == 2048
+    with pytest.raises(ValueError):
+        setup_hparams("small_prior", dict(not_a_key=1))
+    from jukebox_amd.engine import attn_funcs
+    f = attn_funcs(12, 72)
+    assert [d for d in range(72) if f[d] == 7] == [15, 31, 63] and [d for d in range(72) if f[d] == 0] == [47]
+
+
+def test_get_y_matches_reference(tiny_hps):
+    """prior.get_y (per-window offset + lyric re-windowing) against the y the reference computed."""
+    _, priors = _tiny_models(tiny_hps)
+    g = load_golden("priors")
+    top = priors[2]
+    labels = dict(y=torch.from_numpy(g["p2.labels_y"]),
+                  info=[dict(full_tokens=list(map(int, g[f"p2.full_tokens{j}"]))) for j in range(3)])
+    assert np.array_equal(top.get_y(labels, 0).numpy(), g["top.y0"])
+    assert np.array_equal(top.get_y(labels, 24).numpy(), g["top.y24"])
+
+
+def test_window_plan_and_shards():
+    from jukebox_amd.utils.dist_utils import shard_range
+    from jukebox_amd.utils.sample_utils import get_starts, split_batch
+    g = load_golden("misc")
+    i = 0
+    while f"starts{i}" in g.files:
+        assert list(g[f"starts{i}"]) == get_starts(*[int(v) for v in g[f"starts{i}.args"]])
+        i += 1
+    for n, w in ((128, 8), (24, 8), (5, 2), (3, 4)):
+        rs = [shard_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+        assert max(hi - lo for lo, hi in rs) - min(hi - lo for lo, hi in rs) <= 1
+    parts = split_batch(torch.arange(10).view(5, 2), 5, 2)
+    assert [p.shape[0] for p in parts] == [2, 2, 1]
+
+
+def test_two_rank_gloo_exchange(tmp_path):
+    """broadcast of conditioning + all_gather of uneven code shards, world_size 2 over gloo on CPU."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, torch
+        sys.path.insert(0, {ROOT!r})
+        from jukebox_amd.utils.dist_utils import setup_dist_from_env, shard_range, broadcast_tensor, gather_shards
+        from jukebox_amd.utils import dist_adapter as dist
+        rank, local, dev = setup_dist_from_env("gloo")
+        assert dist.get_world_size() == 2
+        y = torch.arange(15, dtype=torch.int64).view(5, 3) if rank == 0 else None
+        y = broadcast_tensor(y, 0)
+        assert y.shape == (5, 3) and int(y.sum()) == 105
+        lo, hi = shard_range(5)
+        local_codes = (torch.arange(lo, hi).view(-1, 1) * 10 + torch.arange(4).view(1, 4)).long()
+        full = gather_shards(local_codes, 5)
+        want = (torch.arange(5).view(-1, 1) * 10 + torch.arange(4).view(1, 4)).long()
+        assert torch.equal(full, want), full
+        print("rank", rank, "ok")
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
