@@ -186,6 +186,10 @@ int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
 /* Run n_steps decode steps starting at position t0 (sets *t_dev = t0 first).  use_graph != 0 captures one step
  * into a hipGraph on first use and replays it. */
 int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
+/* Measurement aid: n_steps eager decode steps with HIP events recorded on `stream` around every LayerNorm-fused
+ * projection launch (attn.c_attn and mlp.c_fc -- the dominant kernel of the decode step).  Synchronises.
+ * out[0] = average microseconds per launch, out[1] = launches timed, out[2] = average algorithmic bytes per launch. */
+int jb_engine_probe_projection(void* handle, int t0, int n_steps, void* stream, double* out /* host, 3 doubles */);
 /* Number of kernel launches in one decode step (for launch-overhead accounting). */
 int jb_engine_launches_per_step(void* handle);
 

@@ -74,6 +74,7 @@ _SIGS = {
     "jb_engine_destroy": (i32, [vp]),
     "jb_engine_prefill": (i32, [vp, i32, i32, vp]),
     "jb_engine_decode": (i32, [vp, i32, i32, i32, vp]),
+    "jb_engine_probe_projection": (i32, [vp, i32, i32, vp, C.POINTER(C.c_double)]),
     "jb_engine_launches_per_step": (i32, [vp]),
 }
 EXPORTS = tuple(_SIGS)

@@ -71,8 +71,13 @@ extern "C" int jb_engine_launches_per_step(void* handle) {
         if (rc__ != JB_OK) return rc__; \
     } while (0)
 
+// Optional in-situ timing of the dominant kernel (the LayerNorm-fused weight-streaming projections c_attn and
+// mlp.c_fc): HIP events recorded on the launch stream around each of those launches.
+struct StepProbe { std::vector<hipEvent_t>* ev; };
+#define JB_PROBE(pr) do { if (pr) { hipEvent_t ev__; if (hipEventCreate(&ev__) == hipSuccess) { hipEventRecord(ev__, s); (pr)->ev->push_back(ev__); } } } while (0)
+
 // One decode step at position *t_dev; everything position-dependent is read on the device.
-static int enqueue_step(JbEngine* e, hipStream_t s) {
+static int enqueue_step(JbEngine* e, hipStream_t s, StepProbe* probe = nullptr) {
     const jb_engine_cfg& c = e->cfg;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
     JB_TRY(jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
@@ -85,7 +90,9 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
         g.x = c.x_a; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln0_g; g.ln_beta = L.ln0_b; g.ln_eps = c.ln_eps;
         g.W = L.w_attn; g.bias = L.b_attn; g.K = W; g.J = 3 * S; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
         g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
+        JB_PROBE(probe);
         JB_TRY(jb_gemv(&g, s));
+        JB_PROBE(probe);
         JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
                               c.block_ctx, c.t_dev, c.seq_len, s));
         // attn.c_proj + residual: x_b = x_a + a
@@ -97,7 +104,9 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
         g = {};
         g.dtype = c.dtype; g.x = c.x_b; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln1_g; g.ln_beta = L.ln1_b; g.ln_eps = c.ln_eps;
         g.W = L.w_fc; g.bias = L.b_fc; g.K = W; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
+        JB_PROBE(probe);
         JB_TRY(jb_gemv(&g, s));
+        JB_PROBE(probe);
         // mlp.c_proj + residual: x_a = x_b + m   (h = x + a + m, transformer.py:82-83)
         g = {};
         g.dtype = c.dtype; g.x = c.mlp; g.ldx = M; g.n_rows = N; g.W = L.w_proj2; g.bias = L.b_proj2; g.K = M; g.J = W;
@@ -208,5 +217,37 @@ extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
     }
     set_int_kernel<<<1, 1, 0, s>>>(c.t_dev, t0 + n_t);
     JB_CHECK_LAUNCH();
+    return JB_OK;
+}
+
+// Eager decode steps with HIP events around every LayerNorm-fused projection launch (2 per layer per step).
+// Synchronises the stream.  out[0] = average microseconds per such launch, out[1] = number of launches timed,
+// out[2] = average algorithmic bytes per such launch (weights once + activation rows in + rows out).
+extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, void* stream, double* out) {
+    JB_REQUIRE(handle && out, "null pointer");
+    JbEngine* e = (JbEngine*)handle;
+    JB_REQUIRE(t0 >= 0 && n_steps > 0 && t0 + n_steps <= e->cfg.seq_len, "step range outside the sequence");
+    hipStream_t s = (hipStream_t)stream;
+    set_int_kernel<<<1, 1, 0, s>>>(e->cfg.t_dev, t0);
+    JB_CHECK_LAUNCH();
+    std::vector<hipEvent_t> ev;
+    StepProbe pr{&ev};
+    for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s, &pr));
+    JB_HIP(hipStreamSynchronize(s));
+    double total_ms = 0.0;
+    size_t pairs = ev.size() / 2;
+    for (size_t i = 0; i < pairs; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) total_ms += ms;
+    }
+    for (hipEvent_t x : ev) (void)hipEventDestroy(x);
+    const jb_engine_cfg& c = e->cfg;
+    const double esz = c.dtype == JB_F16 ? 2.0 : 4.0;
+    const double W = c.width, S = c.n_state, M = c.n_mlp, N = c.n_batch;
+    const double b_attn = W * 3 * S * esz + N * W * esz + N * 3 * S * esz;
+    const double b_fc = W * M * esz + N * W * esz + N * M * esz;
+    out[0] = pairs ? total_ms * 1e3 / (double)pairs : 0.0;
+    out[1] = (double)pairs;
+    out[2] = 0.5 * (b_attn + b_fc);
     return JB_OK;
 }

@@ -163,6 +163,12 @@ class PriorEngine:
     def decode(self, t0, n_steps, use_graph=True):
         L.check(L.lib().jb_engine_decode(self.handle, t0, n_steps, int(use_graph), L.stream()))
 
+    def probe_projection(self, t0, n_steps):
+        """(avg_us_per_launch, launches, avg_algorithmic_bytes) of the LN-fused projection kernel, timed in situ."""
+        out = (C.c_double * 3)()
+        L.check(L.lib().jb_engine_probe_projection(self.handle, t0, n_steps, L.stream(), out))
+        return out[0], int(out[1]), out[2]
+
     @property
     def launches_per_step(self):
         return L.lib().jb_engine_launches_per_step(self.handle)

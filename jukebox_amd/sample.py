@@ -100,11 +100,15 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
         if local_hps.n_samples > 0:
             zs_local = sample_level(zs_local, _shard_labels(labels[level], lo, hi), kw, level, prior, total_length,
                                     hop_length, local_hps)
-        prior.cpu()                              # sample.py:104: drops the engine's device copies
-        empty_cache()
+        if not hps.get("keep_priors_resident", False):
+            prior.cpu()                          # sample.py:104: drops the engine's device copies
+            empty_cache()
         zs[level] = gather_shards(zs_local[level], hps.n_samples)
         x_local = prior.decode(zs_local[level:], start_level=level, bs_chunks=max(1, zs_local[level].shape[0]))
         xs[level] = x_local
+        _sample.level_done = getattr(_sample, "level_done", None)
+        if callable(_sample.level_done):
+            _sample.level_done(level)
         if save:
             x = gather_shards(x_local, hps.n_samples)
             if rank == 0:
