@@ -101,6 +101,41 @@ def cpu_baseline(prior, n_batch, steps, total_decode_steps, audio_seconds):
                        "are not charged to the CPU)")
 
 
+def projection_roofline(eng, t0, n_steps):
+    """Dominant kernel, timed in situ with HIP events on the launch stream: the LayerNorm-fused weight-streaming
+    projections (attn.c_attn / mlp.c_fc) of an engine's decode step."""
+    us, launches, abytes = eng.probe_projection(t0, n_steps)
+    achieved = abytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    return dict(bound="hbm", kernel="gemv_kernel<f16, LN-fused> (attn.c_attn / mlp.c_fc of the decode step)",
+                achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=None, avg_launch_us=round(us, 3), launches_timed=launches, bytes_per_launch=int(abytes))
+
+
+def roofline_only(a, device):
+    """Level-0 upsampler only: 256 graph-replayed decode steps at t = 4096.. plus the in-situ probe.  This is the
+    command whose rocprofv3 kernel-trace summary is committed under profiles/."""
+    assert a.model != "tiny"
+    torch.manual_seed(0)
+    with torch.device(device):
+        vq = make_vqvae(setup_hparams(MODELS[a.model][0], dict(sample_length=262144, restore_vqvae="")), device)
+        prior = make_prior(setup_hparams(MODELS[a.model][1], dict(restore_prior="")), vq, device)
+    N = a.samples_per_gpu
+    ar = prior.prior
+    eng = ar.engine(N, True)
+    eng.set_cond(torch.randn(N, ar.input_dims, ar.width, device=device) * 0.01, torch.randn(N, 1, ar.width, device=device) * 0.01)
+    eng.set_sampling(temp=0.99, seed=1)
+    eng.decode(4096, 8)
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    eng.decode(4096, 256)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - ts) / 256 * 1e3
+    out = dict(roofline=projection_roofline(eng, 4096, 16), level0_decode_ms_per_token_step=round(ms, 4),
+               launches_per_token_step=eng.launches_per_step, weights_gb=round(eng.weight_bytes() / 1e9, 3),
+               kv_cache_gb=round(eng.cache_bytes() / 1e9, 3))
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +146,9 @@ def main():
     ap.add_argument("--samples-per-gpu", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="build only the level-0 upsampler, run a short decode burst and print the roofline block "
+                         "(the command profiled under profiles/)")
     a = ap.parse_args()
 
     rank, local_rank, device = setup_dist_from_env()
@@ -118,6 +156,8 @@ def main():
     assert world == a.gpus or world == 1, f"launched with {world} ranks but --gpus {a.gpus}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
 
+    if a.roofline_only:
+        return roofline_only(a, device)
     tiny = a.model == "tiny"
     sr = 22050 if tiny else 44100
     hop = 64 if tiny else 128
@@ -172,8 +212,7 @@ def main():
     # dominant kernel, timed in situ with HIP events on the launch stream: the LayerNorm-fused weight-streaming
     # projections of the level-0 upsampler's decode step
     eng = next(iter(priors[0].prior._engines.values()))
-    us, launches, abytes = eng.probe_projection(4096 if not tiny else 64, 16 if not tiny else 8)
-    achieved = abytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    roofline = projection_roofline(eng, 4096 if not tiny else 64, 16 if not tiny else 8)
     # one decode step (graph replay) of the same engine
     torch.cuda.synchronize()
     ts = time.perf_counter()
@@ -182,9 +221,6 @@ def main():
     torch.cuda.synchronize()
     breakdown["level0_decode_ms_per_token_step"] = round((time.perf_counter() - ts) / n_probe * 1e3, 4)
     breakdown["launches_per_token_step"] = eng.launches_per_step
-    roofline = dict(bound="hbm", kernel="gemv_kernel<f16, LN-fused> (attn.c_attn / mlp.c_fc of the decode step)",
-                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=None, avg_launch_us=round(us, 3), launches_timed=launches, bytes_per_launch=int(abytes))
 
     out = dict(metric="generated audio sec/sec (3-level ancestral sample)", value=round(value, 4), unit="audio_s/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 1),

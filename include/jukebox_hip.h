@@ -92,6 +92,7 @@ typedef struct jb_gemv_args {
     int act;
     int qkv_split, S;
     void* kcache; void* vcache; int cache_cap; const int* t_dev;
+    const void* prefetch; int64_t prefetch_bytes;   /* optional: memory the NEXT launch will stream (touched early, values unused) */
 } jb_gemv_args;
 int jb_gemv(const jb_gemv_args* args /* host */, void* stream);
 
@@ -103,6 +104,11 @@ int jb_gemv(const jb_gemv_args* args /* host */, void* stream);
 int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache,
                    int cache_cap, void* out, int64_t ldo, int n_batch, int n_head, int d_head,
                    int block_ctx, const int* t_dev, int max_len, void* stream);
+
+/* Tuning hook: workgroup size (multiple of 64, <= 1024) and key/value row pairs in flight per wave (2, 4 or 8) of
+ * the generic kernel of jb_attn_decode (defaults 512 / 4; a value <= 0 keeps the current one).  kb < 0 disables the
+ * fp16 MFMA fast path (QK^T on MFMA) so that the generic kernel runs for every dtype. */
+void jb_tune_attn_decode(int threads, int kb);
 
 /* Chunked-prefill attention (q_l > 1) on MFMA with LDS-staged k/v tiles and online softmax:
  * queries at positions t0 .. t0+n_q-1 against the caches (already holding those positions).
@@ -164,6 +170,7 @@ typedef struct jb_engine_cfg {
     const float* start; int64_t start_stride;
     const float* x_cond; int64_t xc_n_stride, xc_t_stride;
     int add_cond_after;
+    int prefetch_next_weights;                             /* decode step: each projection touches the next one's weights */
     /* decode-step work buffers */
     void *x_a, *x_b, *q, *att, *mlp;                        /* engine dtype: [n][W],[n][W],[n][S],[n][S],[n][M] */
     float *xf, *logits;                                    /* [n][W], [n][bins] */
@@ -186,9 +193,10 @@ int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
 /* Run n_steps decode steps starting at position t0 (sets *t_dev = t0 first).  use_graph != 0 captures one step
  * into a hipGraph on first use and replays it. */
 int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
-/* Measurement aid: n_steps eager decode steps with HIP events recorded on `stream` around every LayerNorm-fused
- * projection launch (attn.c_attn and mlp.c_fc -- the dominant kernel of the decode step).  Synchronises.
- * out[0] = average microseconds per launch, out[1] = launches timed, out[2] = average algorithmic bytes per launch. */
+/* Measurement aid: n_steps passes over all layers launching only the LayerNorm-fused projections (attn.c_attn and
+ * mlp.c_fc -- the dominant kernel of the decode step) with their real arguments, back to back on `stream`, bracketed
+ * by one HIP event pair.  Synchronises.  out[0] = average microseconds per launch, out[1] = launches timed,
+ * out[2] = average algorithmic bytes per launch. */
 int jb_engine_probe_projection(void* handle, int t0, int n_steps, void* stream, double* out /* host, 3 doubles */);
 /* Number of kernel launches in one decode step (for launch-overhead accounting). */
 int jb_engine_launches_per_step(void* handle);

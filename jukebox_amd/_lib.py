@@ -30,7 +30,7 @@ class GemvArgs(C.Structure):
                 ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
                 ("W", vp), ("bias", vp), ("K", i32), ("J", i32), ("out", vp), ("ldo", i64),
                 ("res", vp), ("ldr", i64), ("act", i32), ("qkv_split", i32), ("S", i32),
-                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp)]
+                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp), ("prefetch", vp), ("prefetch_bytes", i64)]
 
 
 class SampleParams(C.Structure):
@@ -48,7 +48,7 @@ class EngineCfg(C.Structure):
     _fields_ = [("dtype", i32), ("n_batch", i32), ("width", i32), ("n_state", i32), ("n_head", i32), ("n_mlp", i32),
                 ("n_layers", i32), ("seq_len", i32), ("block_ctx", i32), ("bins", i32), ("ln_eps", f32),
                 ("x_emb", vp), ("pos_emb", vp), ("x_out_packed", vp), ("start", vp), ("start_stride", i64),
-                ("x_cond", vp), ("xc_n_stride", i64), ("xc_t_stride", i64), ("add_cond_after", i32),
+                ("x_cond", vp), ("xc_n_stride", i64), ("xc_t_stride", i64), ("add_cond_after", i32), ("prefetch_next_weights", i32),
                 ("x_a", vp), ("x_b", vp), ("q", vp), ("att", vp), ("mlp", vp), ("xf", vp), ("logits", vp),
                 ("chunk_cap", i32), ("c_xa", vp), ("c_xb", vp), ("c_h", vp), ("c_q", vp), ("c_att", vp),
                 ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
@@ -64,6 +64,7 @@ _SIGS = {
     "jb_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "jb_gemv": (i32, [C.POINTER(GemvArgs), vp]),
     "jb_attn_decode": (i32, [i32, i32, vp, i64, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
+    "jb_tune_attn_decode": (None, [i32, i32]),
     "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "jb_embed": (i32, [i32, vp, vp, i64, vp, vp, vp, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
     "jb_final_add": (i32, [i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, i32, vp]),

@@ -37,13 +37,12 @@ __device__ __forceinline__ KeySet decode_key_set(int func, int t, int bc, int ca
 // reuse to exploit with a single query row, so this runs on the vector ALU; the prefill kernel below
 // is the MFMA one.  In half mode the probabilities are rounded to half before multiplying the values
 // (factored_attention.py:98) relative to the running maximum.
-template <typename T, int NCH>
+template <typename T, int NCH, int KB>
 __global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ldq, const T* __restrict__ kc,
                                    const T* __restrict__ vc, int cap, T* __restrict__ out, int64_t ldo, int n_head,
                                    int d, int bc, const int* __restrict__ t_dev) {
     using V = typename Frag<T>::vec;
     constexpr int E = Frag<T>::E;
-    constexpr int KB = 4;                    // key/value row pairs in flight per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* s_ml = smem;                      // [nw][2] running max / sum per wave
@@ -153,6 +152,131 @@ __global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ld
     }
 }
 
+// Decode attention, fp16 fast path: QK^T on MFMA.  Wave w owns 16-key tiles w, w+nw, ...; for a tile it requests the
+// K fragments (lane = key l&15, channel slot l>>4: the A operand) and the 16 value rows (lane = 8-channel slice)
+// together, multiplies the K tile with the query replicated in all 16 B columns -- so every lane ends up with the
+// scores of keys (l>>4)*4 + r and the softmax statistics need only two cross-lane steps -- and accumulates p*V on the
+// vector ALU from the coalesced value rows.  No per-key shuffle reduction (6 ds_bpermute per key in the generic kernel).
+template <int ND32>
+__global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f16* __restrict__ q, int64_t ldq,
+                                                               const f16* __restrict__ kc, const f16* __restrict__ vc, int cap,
+                                                               f16* __restrict__ out, int64_t ldo, int n_head, int bc,
+                                                               const int* __restrict__ t_dev) {
+    constexpr int d = ND32 * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nw = blockDim.x >> 6;
+    float* s_ml = smem;                      // [nw][2]
+    float* s_pw = smem + 2 * nw;             // [nw][16] probabilities of the wave's current tile
+    float* s_o = s_pw + 16 * nw;             // [nw][d]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int n = blockIdx.x, h = blockIdx.y;
+    const int S = n_head * d;
+    const int t = *t_dev;
+    const KeySet ks = decode_key_set(func, t, bc, cap);
+    f16* o = out + (int64_t)n * ldo + h * d;
+    if (ks.count == 0) {
+        for (int i = threadIdx.x; i < d; i += blockDim.x) o[i] = (f16)0;
+        return;
+    }
+    const float scale = 1.0f / sqrtf(sqrtf((float)d));
+    const float scale2 = scale * scale;
+    const f16* qrow = q + (int64_t)n * ldq + h * d;
+    f16x8 qf[ND32];
+#pragma unroll
+    for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+    const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
+    const f16* vbase = vc + ((int64_t)n * cap) * S + h * d;
+    const int c0 = min(lane * 8, d - 8);     // this lane's value channels (lanes past d/8 compute unused duplicates)
+
+    float m_w = -INFINITY, l_w = 0.f;
+    float of[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) of[e] = 0.f;
+    float* pw = s_pw + 16 * wave;
+
+    const int ntiles = (ks.count + 15) >> 4;
+    for (int tt = wave; tt < ntiles; tt += nw) {
+        const int kbase_i = tt * 16;
+        // ---- requests: K fragments of key (kbase_i + c), value rows kbase_i + 0..15 ----
+        const int ki = min(kbase_i + c, ks.count - 1);
+        const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * S + g * 8;
+        f16x8 kf[ND32];
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) kf[dt] = ld_frag<f16>(kr + dt * 32);
+        f16x8 vv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int vi = min(kbase_i + k, ks.count - 1);
+            vv[k] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0);
+        }
+        // ---- scores of keys g*4 + r (identical in all 16 columns) ----
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) sc = jb_mfma(kf[dt], qf[dt], sc);
+        float pv[4], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = kbase_i + g * 4 + r < ks.count;
+            // reference: w = matmul(q, k) (half result), w.mul_(scale*scale) (half), then .float()
+            pv[r] = ok ? jb_round<f16>(jb_round<f16>(sc[r]) * scale2) : -INFINITY;
+            mx = fmaxf(mx, pv[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_w, mx);                 // finite: every tile has at least one valid key
+        const float alpha = expf(m_w - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pv[r] = (pv[r] == -INFINITY) ? 0.f : expf(pv[r] - m_new);
+            ps += pv[r];
+        }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l_w = l_w * alpha + ps;
+        m_w = m_new;
+        if (c == 0) *reinterpret_cast<f32x4*>(pw + g * 4) = f32x4{pv[0], pv[1], pv[2], pv[3]};
+        // same wave: LDS accesses are issued in order, the compiler's lgkmcnt wait suffices
+        f32x4 p4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p4[i] = *reinterpret_cast<const f32x4*>(pw + i * 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) of[e] *= alpha;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float pr = jb_round<f16>(p4[k >> 2][k & 3]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) of[e] += pr * (float)vv[k][e];
+        }
+    }
+    if (lane == 0) { s_ml[2 * wave] = m_w; s_ml[2 * wave + 1] = l_w; }
+    if (lane * 8 < d) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_o[wave * d + lane * 8 + e] = of[e];
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);
+    float lsum = 0.f;
+    for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] * expf(s_ml[2 * w] - m);
+    const float inv = 1.0f / lsum;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += s_o[w * d + i] * expf(s_ml[2 * w] - m);
+        o[i] = (f16)(a * inv);
+    }
+}
+
+// launch shape of the decode attention: threads per (sample, head) workgroup and key/value row pairs in flight per wave
+static int g_dec_threads = 512, g_dec_kb = 4, g_dec_mfma = 1;
+extern "C" void jb_tune_attn_decode(int threads, int kb) {
+    if (threads > 0) g_dec_threads = threads;
+    if (kb > 0) g_dec_kb = kb;
+    g_dec_mfma = kb >= 0;          // kb < 0 selects the generic (vector-ALU QK^T) kernel for every dtype
+}
+
 extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache,
                               const void* vcache, int cache_cap, void* out, int64_t ldo, int n_batch, int n_head,
                               int d_head, int block_ctx, const int* t_dev, int max_len, void* stream) {
@@ -164,17 +288,47 @@ extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t l
     const int nch = (d_head + 64 * E - 1) / (64 * E);
     if (nch > 2) JB_UNSUPPORTED("d_head too large for the decode attention kernel");
     // long (dense) rows get 16 waves to keep more row loads in flight; short patterns 4
-    const int threads = (attn_func == JB_ATTN_DENSE && max_len > 1024) ? 1024 : 512;
+    const int threads = g_dec_threads;
     const int nw = threads / 64;
     size_t lds = (size_t)(2 * nw + nw * d_head) * sizeof(float);
     (void)max_len;
     dim3 grid(n_batch, n_head);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == JB_F16 && g_dec_mfma && d_head % 32 == 0 && d_head <= 512 && ldq % 8 == 0 && (n_head * d_head) % 8 == 0) {
+        const int nwm = 8;
+        size_t ldsm = (size_t)(2 * nwm + 16 * nwm + nwm * d_head) * sizeof(float);
+#define JB_LAUNCH_DECM(ND)                                                                                      \
+    attn_decode_mfma_kernel<ND><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,    \
+                                                           (const f16*)vcache, cache_cap, (f16*)out, ldo, n_head, \
+                                                           block_ctx, t_dev)
+        switch (d_head / 32) {
+            case 1: JB_LAUNCH_DECM(1); break;
+            case 2: JB_LAUNCH_DECM(2); break;
+            case 4: JB_LAUNCH_DECM(4); break;
+            case 8: JB_LAUNCH_DECM(8); break;
+            case 15: JB_LAUNCH_DECM(15); break;
+            case 16: JB_LAUNCH_DECM(16); break;
+            default: goto generic;
+        }
+#undef JB_LAUNCH_DECM
+        JB_CHECK_LAUNCH();
+        return JB_OK;
+    }
+generic:
 #define JB_LAUNCH_DEC(T, NCH)                                                                                   \
     do {                                                                                                        \
-        attn_decode_kernel<T, NCH><<<grid, threads, lds, s>>>(attn_func, (const T*)q, ldq, (const T*)kcache,    \
-                                                              (const T*)vcache, cache_cap, (T*)out, ldo, n_head, \
-                                                              d_head, block_ctx, t_dev);                        \
+        if (g_dec_kb == 8 && NCH == 1)                                                                          \
+            attn_decode_kernel<T, NCH, 8><<<grid, threads, lds, s>>>(attn_func, (const T*)q, ldq, (const T*)kcache, \
+                                                                 (const T*)vcache, cache_cap, (T*)out, ldo, n_head, \
+                                                                 d_head, block_ctx, t_dev);                     \
+        else if (g_dec_kb == 2)                                                                                 \
+            attn_decode_kernel<T, NCH, 2><<<grid, threads, lds, s>>>(attn_func, (const T*)q, ldq, (const T*)kcache, \
+                                                                 (const T*)vcache, cache_cap, (T*)out, ldo, n_head, \
+                                                                 d_head, block_ctx, t_dev);                     \
+        else                                                                                                    \
+            attn_decode_kernel<T, NCH, 4><<<grid, threads, lds, s>>>(attn_func, (const T*)q, ldq, (const T*)kcache, \
+                                                                 (const T*)vcache, cache_cap, (T*)out, ldo, n_head, \
+                                                                 d_head, block_ctx, t_dev);                     \
     } while (0)
     if (dtype == JB_F16) { if (nch == 1) JB_LAUNCH_DEC(f16, 1); else JB_LAUNCH_DEC(f16, 2); }
     else { if (nch == 1) JB_LAUNCH_DEC(float, 1); else JB_LAUNCH_DEC(float, 2); }

@@ -71,46 +71,49 @@ extern "C" int jb_engine_launches_per_step(void* handle) {
         if (rc__ != JB_OK) return rc__; \
     } while (0)
 
-// Optional in-situ timing of the dominant kernel (the LayerNorm-fused weight-streaming projections c_attn and
-// mlp.c_fc): HIP events recorded on the launch stream around each of those launches.
-struct StepProbe { std::vector<hipEvent_t>* ev; };
-#define JB_PROBE(pr) do { if (pr) { hipEvent_t ev__; if (hipEventCreate(&ev__) == hipSuccess) { hipEventRecord(ev__, s); (pr)->ev->push_back(ev__); } } } while (0)
-
 // One decode step at position *t_dev; everything position-dependent is read on the device.
-static int enqueue_step(JbEngine* e, hipStream_t s, StepProbe* probe = nullptr) {
+static int enqueue_step(JbEngine* e, hipStream_t s) {
     const jb_engine_cfg& c = e->cfg;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
     JB_TRY(jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
                     c.xc_n_stride, c.xc_t_stride, N, W, 0, c.t_dev, 1, s));
+    const bool pf = c.prefetch_next_weights != 0;
+    const int64_t esz = c.dtype == JB_F16 ? 2 : 4;
+    const int64_t by_attn = jb_packed_weight_bytes(W, 3 * S, c.dtype), by_proj = jb_packed_weight_bytes(S, W, c.dtype);
+    const int64_t by_fc = jb_packed_weight_bytes(W, M, c.dtype), by_proj2 = jb_packed_weight_bytes(M, W, c.dtype);
+    (void)esz;
     for (int l = 0; l < c.n_layers; ++l) {
         const jb_layer& L = e->layers[l];
         jb_gemv_args g = {};
         g.dtype = c.dtype;
+        if (pf) { g.prefetch = L.w_proj; g.prefetch_bytes = by_proj; }
         // a7/a8/a9: ln_0 + c_attn, k/v appended at *t_dev
         g.x = c.x_a; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln0_g; g.ln_beta = L.ln0_b; g.ln_eps = c.ln_eps;
         g.W = L.w_attn; g.bias = L.b_attn; g.K = W; g.J = 3 * S; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
         g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
-        JB_PROBE(probe);
         JB_TRY(jb_gemv(&g, s));
-        JB_PROBE(probe);
         JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
                               c.block_ctx, c.t_dev, c.seq_len, s));
         // attn.c_proj + residual: x_b = x_a + a
         g = {};
         g.dtype = c.dtype; g.x = c.att; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
         g.out = c.x_b; g.ldo = W; g.res = c.x_a; g.ldr = W;
+        if (pf) { g.prefetch = L.w_fc; g.prefetch_bytes = by_fc; }
         JB_TRY(jb_gemv(&g, s));
         // ln_1 + mlp.c_fc + quick_gelu
         g = {};
         g.dtype = c.dtype; g.x = c.x_b; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln1_g; g.ln_beta = L.ln1_b; g.ln_eps = c.ln_eps;
         g.W = L.w_fc; g.bias = L.b_fc; g.K = W; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
-        JB_PROBE(probe);
+        if (pf) { g.prefetch = L.w_proj2; g.prefetch_bytes = by_proj2; }
         JB_TRY(jb_gemv(&g, s));
-        JB_PROBE(probe);
         // mlp.c_proj + residual: x_a = x_b + m   (h = x + a + m, transformer.py:82-83)
         g = {};
         g.dtype = c.dtype; g.x = c.mlp; g.ldx = M; g.n_rows = N; g.W = L.w_proj2; g.bias = L.b_proj2; g.K = M; g.J = W;
         g.out = c.x_a; g.ldo = W; g.res = c.x_b; g.ldr = W;
+        if (pf) {
+            if (l + 1 < c.n_layers) { g.prefetch = e->layers[l + 1].w_attn; g.prefetch_bytes = by_attn; }
+            else { g.prefetch = c.x_out_packed; g.prefetch_bytes = jb_packed_weight_bytes(W, c.bins, JB_F32); }
+        }
         JB_TRY(jb_gemv(&g, s));
     }
     JB_TRY(jb_final_add(c.dtype, c.x_a, c.xf, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride, c.xc_t_stride, N, W,
@@ -220,34 +223,54 @@ extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
     return JB_OK;
 }
 
-// Eager decode steps with HIP events around every LayerNorm-fused projection launch (2 per layer per step).
-// Synchronises the stream.  out[0] = average microseconds per such launch, out[1] = number of launches timed,
-// out[2] = average algorithmic bytes per such launch (weights once + activation rows in + rows out).
+// In-situ timing of the dominant kernel: n_steps passes over all layers launching ONLY the LayerNorm-fused
+// projections (attn.c_attn, mlp.c_fc) with their real arguments -- 2*L launches per pass, every launch streaming a
+// different, cold weight matrix as in the real step -- back to back on `stream`, bracketed by one HIP event pair.
+// Synchronises the stream.  out[0] = average microseconds per launch, out[1] = launches timed, out[2] = average
+// algorithmic bytes per launch (weights once + activation rows in + rows out).
 extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, void* stream, double* out) {
     JB_REQUIRE(handle && out, "null pointer");
     JbEngine* e = (JbEngine*)handle;
-    JB_REQUIRE(t0 >= 0 && n_steps > 0 && t0 + n_steps <= e->cfg.seq_len, "step range outside the sequence");
+    JB_REQUIRE(t0 >= 0 && n_steps > 0 && t0 < e->cfg.seq_len, "position outside the sequence");
     hipStream_t s = (hipStream_t)stream;
-    set_int_kernel<<<1, 1, 0, s>>>(e->cfg.t_dev, t0);
-    JB_CHECK_LAUNCH();
-    std::vector<hipEvent_t> ev;
-    StepProbe pr{&ev};
-    for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s, &pr));
-    JB_HIP(hipStreamSynchronize(s));
-    double total_ms = 0.0;
-    size_t pairs = ev.size() / 2;
-    for (size_t i = 0; i < pairs; ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) total_ms += ms;
-    }
-    for (hipEvent_t x : ev) (void)hipEventDestroy(x);
     const jb_engine_cfg& c = e->cfg;
+    const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp;
+    set_int_kernel<<<1, 1, 0, s>>>(c.t_dev, t0);
+    JB_CHECK_LAUNCH();
+    hipEvent_t e0, e1;
+    JB_HIP(hipEventCreate(&e0));
+    JB_HIP(hipEventCreate(&e1));
+    auto burst = [&](int reps) -> int {
+        for (int i = 0; i < reps; ++i)
+            for (int l = 0; l < c.n_layers; ++l) {
+                const jb_layer& L = e->layers[l];
+                jb_gemv_args g = {};
+                g.dtype = c.dtype; g.x = c.x_a; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln0_g; g.ln_beta = L.ln0_b; g.ln_eps = c.ln_eps;
+                g.W = L.w_attn; g.bias = L.b_attn; g.K = W; g.J = 3 * S; g.out = c.q; g.ldo = S;
+                g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
+                JB_TRY(jb_gemv(&g, s));
+                g = {};
+                g.dtype = c.dtype; g.x = c.x_b; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln1_g; g.ln_beta = L.ln1_b; g.ln_eps = c.ln_eps;
+                g.W = L.w_fc; g.bias = L.b_fc; g.K = W; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
+                JB_TRY(jb_gemv(&g, s));
+            }
+        return JB_OK;
+    };
+    JB_TRY(burst(1));                                   // warm-up pass (instruction caches, LDS attributes)
+    JB_HIP(hipEventRecord(e0, s));
+    JB_TRY(burst(n_steps));
+    JB_HIP(hipEventRecord(e1, s));
+    JB_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    JB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double launches = 2.0 * c.n_layers * n_steps;
     const double esz = c.dtype == JB_F16 ? 2.0 : 4.0;
-    const double W = c.width, S = c.n_state, M = c.n_mlp, N = c.n_batch;
-    const double b_attn = W * 3 * S * esz + N * W * esz + N * 3 * S * esz;
-    const double b_fc = W * M * esz + N * W * esz + N * M * esz;
-    out[0] = pairs ? total_ms * 1e3 / (double)pairs : 0.0;
-    out[1] = (double)pairs;
+    const double b_attn = (double)W * 3 * S * esz + (double)N * W * esz + (double)N * 3 * S * esz;
+    const double b_fc = (double)W * M * esz + (double)N * W * esz + (double)N * M * esz;
+    out[0] = (double)ms * 1e3 / launches;
+    out[1] = launches;
     out[2] = 0.5 * (b_attn + b_fc);
     return JB_OK;
 }

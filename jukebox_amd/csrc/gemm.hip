@@ -273,6 +273,7 @@ struct GemvParams {
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     const void* W; int K, nkt;
     int vec_x, lds_pitch, fast;
+    const void* pf_ptr; long long pf_bytes;     // next kernel's weights: touched early so they are in the memory-side cache
     long long* dbg;
     const int* t_dev;
     EpiParams epi;
@@ -370,6 +371,17 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
                                       ? (float)((const T*)p.epi.res)[(int64_t)row * p.epi.ldr + jb + r] : 0.f;
                 }
         }
+    }
+
+    // Cross-kernel prefetch: one dword per 128-byte line of the NEXT projection's weight image.  HBM is ~7 % busy in
+    // this latency-bound chain, so pulling the next kernel's weights into the Infinity Cache while this kernel runs
+    // costs nothing and turns the next kernel's cold HBM stream into cache hits.  The values are summed and consumed
+    // by an empty asm at the end, so the compiler tracks (and never reuses) their registers.
+    int pf_sum = 0;
+    if (p.pf_ptr) {
+        const long long stride = (long long)gridDim.x * (NW * 64) * 128;
+        for (long long off = ((long long)blockIdx.x * (NW * 64) + threadIdx.x) * 128; off < p.pf_bytes; off += stride)
+            pf_sum += *reinterpret_cast<const int*>(reinterpret_cast<const char*>(p.pf_ptr) + off);
     }
 
     if constexpr (LNS && FAST && NV > 0) {
@@ -585,6 +597,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     for (int mt = 0; mt < MT; ++mt) s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
     __syncthreads();
     JB_STAMP(6);
+    asm volatile("" ::"v"(pf_sum));
     if (wave != 0) return;
 
 #pragma unroll
@@ -684,6 +697,7 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     p.W = a->W; p.K = a->K;
     p.vec_x = (a->ldx % E == 0) && aligned_to(a->x, 16);
     p.t_dev = a->t_dev;
+    p.pf_ptr = a->prefetch; p.pf_bytes = a->prefetch_bytes;
     p.dbg = nullptr;
 #ifdef JB_TIMING
     p.dbg = jb_dbg_ptr;

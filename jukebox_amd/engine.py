@@ -8,6 +8,7 @@ Transformer / FactoredAttention while sampling (jukebox/transformer/factored_att
 (N, seq_len, n_state) k/v arrays.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -132,6 +133,7 @@ class PriorEngine:
             c.xc_n_stride = self.x_cond.stride(0)
             c.xc_t_stride = self.x_cond.stride(1) if self.x_cond.shape[1] > 1 else 0
         c.add_cond_after = int(self.add_cond_after)
+        c.prefetch_next_weights = int(os.environ.get("JB_PREFETCH", "0"))
         b = self.buf
         for k in ("x_a", "x_b", "q", "att", "mlp", "xf", "logits", "c_xa", "c_xb", "c_h", "c_q", "c_att", "c_mlp"):
             setattr(c, k, b[k].data_ptr())

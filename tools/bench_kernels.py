@@ -45,5 +45,7 @@ bench("gemv plain+res K=1920 J=1920", lambda: H.gemv(x, w_fc, bias=bias[:W], res
 bench("gemv plain K=480 J=1920 (+res)", lambda: H.gemv(xs, w_proj, bias=bias[:W], res=x, out=out_w))
 bench("gemv LN K=1920 J=1440", lambda: H.gemv(x, w_attn, bias=bias[:3 * S], ln=(g, b), out=out_3s))
 bench("gemv LN+gelu K=1920 J=1920", lambda: H.gemv(x, w_fc, bias=bias[:W], ln=(g, b), act=L.ACT_QUICK_GELU, out=out_w))
-for f in (1, 2, 3):
-    bench(f"attn_decode func {f} t=4500", lambda f=f: H.attn_decode(f, xs, kc, vc, 1, 64, t_dev, T))
+for thr, kb in ((512, -1), (512, 4)):
+    L.lib().jb_tune_attn_decode(thr, kb)
+    for f in (1, 2, 3):
+        bench(f"attn_decode func {f} t=4500 thr={thr} kb={kb}", lambda f=f: H.attn_decode(f, xs, kc, vc, 1, 64, t_dev, T))
