@@ -74,6 +74,85 @@ def sample_level(zs, labels, sampling_kwargs, level, prior, total_length, hop_le
     return zs
 
 
+def _level_plan(prior, zs_level_len, total_length, hop_length):
+    """[(start, sample_tokens or None)] for one level -- the windows sample_level would visit."""
+    if total_length >= prior.n_ctx:
+        return [(start, None) for start in get_starts(total_length, prior.n_ctx, hop_length)]
+    n_ctx, cur = prior.n_ctx, zs_level_len
+    if cur < n_ctx - total_length:
+        return [(0, cur + total_length)]
+    return [(cur - n_ctx + total_length, n_ctx)]
+
+
+def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_levels, hps, local_hps, lo, hi, device):
+    """Same windows, same tokens as the sequential level loop, scheduled as a pipeline: every level runs on its own
+    HIP stream (driven by its own host thread) and starts a window as soon as the upper-level codes that window is
+    conditioned on exist (prior.get_z_conds needs zs[level+1][start/cd : end/cd]).  The decode step is latency-bound
+    and uses at most half of the CUs, so the three levels overlap almost for free.  Tokens are a pure function of
+    (seed, global sample index, position), so the schedule does not change the result."""
+    import threading
+    cond = threading.Condition()
+    progress = {l: int(z.shape[1]) for l, z in enumerate(zs_local)}
+    ready_event = {}
+    errors = []
+    levels = sorted(sample_levels, reverse=True)
+    current = torch_cuda_current_stream(device)
+
+    def worker(level):
+        try:
+            prior = priors[level]
+            stream = t.cuda.Stream(device=device)
+            stream.wait_stream(current)
+            with t.cuda.stream(stream):
+                total_length = hps.sample_length // prior.raw_to_tokens
+                hop_length = int(hps.hop_fraction[level] * prior.n_ctx)
+                kw = dict(sampling_kwargs[level])
+                kw["sample_base"] = lo
+                lab = _shard_labels(labels[level], lo, hi)
+                for start, sample_tokens in _level_plan(prior, zs_local[level].shape[1], total_length, hop_length):
+                    if prior.x_cond and (level + 1) in sample_levels:
+                        need = (start + prior.n_ctx) // prior.cond_downsample
+                        with cond:
+                            cond.wait_for(lambda: progress[level + 1] >= need or errors)
+                            if errors:
+                                return
+                            ev = ready_event.get(level + 1)
+                        if ev is not None:
+                            stream.wait_event(ev)
+                    k = dict(kw)
+                    if sample_tokens is not None:
+                        k["sample_tokens"] = sample_tokens
+                    out = sample_single_window(list(zs_local), lab, k, level, prior, start, local_hps)
+                    ev = t.cuda.Event()
+                    ev.record(stream)
+                    with cond:
+                        zs_local[level] = out[level]
+                        progress[level] = int(out[level].shape[1])
+                        ready_event[level] = ev
+                        cond.notify_all()
+                callback = getattr(_sample, "level_done", None)
+                stream.synchronize()
+                if callable(callback):
+                    callback(level)
+        except BaseException as e:          # noqa: BLE001 -- re-raised in the caller
+            with cond:
+                errors.append(e)
+                cond.notify_all()
+
+    threads = [threading.Thread(target=worker, args=(l,), name=f"level{l}") for l in levels]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+    return zs_local
+
+
+def torch_cuda_current_stream(device):
+    return t.cuda.current_stream(device)
+
+
 def _shard_labels(labels, lo, hi):
     return dict(y=labels["y"][lo:hi].contiguous(), info=labels["info"][lo:hi])
 
@@ -87,6 +166,13 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
     local_hps.n_samples = hi - lo
     zs_local = [z[lo:hi].contiguous() for z in zs]
     xs = {}
+    pipelined = bool(hps.get("pipeline_levels", False)) and hps.get("keep_priors_resident", False) \
+        and len(sample_levels) > 1 and local_hps.n_samples > 0 and str(device).startswith("cuda")
+    if pipelined:
+        for level in sample_levels:
+            priors[level].to(device)
+        zs_local = _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_levels, hps, local_hps, lo, hi,
+                                            device)
     for level in reversed(sample_levels):
         prior = priors[level]
         prior.to(device)                         # sample.py:95 (prior.cuda()); binds the HIP engine lazily
@@ -97,7 +183,7 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
         hop_length = int(hps.hop_fraction[level] * prior.n_ctx)
         kw = dict(sampling_kwargs[level])
         kw["sample_base"] = lo
-        if local_hps.n_samples > 0:
+        if local_hps.n_samples > 0 and not pipelined:
             zs_local = sample_level(zs_local, _shard_labels(labels[level], lo, hi), kw, level, prior, total_length,
                                     hop_length, local_hps)
         if not hps.get("keep_priors_resident", False):
@@ -107,7 +193,7 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
         x_local = prior.decode(zs_local[level:], start_level=level, bs_chunks=max(1, zs_local[level].shape[0]))
         xs[level] = x_local
         _sample.level_done = getattr(_sample, "level_done", None)
-        if callable(_sample.level_done):
+        if callable(_sample.level_done) and not pipelined:
             _sample.level_done(level)
         if save:
             x = gather_shards(x_local, hps.n_samples)

@@ -136,3 +136,23 @@ def test_factored_attention_module_chunks(func):
         att.check_cache(2, pos, False)
     got = torch.cat(ys, 1).cpu().numpy()
     assert np.abs(got - y_chunks).max() < 5e-6
+
+
+def test_pipelined_levels_equal_sequential(models):
+    """The level pipeline (one stream per level) draws exactly the tokens of the reference's sequential level loop,
+    with random (non-greedy) sampling in fp16."""
+    from jukebox_amd import sample as S
+    vq, priors = models
+    g = load_golden("priors")
+    n = 3
+    labels = [dict(y=cu(g[f"p{i}.labels_y"]),
+                   info=[dict(full_tokens=list(map(int, g[f"p{i}.full_tokens{j}"]))) for j in range(n)]) for i in range(3)]
+    sk = [dict(temp=0.99, fp16=True, chunk_size=8, max_batch_size=3) for _ in range(3)]
+    outs = []
+    for pipe in (False, True):
+        hps = Hyperparams(n_samples=n, sample_length=4608, hop_fraction=[0.5, 0.5, 0.125], sr=22050, name="unused",
+                          keep_priors_resident=True, pipeline_levels=pipe)
+        zs = S.ancestral_sample(labels, sk, priors, hps, save=False)
+        outs.append([z.cpu().numpy() for z in zs])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
