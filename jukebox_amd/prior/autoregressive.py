@@ -68,8 +68,12 @@ class ConditionalAutoregressive2D(nn.Module):
         self._engines = {}
 
     def _apply(self, fn, *a, **k):
-        self._engines = {}              # device copies are dropped when the module moves (prior.cpu())
-        return super()._apply(fn, *a, **k)
+        before = (self.x_emb.weight.device, self.x_emb.weight.dtype, self.x_emb.weight.data_ptr())
+        out = super()._apply(fn, *a, **k)
+        after = (self.x_emb.weight.device, self.x_emb.weight.dtype, self.x_emb.weight.data_ptr())
+        if before != after:
+            self._engines = {}          # device copies are dropped when the module really moves (prior.cpu())
+        return out
 
     def preprocess(self, x):
         return x.view(x.shape[0], -1).long()
