@@ -114,9 +114,18 @@ def projection_roofline(eng, t0, n_steps):
     projections (attn.c_attn / mlp.c_fc) of an engine's decode step."""
     us, launches, abytes = eng.probe_projection(t0, n_steps)
     achieved = abytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
+    # their own rocprofv3 runs on the same kernel/shapes (profiles/r01_pmc_dominant_kernel.json); null otherwise
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")))
+        if int(pmc["algorithmic_bytes_per_launch"]) == int(abytes):
+            traffic = int(pmc["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
     return dict(bound="hbm", kernel="gemv_kernel<f16, LN-fused> (attn.c_attn / mlp.c_fc of the decode step)",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=None, avg_launch_us=round(us, 3), launches_timed=launches, bytes_per_launch=int(abytes))
+                traffic=traffic, avg_launch_us=round(us, 3), launches_timed=launches, bytes_per_launch=int(abytes))
 
 
 def roofline_only(a, device):
