@@ -118,6 +118,13 @@ void jb_tune_attn_decode(int threads, int kb);
 int jb_attn_prefill(int dtype, int attn_func, const void* q, const void* kcache, const void* vcache, int cache_cap,
                     void* out, int n_batch, int n_head, int d_head, int block_ctx, int t0, int n_q, void* stream);
 
+/* Attention probabilities of one head for queries t0..t0+n_q-1 (softmax over each query's pattern key set), fp32 rows
+ * out[n][out_row0 + i][key position < n_keys_out]; zeros where a key is not attended.  Serves the lyric alignment
+ * (jukebox/align.py:44-49: z_forward(get_attn_weights={alignment_layer}) -> FactoredAttention.w, factored_attention.py:101-105). */
+int jb_attn_probs(int dtype, int attn_func, const void* q, const void* kcache, int cache_cap, float* out,
+                  int64_t out_n_stride, int out_row0, int n_keys_out, int n_batch, int n_head, int d_head, int head,
+                  int block_ctx, int t0, int n_q, void* stream);
+
 /* Token/start embedding + position embedding + conditioning for positions t0..t0+n_t-1
  * (t0 taken from *t_dev when t_dev != NULL).  ConditionalAutoregressive2D.get_emb,
  * jukebox/prior/autoregressive.py:177-197.  tokens [n][tok_stride] int64 holds the token of
@@ -182,6 +189,9 @@ typedef struct jb_engine_cfg {
     int* t_dev;
     float* preds; int64_t preds_n_stride;                  /* optional [n][seq_len][bins] */
     const jb_sample_params* sample_params;                 /* device */
+    /* optional recording of one layer/head's attention probabilities during prefill (alignment): */
+    int rec_layer, rec_head, rec_keys;                     /* rec_layer < 0: off */
+    float* rec_out; int64_t rec_n_stride;                  /* [n][seq_len][rec_keys] */
 } jb_engine_cfg;
 
 /* Transformer.forward(sample=True) + the token loop of ConditionalAutoregressive2D.sample/primed_sample

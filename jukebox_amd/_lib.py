@@ -52,7 +52,8 @@ class EngineCfg(C.Structure):
                 ("x_a", vp), ("x_b", vp), ("q", vp), ("att", vp), ("mlp", vp), ("xf", vp), ("logits", vp),
                 ("chunk_cap", i32), ("c_xa", vp), ("c_xb", vp), ("c_h", vp), ("c_q", vp), ("c_att", vp),
                 ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
-                ("preds", vp), ("preds_n_stride", i64), ("sample_params", vp)]
+                ("preds", vp), ("preds_n_stride", i64), ("sample_params", vp),
+                ("rec_layer", i32), ("rec_head", i32), ("rec_keys", i32), ("rec_out", vp), ("rec_n_stride", i64)]
 
 
 _SIGS = {
@@ -66,6 +67,7 @@ _SIGS = {
     "jb_attn_decode": (i32, [i32, i32, vp, i64, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "jb_tune_attn_decode": (None, [i32, i32]),
     "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "jb_attn_probs": (i32, [i32, i32, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "jb_embed": (i32, [i32, vp, vp, i64, vp, vp, vp, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
     "jb_final_add": (i32, [i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
     "jb_sample_logits": (i32, [vp, i32, i32, vp, vp, i64, vp, vp, i64, vp]),

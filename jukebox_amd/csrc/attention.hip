@@ -564,3 +564,67 @@ extern "C" int jb_attn_prefill(int dtype, int attn_func, const void* q, const vo
     JB_CHECK_LAUNCH();
     return JB_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Attention probabilities of ONE head for a chunk of queries (alignment recording, jukebox/align.py:44-49 via
+// FactoredAttention.record_attn, factored_attention.py:101-105): softmax over the pattern's key set of each query
+// position, written as fp32 rows out[n][out_row0 + i][key position] for key positions < n_keys_out (zeros elsewhere).
+// One wave per query; lanes stride over the keys.  Not on the timed path.
+template <typename T>
+__global__ __launch_bounds__(64) void attn_probs_kernel(int func, const T* __restrict__ q, const T* __restrict__ kc, int cap,
+                                                        float* __restrict__ out, int64_t out_n_stride, int out_row0,
+                                                        int n_keys_out, int n_head, int d, int head, int bc, int t0, int nq) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x, i = blockIdx.x, n = blockIdx.y;
+    const int p = t0 + i, S = n_head * d;
+    const KeySet ks = decode_key_set(func, p, bc, cap);
+    float* orow = out + (int64_t)n * out_n_stride + (int64_t)(out_row0 + i) * n_keys_out;
+    for (int j = lane; j < n_keys_out; j += 64) orow[j] = 0.f;
+    if (ks.count == 0) return;
+    const T* qrow = q + ((int64_t)n * nq + i) * S + head * d;
+    const T* kbase = kc + ((int64_t)n * cap) * S + head * d;
+    const float scale = 1.0f / sqrtf(sqrtf((float)d));
+    const float scale2 = scale * scale;
+    float mx = -INFINITY;
+    for (int k = lane; k < ks.count; k += 64) {
+        const T* kr = kbase + (int64_t)(ks.start + k * ks.stride) * S;
+        float acc = 0.f;
+        for (int c = 0; c < d; ++c) acc += (float)qrow[c] * (float)kr[c];
+        const float sc = jb_round<T>(jb_round<T>(acc) * scale2);
+        sm[k] = sc;
+        mx = fmaxf(mx, sc);
+    }
+    mx = jb_wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < ks.count; k += 64) sum += expf(sm[k] - mx);
+    sum = jb_wave_sum(sum);
+    __syncthreads();
+    for (int k = lane; k < ks.count; k += 64) {
+        const int pos = ks.start + k * ks.stride;
+        if (pos < n_keys_out) orow[pos] = jb_round<T>(expf(sm[k] - mx) / sum);
+    }
+}
+
+extern "C" int jb_attn_probs(int dtype, int attn_func, const void* q, const void* kcache, int cache_cap, float* out,
+                             int64_t out_n_stride, int out_row0, int n_keys_out, int n_batch, int n_head, int d_head,
+                             int head, int block_ctx, int t0, int n_q, void* stream) {
+    JB_REQUIRE(q && kcache && out, "null pointer");
+    JB_REQUIRE(dtype == JB_F32 || dtype == JB_F16, "bad dtype");
+    JB_REQUIRE(n_batch > 0 && n_q > 0 && head >= 0 && head < n_head && n_keys_out > 0, "bad dims");
+    size_t lds = (size_t)(t0 + n_q > cache_cap ? t0 + n_q : cache_cap) * sizeof(float);
+    if (lds > 160 * 1024) JB_UNSUPPORTED("key set too long for the LDS score row");
+    dim3 grid(n_q, n_batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == JB_F16) {
+        if (lds > 64 * 1024) JB_HIP(hipFuncSetAttribute((const void*)attn_probs_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attn_probs_kernel<f16><<<grid, 64, lds, s>>>(attn_func, (const f16*)q, (const f16*)kcache, cache_cap, out, out_n_stride,
+                                                     out_row0, n_keys_out, n_head, d_head, head, block_ctx, t0, n_q);
+    } else {
+        if (lds > 64 * 1024) JB_HIP(hipFuncSetAttribute((const void*)attn_probs_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attn_probs_kernel<float><<<grid, 64, lds, s>>>(attn_func, (const float*)q, (const float*)kcache, cache_cap, out,
+                                                       out_n_stride, out_row0, n_keys_out, n_head, d_head, head, block_ctx, t0, n_q);
+    }
+    JB_CHECK_LAUNCH();
+    return JB_OK;
+}

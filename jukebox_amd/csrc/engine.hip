@@ -43,6 +43,8 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
                        L.ln0_g && L.ln0_b && L.ln1_g && L.ln1_b && L.kcache && L.vcache && L.cache_cap > 0,
                    "incomplete layer descriptor");
     }
+    JB_REQUIRE(!cfg->rec_out || (cfg->rec_layer >= 0 && cfg->rec_layer < cfg->n_layers && cfg->rec_keys > 0 &&
+                                 cfg->rec_head >= 0 && cfg->rec_head < cfg->n_head), "bad attention recording request");
     JbEngine* e = new JbEngine();
     e->cfg = *cfg;
     e->layers.assign(layers, layers + cfg->n_layers);
@@ -197,6 +199,9 @@ extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
             JB_TRY(jb_gemm(&g, s));
             JB_TRY(jb_attn_prefill(c.dtype, L.attn_func, c.c_q, L.kcache, L.vcache, L.cache_cap, c.c_att, N, H, d,
                                    c.block_ctx, p0, C, s));
+            if (c.rec_out && l == c.rec_layer)
+                JB_TRY(jb_attn_probs(c.dtype, L.attn_func, c.c_q, L.kcache, L.cache_cap, c.rec_out, c.rec_n_stride, p0,
+                                     c.rec_keys, N, H, d, c.rec_head, c.block_ctx, p0, C, s));
             base(g, c.c_att, S, S, L.w_proj, L.b_proj, W, c.c_xb, W);
             g.res = c.c_xa; g.ldr = W;
             JB_TRY(jb_gemm(&g, s));

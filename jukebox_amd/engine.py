@@ -40,7 +40,7 @@ class PriorEngine:
 
     def __init__(self, sd, prefix, *, n_batch, seq_len, bins, width, depth, heads, attn_order, blocks=None,
                  m_attn=0.25, m_mlp=1.0, prime_len=None, y_cond=False, add_cond_after=True, fp16=True,
-                 chunk_cap=256, want_preds=False, device="cuda"):
+                 chunk_cap=256, want_preds=False, record=None, device="cuda"):
         L.lib()
         self.device = torch.device(device)
         self.N, self.T, self.bins, self.W = n_batch, seq_len, bins, width
@@ -97,6 +97,9 @@ class PriorEngine:
         if want_preds:
             self.buf["c_xf"] = e(N * Cc, W, dtype=torch.float32)
         self.sample_params = H.make_sample_params(device=dev)
+        # record = (layer, head, n_keys): keep that head's attention probabilities during prefill (alignment)
+        self.record = record
+        self.rec_out = e(N, T, record[2], dtype=torch.float32) if record else None
         self.x_cond = None
         self.start = None
         self.handle = None
@@ -143,6 +146,10 @@ class PriorEngine:
         if self.preds is not None:
             c.preds, c.preds_n_stride = self.preds.data_ptr(), self.preds.stride(0)
         c.sample_params = self.sample_params.data_ptr()
+        c.rec_layer = -1
+        if self.record:
+            c.rec_layer, c.rec_head, c.rec_keys = self.record
+            c.rec_out, c.rec_n_stride = self.rec_out.data_ptr(), self.rec_out.stride(0)
         h = C.c_void_p()
         L.check(L.lib().jb_engine_create(C.byref(c), self.layers_c, C.byref(h)))
         self.handle = h

@@ -166,6 +166,7 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
     local_hps.n_samples = hi - lo
     zs_local = [z[lo:hi].contiguous() for z in zs]
     xs = {}
+    alignments = None
     pipelined = bool(hps.get("pipeline_levels", False)) and hps.get("keep_priors_resident", False) \
         and len(sample_levels) > 1 and local_hps.n_samples > 0 and str(device).startswith("cuda")
     if pipelined:
@@ -202,6 +203,17 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
                 os.makedirs(logdir, exist_ok=True)
                 t.save(dict(zs=zs, labels=labels, sampling_kwargs=sampling_kwargs, x=x), f"{logdir}/data.pth.tar")
                 save_wav(logdir, x, hps.sr)
+                top = priors[-1]
+                if alignments is None and top is not None and top.n_tokens > 0 and \
+                        not isinstance(top.labeller, EmptyLabeller) and getattr(top, "alignment_layer", None) is not None \
+                        and len(zs[-1][0]) > 0:
+                    # sample.py:118-120 + align.py:85-97 (the HTML viewer itself is not reproduced)
+                    from .align import get_alignment
+                    ahps = Hyperparams(levels=len(priors), hop_fraction=hps.hop_fraction)
+                    alignments = get_alignment(x, zs, labels[-1], top, sampling_kwargs[-1]["fp16"], ahps, device=device)
+                    if not hps.get("keep_priors_resident", False):
+                        top.cpu()
+                    t.save(dict(alignments=alignments), f"{logdir}/data_align.pth.tar")
     _sample.last_audio = xs
     return zs
 

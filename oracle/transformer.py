@@ -95,6 +95,8 @@ class Transformer:
         self.res_scale = 1.0 / n_depth if res_scale else 1.0
         self.funcs = list(funcs) if funcs is not None else [attn_func_of_layer(attn_order, d) for d in range(n_depth)]
         g = lambda name: np.asarray(sd[prefix + name], dtype=F32)
+        self.record, self.ws = set(), {}
+        self.prime_len = prime_len
         self.layers = []
         for d in range(n_depth):
             p = f"_attn_mods.{d}."
@@ -111,6 +113,12 @@ class Transformer:
                 lay["c_enc_kv_b"] = g(p + "attn.c_enc_kv.b")
             self.layers.append(lay)
         self.del_cache()
+
+    def set_record_attn(self, layers):
+        """transformer.py:141-167 -- layers whose softmax output is kept (None / empty set: off).  For a prime layer
+        only music queries x lyric keys are kept (factored_attention.py:101-105)."""
+        self.record = set(layers) if layers else set()
+        self.ws = {}
 
     def del_cache(self):
         """factored_attention.py:375-381."""
@@ -135,6 +143,7 @@ class Transformer:
             if empty.any():
                 pr = pr.copy()
                 pr[:, :, empty, :] = 0.0
+        self._last_pr = pr
         return r16(np.matmul(pr, v), fp16)
 
     def _split(self, x):
@@ -190,6 +199,13 @@ class Transformer:
                     lo, hi = cols[0], cols[-1] + 1
                     a = self._merge(self._attend(self._split(q), self._split(K[:, lo:hi]),
                                                  self._split(V[:, lo:hi]), mask[:, lo:hi], fp16))
+                    if d in self.record:
+                        w = np.zeros((*self._last_pr.shape[:3], kl), F32)
+                        w[..., lo:hi] = self._last_pr
+                        if func == 7:
+                            assert t0 == 0, "attention recording expects one full-length chunk"
+                            w = w[:, :, self.prime_len:, :self.prime_len]
+                        self.ws[d] = w
         return conv1d(a, lay["c_proj_w"], lay["c_proj_b"], fp16)
 
     def forward(self, x, encoder_kv=None, fp16=False, t0=None):

@@ -257,6 +257,13 @@ def gen_vqvae_and_priors():
         e2e[f"z{level}"] = zs[level].numpy()
         e2e[f"x{level}"] = prior.decode(zs[level:], start_level=level, bs_chunks=n).numpy()
         e2e[f"starts{level}"] = np.array(get_starts(total_length, prior.n_ctx, hop), dtype=np.int64)
+    # ---- lyric alignment of the top level (align.py:15-83), on the codes just sampled ----
+    from jukebox.align import get_alignment
+    top.alignment_layer, top.alignment_head = 15, 1          # the tiny top prior's only prime layer
+    ahps = Hyperparams(levels=3, hop_fraction=hps.hop_fraction)
+    al = get_alignment(None, zs, labels[2], top, False, ahps)
+    for j, a_ in enumerate(al):
+        e2e[f"alignment{j}"] = np.asarray(a_, dtype=np.float32)
     save("e2e", **e2e)
 
 

@@ -156,3 +156,21 @@ def test_pipelined_levels_equal_sequential(models):
         outs.append([z.cpu().numpy() for z in zs])
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_alignment_matches_reference(models):
+    """jukebox/align.py:get_alignment on the codes of the golden 3-level run (fp32): every item's stitched
+    (total_length, n_lyric_characters) attention matrix."""
+    from jukebox_amd.align import get_alignment
+    vq, priors = models
+    g, e = load_golden("priors"), load_golden("e2e")
+    top = priors[2]
+    top.alignment_layer, top.alignment_head = 15, 1
+    labels = dict(y=cu(g["p2.labels_y"]), info=[dict(full_tokens=list(map(int, g[f"p2.full_tokens{j}"]))) for j in range(3)])
+    zs = [cu(e["z0"]), cu(e["z1"]), cu(e["z2"])]
+    hps = Hyperparams(levels=3, hop_fraction=[0.5, 0.5, 0.125])
+    al = get_alignment(None, zs, labels, top, False, hps)
+    top.cuda()
+    for j in range(3):
+        assert al[j].shape == e[f"alignment{j}"].shape
+        assert np.abs(al[j] - e[f"alignment{j}"]).max() < 2e-6

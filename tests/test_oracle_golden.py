@@ -181,3 +181,31 @@ def test_misc_tables():
         i += 1
     for k in (1, 5, 97, 200):
         assert np.array_equal(ops.filter_logits(g["filter.logits"], top_k=k), g[f"filter.top_k{k}"])
+
+
+def test_alignment_matches_reference(tiny_hps):
+    """align.py:15-83 on the tiny top prior: attention of the prime layer (music queries x lyric keys) stitched over hops."""
+    from oracle.align import get_alignment
+    from jukebox_amd.data.labels import get_relevant_lyric_tokens
+    g, (_, _, top) = _priors(tiny_hps)
+    e = load_golden("e2e")
+    labels_y = g["p2.labels_y"]
+    full_tokens = [list(map(int, g[f"p2.full_tokens{j}"])) for j in range(3)]
+    raw_to_tokens = 64
+
+    def get_y(start):
+        y = labels_y.copy()
+        y[:, 2] = top.n_ctx * raw_to_tokens
+        y[:, 1] += start * raw_to_tokens
+        idx = []
+        for i in range(3):
+            toks, ind = get_relevant_lyric_tokens(full_tokens[i], top.n_tokens, int(y[i, 0]), int(y[i, 1]), int(y[i, 2]), f32=True)
+            y[i, -top.n_tokens:] = toks
+            idx.append(ind)
+        return y, idx
+
+    zs = [e["z0"], e["z1"], e["z2"]]
+    al = get_alignment(zs, labels_y, full_tokens, top, get_y, False, [0.5, 0.5, 0.125], 15, 1)
+    for j in range(3):
+        assert al[j].shape == e[f"alignment{j}"].shape
+        assert np.abs(al[j] - e[f"alignment{j}"]).max() < 1e-6
