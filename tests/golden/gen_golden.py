@@ -257,6 +257,19 @@ def gen_vqvae_and_priors():
         e2e[f"z{level}"] = zs[level].numpy()
         e2e[f"x{level}"] = prior.decode(zs[level:], start_level=level, bs_chunks=n).numpy()
         e2e[f"starts{level}"] = np.array(get_starts(total_length, prior.n_ctx, hop), dtype=np.int64)
+    # ---- primed mode (sample.py:143-147): encode a 2304-sample prompt, then continue all levels to 4608 samples ----
+    t.manual_seed(21)
+    xprompt = 2 * t.rand(n, 2304, 1) - 1
+    zs_p = priors[-1].encode(xprompt, start_level=0, end_level=3, bs_chunks=n)
+    e2e["primed.x"] = xprompt.numpy()
+    for level in (0, 1, 2):
+        e2e[f"primed.z_prompt{level}"] = zs_p[level].numpy()
+    for level in (2, 1, 0):
+        prior = priors[level]
+        total_length = hps.sample_length // prior.raw_to_tokens
+        hop = int(hps.hop_fraction[level] * prior.n_ctx)
+        zs_p = ref_sample.sample_level(zs_p, labels[level], sk[level], level, prior, total_length, hop, hps)
+        e2e[f"primed.z{level}"] = zs_p[level].numpy()
     # ---- lyric alignment of the top level (align.py:15-83), on the codes just sampled ----
     from jukebox.align import get_alignment
     top.alignment_layer, top.alignment_head = 15, 1          # the tiny top prior's only prime layer

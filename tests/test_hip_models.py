@@ -174,3 +174,40 @@ def test_alignment_matches_reference(models):
     for j in range(3):
         assert al[j].shape == e[f"alignment{j}"].shape
         assert np.abs(al[j] - e[f"alignment{j}"]).max() < 2e-6
+
+
+def test_primed_mode_and_data_dump(models, tmp_path):
+    """sample.py primed mode: encode a prompt with the VQ-VAE, continue every level (greedy) -- and the data.pth.tar
+    dump / load_codes round trip (sample.py:116,164-175)."""
+    import os
+    from jukebox_amd import sample as S
+    vq, priors = models
+    g, e = load_golden("priors"), load_golden("e2e")
+    n = 3
+    labels = [dict(y=cu(g[f"p{i}.labels_y"]),
+                   info=[dict(full_tokens=list(map(int, g[f"p{i}.full_tokens{j}"]))) for j in range(n)]) for i in range(3)]
+    sk = [dict(temp=1.0, fp16=False, chunk_size=8, max_batch_size=2, top_k=1),
+          dict(temp=1.0, fp16=False, chunk_size=8, max_batch_size=2, top_k=1),
+          dict(temp=1.0, fp16=False, chunk_size=5, max_batch_size=2, top_k=1)]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        hps = Hyperparams(n_samples=n, sample_length=4608, hop_fraction=[0.5, 0.5, 0.125], sr=22050, name="run",
+                          keep_priors_resident=True)
+        for p in priors:
+            p.alignment_layer = None
+        zs = S.primed_sample(cu(e["primed.x"]), labels, sk, priors, hps, save=True)
+        agree = [(zs[l].cpu().numpy() == e[f"primed.z{l}"]).mean() for l in range(3)]
+        prompt_ok = all((zs[l][:, :e[f"primed.z_prompt{l}"].shape[1]].cpu().numpy() == e[f"primed.z_prompt{l}"]).mean() > 0.99
+                        for l in range(3))
+        assert prompt_ok
+        if all(np.array_equal(zs[l][:, :e[f"primed.z_prompt{l}"].shape[1]].cpu().numpy(), e[f"primed.z_prompt{l}"]) for l in range(3)):
+            assert np.array_equal(zs[2].cpu().numpy(), e["primed.z2"])
+            assert min(agree) > 0.98, agree
+        data = torch.load("run/level_0/data.pth.tar", map_location="cpu", weights_only=False)
+        assert set(data) == {"zs", "labels", "sampling_kwargs", "x"} and data["x"].shape == (n, 4608, 1)
+        assert os.path.exists("run/level_0/item_0.wav")
+        zs2 = S.load_codes("run/level_2/data.pth.tar", 2304, priors, hps)
+        assert [z.shape[1] for z in zs2] == [576, 144, 36] and torch.equal(zs2[2].cpu(), zs[2][:, :36].cpu())
+    finally:
+        os.chdir(cwd)
