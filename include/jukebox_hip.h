@@ -135,8 +135,9 @@ int jb_embed(int out_dtype, void* out, const int64_t* tokens, int64_t tok_stride
              int64_t xc_n_stride, int64_t xc_t_stride, int n_batch, int width, int t0, const int* t_dev, int n_t,
              void* stream);
 
-/* xf = float(h) + x_cond[:, t] (add_cond_after_transformer, autoregressive.py:226-227,307-309). */
-int jb_final_add(int h_dtype, const void* h, float* xf, const float* x_cond, int64_t xc_n_stride,
+/* xf = float(h) + x_cond[:, t] (add_cond_after_transformer, autoregressive.py:226-227,307-309).  Output row of
+ * (sample n, chunk position c) is xf + n*xf_n_stride + c*width (xf_n_stride = 0 means n_t*width, i.e. packed). */
+int jb_final_add(int h_dtype, const void* h, float* xf, int64_t xf_n_stride, const float* x_cond, int64_t xc_n_stride,
                  int64_t xc_t_stride, int n_batch, int width, int t0, const int* t_dev, int n_t, void* stream);
 
 /* Temperature, top-k / nucleus filtering and categorical sampling of one token per row, written to
@@ -166,6 +167,10 @@ typedef struct jb_layer {
     const float *ln0_g, *ln0_b, *ln1_g, *ln1_b;
     void *kcache, *vcache;                                 /* [n_batch][cache_cap][n_state], engine dtype */
     int cache_cap;
+    /* cross-attention layers (attn_func 6, factored_attention.py:46-48,273-287): w_attn is n_in x n_state (query only);
+     * c_enc_kv is given as its key and value halves, each n_in x n_state, with the (2*n_state) bias; the caches hold
+     * the projected encoder states, cache_cap = encoder length. */
+    const void *w_enc_k, *w_enc_v; const float* b_enc_kv;
 } jb_layer;
 
 typedef struct jb_engine_cfg {
@@ -177,6 +182,8 @@ typedef struct jb_engine_cfg {
     const float* start; int64_t start_stride;
     const float* x_cond; int64_t xc_n_stride, xc_t_stride;
     int add_cond_after;
+    const void* encoder_kv; int enc_len;                   /* [n][enc_len][width], engine dtype (cross-attention models) */
+    float* hidden_out; int64_t hidden_n_stride;            /* optional: final hidden states of prefilled positions, fp32 [n][seq_len][width] */
     int prefetch_next_weights;                             /* decode step: each projection touches the next one's weights */
     /* decode-step work buffers */
     void *x_a, *x_b, *q, *att, *mlp;                        /* engine dtype: [n][W],[n][W],[n][S],[n][S],[n][M] */
@@ -198,6 +205,9 @@ typedef struct jb_engine_cfg {
  * (jukebox/transformer/transformer.py:169-192, jukebox/prior/autoregressive.py:222-236,289-347). */
 int jb_engine_create(const jb_engine_cfg* cfg /* host */, const jb_layer* layers /* host array */, void** handle);
 int jb_engine_destroy(void* handle);
+/* Cross-attention models: project cfg.encoder_kv through every cross layer's c_enc_kv into that layer's k/v cache
+ * (decode_qkv at sample_t == 0, factored_attention.py:273-280).  Call once per window before prefill / decode. */
+int jb_engine_set_encoder_kv(void* handle, void* stream);
 /* Prefill positions t0..t0+n_t-1 (tokens already in cfg.tokens): fills the k/v caches, leaves *t_dev = t0+n_t. */
 int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
 /* Run n_steps decode steps starting at position t0 (sets *t_dev = t0 first).  use_graph != 0 captures one step

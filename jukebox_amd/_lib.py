@@ -41,14 +41,15 @@ class Layer(C.Structure):
     _fields_ = [("attn_func", i32), ("w_attn", vp), ("w_proj", vp), ("w_fc", vp), ("w_proj2", vp),
                 ("b_attn", vp), ("b_proj", vp), ("b_fc", vp), ("b_proj2", vp),
                 ("ln0_g", vp), ("ln0_b", vp), ("ln1_g", vp), ("ln1_b", vp),
-                ("kcache", vp), ("vcache", vp), ("cache_cap", i32)]
+                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("w_enc_k", vp), ("w_enc_v", vp), ("b_enc_kv", vp)]
 
 
 class EngineCfg(C.Structure):
     _fields_ = [("dtype", i32), ("n_batch", i32), ("width", i32), ("n_state", i32), ("n_head", i32), ("n_mlp", i32),
                 ("n_layers", i32), ("seq_len", i32), ("block_ctx", i32), ("bins", i32), ("ln_eps", f32),
                 ("x_emb", vp), ("pos_emb", vp), ("x_out_packed", vp), ("start", vp), ("start_stride", i64),
-                ("x_cond", vp), ("xc_n_stride", i64), ("xc_t_stride", i64), ("add_cond_after", i32), ("prefetch_next_weights", i32),
+                ("x_cond", vp), ("xc_n_stride", i64), ("xc_t_stride", i64), ("add_cond_after", i32), ("encoder_kv", vp), ("enc_len", i32), ("hidden_out", vp), ("hidden_n_stride", i64),
+                ("prefetch_next_weights", i32),
                 ("x_a", vp), ("x_b", vp), ("q", vp), ("att", vp), ("mlp", vp), ("xf", vp), ("logits", vp),
                 ("chunk_cap", i32), ("c_xa", vp), ("c_xb", vp), ("c_h", vp), ("c_q", vp), ("c_att", vp),
                 ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
@@ -69,12 +70,13 @@ _SIGS = {
     "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "jb_attn_probs": (i32, [i32, i32, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "jb_embed": (i32, [i32, vp, vp, i64, vp, vp, vp, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
-    "jb_final_add": (i32, [i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
+    "jb_final_add": (i32, [i32, vp, vp, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
     "jb_sample_logits": (i32, [vp, i32, i32, vp, vp, i64, vp, vp, i64, vp]),
     "jb_vq_gather": (i32, [vp, vp, vp, i64, i32, i32, vp]),
     "jb_vq_argmin": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
     "jb_engine_create": (i32, [C.POINTER(EngineCfg), C.POINTER(Layer), C.POINTER(vp)]),
     "jb_engine_destroy": (i32, [vp]),
+    "jb_engine_set_encoder_kv": (i32, [vp, vp]),
     "jb_engine_prefill": (i32, [vp, i32, i32, vp]),
     "jb_engine_decode": (i32, [vp, i32, i32, i32, vp]),
     "jb_engine_probe_projection": (i32, [vp, i32, i32, vp, C.POINTER(C.c_double)]),

@@ -93,29 +93,31 @@ extern "C" int jb_embed(int out_dtype, void* out, const int64_t* tokens, int64_t
 }
 
 template <typename T>
-__global__ void final_add_kernel(const T* __restrict__ h, float* __restrict__ xf, const float* __restrict__ x_cond,
+__global__ void final_add_kernel(const T* __restrict__ h, float* __restrict__ xf, int64_t xf_n, const float* __restrict__ x_cond,
                                  int64_t xc_n, int64_t xc_t, int W, int t0, const int* __restrict__ t_dev, int n_t) {
     const int c = blockIdx.x, n = blockIdx.y;
     const int t = (t_dev ? *t_dev : t0) + c;
     const int64_t row = (int64_t)n * n_t + c;
     const float* cd = x_cond ? x_cond + (int64_t)n * xc_n + (int64_t)t * xc_t : nullptr;
+    float* o = xf + (int64_t)n * xf_n + (int64_t)c * W;
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
         float v = (float)h[row * W + i];
         if (cd) v += cd[i];
-        xf[row * W + i] = v;
+        o[i] = v;
     }
 }
 
-extern "C" int jb_final_add(int h_dtype, const void* h, float* xf, const float* x_cond, int64_t xc_n_stride,
-                            int64_t xc_t_stride, int n_batch, int width, int t0, const int* t_dev, int n_t,
-                            void* stream) {
+extern "C" int jb_final_add(int h_dtype, const void* h, float* xf, int64_t xf_n_stride, const float* x_cond,
+                            int64_t xc_n_stride, int64_t xc_t_stride, int n_batch, int width, int t0, const int* t_dev,
+                            int n_t, void* stream) {
     JB_REQUIRE(h && xf, "null pointer");
+    if (xf_n_stride == 0) xf_n_stride = (int64_t)n_t * width;
     dim3 grid(n_t, n_batch);
     hipStream_t s = (hipStream_t)stream;
     if (h_dtype == JB_F16)
-        final_add_kernel<f16><<<grid, 256, 0, s>>>((const f16*)h, xf, x_cond, xc_n_stride, xc_t_stride, width, t0, t_dev, n_t);
+        final_add_kernel<f16><<<grid, 256, 0, s>>>((const f16*)h, xf, xf_n_stride, x_cond, xc_n_stride, xc_t_stride, width, t0, t_dev, n_t);
     else
-        final_add_kernel<float><<<grid, 256, 0, s>>>((const float*)h, xf, x_cond, xc_n_stride, xc_t_stride, width, t0, t_dev, n_t);
+        final_add_kernel<float><<<grid, 256, 0, s>>>((const float*)h, xf, xf_n_stride, x_cond, xc_n_stride, xc_t_stride, width, t0, t_dev, n_t);
     JB_CHECK_LAUNCH();
     return JB_OK;
 }

@@ -31,14 +31,16 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
     JB_REQUIRE(cfg->width > 0 && cfg->n_state > 0 && cfg->n_head > 0 && cfg->n_mlp > 0 && cfg->n_layers > 0, "bad dims");
     JB_REQUIRE(cfg->n_state % cfg->n_head == 0, "n_state must divide by n_head");
     JB_REQUIRE(cfg->seq_len > 0 && cfg->bins > 0, "bad seq_len / bins");
-    JB_REQUIRE(cfg->x_emb && cfg->pos_emb && cfg->x_out_packed && cfg->start, "missing embedding tables");
+    JB_REQUIRE(cfg->x_emb && cfg->pos_emb && cfg->start, "missing embedding tables");
     JB_REQUIRE(cfg->x_a && cfg->x_b && cfg->q && cfg->att && cfg->mlp && cfg->xf && cfg->logits, "missing decode buffers");
     JB_REQUIRE(cfg->tokens && cfg->t_dev && cfg->sample_params, "missing token / counter / sampler buffers");
     for (int l = 0; l < cfg->n_layers; ++l) {
         const jb_layer& L = layers[l];
-        JB_REQUIRE(L.attn_func == 0 || L.attn_func == 1 || L.attn_func == 2 || L.attn_func == 3 || L.attn_func == 7,
-                   "unsupported attn_func (cross attention is SURVEY 8f item 3)");
-        JB_REQUIRE(L.attn_func == 0 || L.attn_func == 7 || cfg->block_ctx > 0, "block_ctx required");
+        JB_REQUIRE(L.attn_func == 0 || L.attn_func == 1 || L.attn_func == 2 || L.attn_func == 3 || L.attn_func == 6 ||
+                       L.attn_func == 7, "unsupported attn_func");
+        JB_REQUIRE(L.attn_func == 0 || L.attn_func == 6 || L.attn_func == 7 || cfg->block_ctx > 0, "block_ctx required");
+        JB_REQUIRE(L.attn_func != 6 || (L.w_enc_k && L.w_enc_v && L.b_enc_kv && cfg->encoder_kv && cfg->enc_len > 0 &&
+                                        L.cache_cap == cfg->enc_len), "cross-attention layer needs c_enc_kv and encoder_kv");
         JB_REQUIRE(L.w_attn && L.w_proj && L.w_fc && L.w_proj2 && L.b_attn && L.b_proj && L.b_fc && L.b_proj2 &&
                        L.ln0_g && L.ln0_b && L.ln1_g && L.ln1_b && L.kcache && L.vcache && L.cache_cap > 0,
                    "incomplete layer descriptor");
@@ -91,8 +93,13 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
         if (pf) { g.prefetch = L.w_proj; g.prefetch_bytes = by_proj; }
         // a7/a8/a9: ln_0 + c_attn, k/v appended at *t_dev
         g.x = c.x_a; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln0_g; g.ln_beta = L.ln0_b; g.ln_eps = c.ln_eps;
-        g.W = L.w_attn; g.bias = L.b_attn; g.K = W; g.J = 3 * S; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
-        g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
+        g.W = L.w_attn; g.bias = L.b_attn; g.K = W; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
+        if (L.attn_func == JB_ATTN_CROSS) {
+            g.J = S;                         // query only; k/v come from the encoder (set_encoder_kv)
+        } else {
+            g.J = 3 * S;
+            g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
+        }
         JB_TRY(jb_gemv(&g, s));
         JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
                               c.block_ctx, c.t_dev, c.seq_len, s));
@@ -118,7 +125,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
         }
         JB_TRY(jb_gemv(&g, s));
     }
-    JB_TRY(jb_final_add(c.dtype, c.x_a, c.xf, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride, c.xc_t_stride, N, W,
+    JB_TRY(jb_final_add(c.dtype, c.x_a, c.xf, 0, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride, c.xc_t_stride, N, W,
                         0, c.t_dev, 1, s));
     jb_gemv_args g = {};
     g.dtype = JB_F32; g.x = c.xf; g.ldx = W; g.n_rows = N; g.W = c.x_out_packed; g.K = W; g.J = c.bins;
@@ -135,6 +142,7 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
     JB_REQUIRE(handle, "null engine");
     JbEngine* e = (JbEngine*)handle;
     JB_REQUIRE(t0 >= 0 && n_steps >= 0 && t0 + n_steps <= e->cfg.seq_len, "step range outside the sequence");
+    JB_REQUIRE(e->cfg.x_out_packed && e->cfg.bins > 0, "this engine has no logits head (only_encode)");
     hipStream_t s = (hipStream_t)stream;
     set_int_kernel<<<1, 1, 0, s>>>(e->cfg.t_dev, t0);
     JB_CHECK_LAUNCH();
@@ -166,6 +174,28 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
     return JB_OK;
 }
 
+// decode_qkv at sample_t == 0 (factored_attention.py:273-280): key / value = c_enc_kv(encoder_kv), once per window.
+extern "C" int jb_engine_set_encoder_kv(void* handle, void* stream) {
+    JB_REQUIRE(handle, "null engine");
+    JbEngine* e = (JbEngine*)handle;
+    const jb_engine_cfg& c = e->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    const int N = c.n_batch, W = c.width, S = c.n_state;
+    for (int l = 0; l < c.n_layers; ++l) {
+        const jb_layer& L = e->layers[l];
+        if (L.attn_func != JB_ATTN_CROSS) continue;
+        for (int part = 0; part < 2; ++part) {
+            jb_gemm_args g = {};
+            g.dtype = c.dtype; g.A = c.encoder_kv; g.lda = W; g.W = part == 0 ? L.w_enc_k : L.w_enc_v;
+            g.bias = L.b_enc_kv + part * S; g.out = part == 0 ? L.kcache : L.vcache; g.ldo = S;
+            g.n_seq = N; g.t_in = c.enc_len; g.t_out = c.enc_len; g.in_seq_stride = c.enc_len; g.out_seq_stride = c.enc_len;
+            g.K = W; g.J = S; g.n_taps = 1; g.in_stride = 1; g.out_stride = 1; g.res_scale = 1.0f;
+            JB_TRY(jb_gemm(&g, s));
+        }
+    }
+    return JB_OK;
+}
+
 // Chunked prefill of positions t0 .. t0+n_t-1 (primed_sample, autoregressive.py:284-318), in sub-chunks of
 // at most chunk_cap positions; outputs are discarded unless preds is set (get_preds).
 extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
@@ -194,8 +224,12 @@ extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
             const jb_layer& L = e->layers[l];
             jb_gemm_args g;
             JB_TRY(jb_layernorm_fwd(c.c_xa, c.dtype, c.c_h, c.dtype, L.ln0_g, L.ln0_b, rows, W, c.ln_eps, s));
-            base(g, c.c_h, W, W, L.w_attn, L.b_attn, 3 * S, c.c_q, S);
-            g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.cache_t0 = p0;
+            if (L.attn_func == JB_ATTN_CROSS) {
+                base(g, c.c_h, W, W, L.w_attn, L.b_attn, S, c.c_q, S);
+            } else {
+                base(g, c.c_h, W, W, L.w_attn, L.b_attn, 3 * S, c.c_q, S);
+                g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.cache_t0 = p0;
+            }
             JB_TRY(jb_gemm(&g, s));
             JB_TRY(jb_attn_prefill(c.dtype, L.attn_func, c.c_q, L.kcache, L.vcache, L.cache_cap, c.c_att, N, H, d,
                                    c.block_ctx, p0, C, s));
@@ -213,8 +247,12 @@ extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
             g.res = c.c_xb; g.ldr = W;
             JB_TRY(jb_gemm(&g, s));
         }
+        if (c.hidden_out)      // only_encode models: the activations are the output (autoregressive.py:155-157)
+            JB_TRY(jb_final_add(c.dtype, c.c_xa, c.hidden_out + (int64_t)p0 * W, c.hidden_n_stride,
+                                c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride, c.xc_t_stride, N, W, p0, nullptr, C, s));
         if (c.preds) {
-            JB_TRY(jb_final_add(c.dtype, c.c_xa, c.c_xf, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride,
+            JB_REQUIRE(c.x_out_packed, "preds requested from an engine without a logits head");
+            JB_TRY(jb_final_add(c.dtype, c.c_xa, c.c_xf, 0, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride,
                                 c.xc_t_stride, N, W, p0, nullptr, C, s));
             jb_gemm_args g;
             base(g, c.c_xf, W, W, c.x_out_packed, nullptr, c.bins, c.preds, c.bins);

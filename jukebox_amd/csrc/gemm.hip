@@ -479,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
             }
         }
         JB_STAMP(1);
-        float* s_g = reinterpret_cast<float*>(s_x + (int64_t)16 * MT * pitch);   // [pitch] gamma, then [pitch] beta
+        float* s_g = reinterpret_cast<float*>(s_x + (int64_t)p.n_rows * pitch);   // [pitch] gamma, then [pitch] beta
         float* s_b = s_g + pitch;
         for (int k = threadIdx.x; k < pitch; k += NW * 64) {
             s_g[k] = k < p.K ? p.ln_gamma[k] : 0.f;
@@ -657,7 +657,7 @@ static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
     int nw = p.nkt >= 32 ? 8 : 4;
     if (ln && nw == 8) {   // keep the staged rows + partial tiles within the 160 KiB of LDS
         size_t pit = ((p.K + E - 1) / E) * E + E;
-        size_t need = (size_t)8 * mt * 64 * sizeof(f32x4) + (size_t)16 * mt * pit * sizeof(T) + 2 * pit * sizeof(float);
+        size_t need = (size_t)8 * mt * 64 * sizeof(f32x4) + (size_t)p.n_rows * pit * sizeof(T) + 2 * pit * sizeof(float);
         if (need > 160 * 1024) nw = 4;
     }
     size_t lds = (size_t)nw * mt * 64 * sizeof(f32x4);
@@ -665,7 +665,7 @@ static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
         // row pitch: K rounded up to E, plus one 16-byte slot so that the 16 rows of a fragment read
         // fall into different LDS slots (cdna_hip_programming.md Guideline 4)
         p.lds_pitch = ((p.K + E - 1) / E) * E + E;
-        lds += (size_t)16 * mt * p.lds_pitch * sizeof(T) + (size_t)2 * p.lds_pitch * sizeof(float);
+        lds += (size_t)p.n_rows * p.lds_pitch * sizeof(T) + (size_t)2 * p.lds_pitch * sizeof(float);   // rows, then gamma | beta
         if (lds > 160 * 1024) {
             jb_set_error("jb_gemv: LayerNorm rows do not fit in LDS (n_rows x K too large)");
             return JB_ERR_UNSUPPORTED;

@@ -40,7 +40,7 @@ class PriorEngine:
 
     def __init__(self, sd, prefix, *, n_batch, seq_len, bins, width, depth, heads, attn_order, blocks=None,
                  m_attn=0.25, m_mlp=1.0, prime_len=None, y_cond=False, add_cond_after=True, fp16=True,
-                 chunk_cap=256, want_preds=False, record=None, device="cuda"):
+                 chunk_cap=256, want_preds=False, record=None, encoder_dims=0, only_encode=False, device="cuda"):
         L.lib()
         self.device = torch.device(device)
         self.N, self.T, self.bins, self.W = n_batch, seq_len, bins, width
@@ -59,7 +59,9 @@ class PriorEngine:
         self.x_emb = f32("x_emb.weight")
         self.pos_emb = f32("pos_emb.pos_emb")
         self.start_token = None if y_cond else f32("start_token")
-        self.x_out = H.pack_linear_w(f32("x_out.weight"), torch.float32)
+        self.only_encode = only_encode
+        self.x_out = None if only_encode else H.pack_linear_w(f32("x_out.weight"), torch.float32)
+        self.enc_len = int(encoder_dims or 0)
         self._keep = []          # tensors referenced by raw pointer from the engine
         self.layers_c = (L.Layer * depth)()
         N, T, S, W, M = self.N, self.T, self.S, self.W, self.M
@@ -67,12 +69,18 @@ class PriorEngine:
         for d in range(depth):
             p = f"transformer._attn_mods.{d}."
             func = self.funcs[d]
-            if func not in (0, 1, 2, 3, 7):
-                raise L.JukeboxHipError(f"attn_func {func} is not supported by the engine yet")
+            if func not in (0, 1, 2, 3, 6, 7):
+                raise L.JukeboxHipError(f"attn_func {func} is not supported by the engine")
             ws = [H.pack_conv1d_w(g(p + n), dt) for n in ("attn.c_attn.w", "attn.c_proj.w", "mlp.c_fc.w", "mlp.c_proj.w")]
             bs = [f32(p + n) for n in ("attn.c_attn.b", "attn.c_proj.b", "mlp.c_fc.b", "mlp.c_proj.b")]
             lns = [f32(p + n) for n in ("ln_0.weight", "ln_0.bias", "ln_1.weight", "ln_1.bias")]
-            cap = self.prime_cap if func == 7 else T
+            cap = self.prime_cap if func == 7 else (self.enc_len if func == 6 else T)
+            if func == 6:
+                # c_enc_kv (n_in, 2*n_state): key half and value half as separate packed matrices
+                wkv = g(p + "attn.c_enc_kv.w")
+                enc = [H.PackedWeight(H.pack_weight(wkv, W, S, 2 * S, 1, dt, offset_elems=part * S), W, S, dt) for part in (0, 1)]
+                b_enc = f32(p + "attn.c_enc_kv.b")
+                self._keep += enc + [b_enc]
             kc = torch.zeros((N, cap, S), dtype=dt, device=dev)
             vc = torch.zeros((N, cap, S), dtype=dt, device=dev)
             self.kcaches.append(kc)
@@ -84,11 +92,13 @@ class PriorEngine:
             lc.b_attn, lc.b_proj, lc.b_fc, lc.b_proj2 = (b.data_ptr() for b in bs)
             lc.ln0_g, lc.ln0_b, lc.ln1_g, lc.ln1_b = (t.data_ptr() for t in lns)
             lc.kcache, lc.vcache, lc.cache_cap = kc.data_ptr(), vc.data_ptr(), cap
+            if func == 6:
+                lc.w_enc_k, lc.w_enc_v, lc.b_enc_kv = enc[0].ptr, enc[1].ptr, b_enc.data_ptr()
 
         e = lambda *shape, dtype=dt: torch.zeros(shape, dtype=dtype, device=dev)
         Cc = self.chunk_cap
         self.buf = dict(x_a=e(N, W), x_b=e(N, W), q=e(N, S), att=e(N, S), mlp=e(N, M),
-                        xf=e(N, W, dtype=torch.float32), logits=e(N, bins, dtype=torch.float32),
+                        xf=e(N, W, dtype=torch.float32), logits=e(N, max(bins, 1), dtype=torch.float32),
                         c_xa=e(N * Cc, W), c_xb=e(N * Cc, W), c_h=e(N * Cc, W), c_q=e(N * Cc, S), c_att=e(N * Cc, S),
                         c_mlp=e(N * Cc, M))
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
@@ -100,6 +110,8 @@ class PriorEngine:
         # record = (layer, head, n_keys): keep that head's attention probabilities during prefill (alignment)
         self.record = record
         self.rec_out = e(N, T, record[2], dtype=torch.float32) if record else None
+        self.hidden = e(N, T, W, dtype=torch.float32) if only_encode else None
+        self.encoder_kv = e(N, self.enc_len, W) if self.enc_len else None
         self.x_cond = None
         self.start = None
         self.handle = None
@@ -129,7 +141,12 @@ class PriorEngine:
         c = L.EngineCfg()
         c.dtype, c.n_batch, c.width, c.n_state, c.n_head, c.n_mlp = self.code, self.N, self.W, self.S, self.H, self.M
         c.n_layers, c.seq_len, c.block_ctx, c.bins, c.ln_eps = self.depth, self.T, self.block_ctx, self.bins, 1e-5
-        c.x_emb, c.pos_emb, c.x_out_packed = self.x_emb.data_ptr(), self.pos_emb.data_ptr(), self.x_out.ptr
+        c.x_emb, c.pos_emb = self.x_emb.data_ptr(), self.pos_emb.data_ptr()
+        c.x_out_packed = self.x_out.ptr if self.x_out is not None else None
+        if self.encoder_kv is not None:
+            c.encoder_kv, c.enc_len = self.encoder_kv.data_ptr(), self.enc_len
+        if self.hidden is not None:
+            c.hidden_out, c.hidden_n_stride = self.hidden.data_ptr(), self.hidden.stride(0)
         c.start, c.start_stride = self.start.data_ptr(), self.start_stride
         if self.x_cond is not None:
             c.x_cond = self.x_cond.data_ptr()
@@ -165,6 +182,13 @@ class PriorEngine:
         except Exception:
             pass
 
+    def set_encoder_kv(self, encoder_kv):
+        """encoder_kv (N, enc_len, W): lyric-encoder states for the cross-attention layers; projects them through every
+        c_enc_kv into the layer caches (decode_qkv at sample_t == 0).  Call after set_cond."""
+        assert self.encoder_kv is not None and tuple(encoder_kv.shape) == tuple(self.encoder_kv.shape)
+        self.encoder_kv.copy_(encoder_kv.to(self.dtype))
+        L.check(L.lib().jb_engine_set_encoder_kv(self.handle, L.stream()))
+
     # -- the two hot loops ---------------------------------------------------------------------------------
     def prefill(self, t0, n_t):
         L.check(L.lib().jb_engine_prefill(self.handle, t0, n_t, L.stream()))
@@ -187,4 +211,4 @@ class PriorEngine:
 
     def weight_bytes(self):
         return sum(t.data.numel() * t.data.element_size() if isinstance(t, H.PackedWeight) else 0 for t in self._keep) \
-            + self.x_out.data.numel() * 4
+            + (self.x_out.data.numel() * 4 if self.x_out is not None else 0)

@@ -86,7 +86,11 @@ def make_prior(hps, vqvae, device="cuda"):
     if hps.use_tokens and not hps.single_enc_dec:
         prime_kwargs = dict(use_tokens=hps.use_tokens, prime_loss_fraction=hps.prime_loss_fraction, n_tokens=hps.n_tokens,
                             bins=hps.n_vocab, width=hps.prime_width, depth=hps.prime_depth, heads=hps.prime_heads,
-                            attn_order=hps.prime_attn_order, blocks=hps.prime_blocks, init_scale=hps.prime_init_scale)
+                            attn_order=hps.prime_attn_order, blocks=hps.prime_blocks, spread=hps.prime_spread,
+                            attn_dropout=hps.prime_attn_dropout, resid_dropout=hps.prime_resid_dropout,
+                            emb_dropout=hps.prime_emb_dropout, zero_out=hps.prime_zero_out, res_scale=hps.prime_res_scale,
+                            pos_init=hps.prime_pos_init, init_scale=hps.prime_init_scale, m_attn=hps.prime_m_attn,
+                            m_mlp=hps.prime_m_mlp, checkpoint_res=0, checkpoint_attn=0, checkpoint_mlp=0)
     else:
         prime_kwargs = dict(use_tokens=hps.use_tokens, prime_loss_fraction=hps.prime_loss_fraction, n_tokens=hps.n_tokens,
                             bins=hps.n_vocab)

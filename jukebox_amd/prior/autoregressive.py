@@ -94,6 +94,8 @@ class ConditionalAutoregressive2D(nn.Module):
             if self.x_emb.weight.device.type != "cuda":
                 raise RuntimeError("move the prior to the GPU before sampling (prior.cuda()); there is no CPU path")
             self._engines[key] = PriorEngine(sd, "", n_batch=n_samples, seq_len=self.input_dims, bins=self.bins,
+                                             encoder_dims=self.encoder_dims if 6 in self._funcs() else 0,
+                                             only_encode=self.only_encode,
                                              width=self.width, depth=self.depth, heads=self.heads,
                                              attn_order=self.attn_order, blocks=self.blocks, m_attn=self.m_attn,
                                              m_mlp=self.m_mlp, prime_len=self.prime_len, y_cond=self.y_cond,
@@ -101,6 +103,26 @@ class ConditionalAutoregressive2D(nn.Module):
                                              chunk_cap=chunk_cap, want_preds=want_preds,
                                              device=self.x_emb.weight.device)
         return self._engines[key]
+
+    def _funcs(self):
+        from ..engine import attn_funcs
+        return attn_funcs(self.attn_order, self.depth)
+
+    def forward(self, x, x_cond=None, y_cond=None, encoder_kv=None, fp16=False, **kw):
+        """Teacher-forced pass over a full sequence.  Only the `only_encode` use of the reference's forward is on the
+        sampling path (the lyric encoder of separated enc-dec priors, prior.py:285-292, autoregressive.py:114-157):
+        returns the final activations (N, T, width) fp32.  The training loss path is out of scope."""
+        assert self.only_encode, "the training forward (losses) is out of scope; use sample / primed_sample"
+        assert not self.x_cond and not self.y_cond and x_cond is None and y_cond is None and encoder_kv is None
+        with t.no_grad():
+            x = self.preprocess(x)
+            N, D = x.shape
+            assert D == self.input_dims and (0 <= x).all() and (x < self.bins).all()
+            eng = self.engine(N, fp16)
+            eng.set_cond(None, None)
+            eng.tokens[:, :D] = x
+            eng.prefill(0, D)
+            return eng.hidden[:, :D].clone()
 
     def _check_cond(self, N, x_cond, y_cond):
         D = self.input_dims
@@ -118,14 +140,18 @@ class ConditionalAutoregressive2D(nn.Module):
     def _run(self, n_samples, x_prime, x_cond, y_cond, encoder_kv, fp16, temp, top_k, top_p, get_preds, sample_tokens,
              seed=0, sample_base=0):
         assert self.training is False
-        assert encoder_kv is None, "separate lyric encoder (cross attention) is not on the HIP path yet"
         assert top_k == 0 or top_p == 0.0
+        has_cross = 6 in self._funcs()
+        assert (encoder_kv is not None) == has_cross, "encoder_kv is required exactly for cross-attention models"
         if sample_tokens is None:
             sample_tokens = self.input_dims
         self._check_cond(n_samples, x_cond, y_cond)
         eng = self.engine(n_samples, fp16, want_preds=get_preds)
         eng.set_cond(x_cond, y_cond)
         eng.set_sampling(temp=temp, top_k=top_k, top_p=top_p, seed=seed, sample_base=sample_base)
+        if has_cross:
+            assert tuple(encoder_kv.shape) == (n_samples, self.encoder_dims, self.width)
+            eng.set_encoder_kv(encoder_kv)
         n_prime = 0
         if x_prime is not None:
             x_prime = self.preprocess(x_prime)

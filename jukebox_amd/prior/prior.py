@@ -56,9 +56,21 @@ class SimplePrior(nn.Module):
                                                      prime_len=self.prime_loss_dims, **prior_kwargs)
         else:
             if self.n_tokens != 0 and self.use_tokens:
-                raise NotImplementedError("separate lyric encoder + cross attention (prior_5b_lyrics) is the next widening "
-                                          "step (SURVEY.md section 8f item 3); it has no HIP path yet")
-            self.prime_loss_dims = 0
+                # separate lyric encoder whose last-layer states are cross-attended by the decoder (prior.py:104-117)
+                from ..transformer.ops import Conv1D, LayerNorm
+                prime_input_shape = (self.n_tokens,)
+                self.prime_loss_dims = int(np.prod(prime_input_shape))
+                self.prime_acts_width, self.prime_state_width = prime_kwargs["width"], prior_kwargs["width"]
+                self.prime_prior = ConditionalAutoregressive2D(input_shape=prime_input_shape, x_cond=False, y_cond=False,
+                                                               only_encode=True, **prime_kwargs)
+                self.prime_state_proj = Conv1D(self.prime_acts_width, self.prime_state_width,
+                                               init_scale=prime_kwargs["init_scale"])
+                self.prime_state_ln = LayerNorm(self.prime_state_width)
+                self.prime_bins = prime_kwargs["bins"]
+                self.prime_x_out = nn.Linear(self.prime_state_width, self.prime_bins, bias=False)
+                nn.init.normal_(self.prime_x_out.weight, std=0.02 * prior_kwargs["init_scale"])
+            else:
+                self.prime_loss_dims = 0
             self.gen_loss_dims = int(np.prod(self.z_shape))
             self.total_loss_dims = self.prime_loss_dims + self.gen_loss_dims
             self.prior = ConditionalAutoregressive2D(x_cond=(self.x_cond or self.y_cond), y_cond=self.y_cond,
@@ -153,6 +165,20 @@ class SimplePrior(nn.Module):
         x_cond = self.x_emb(z_conds) if self.x_cond else y_pos
         return x_cond, y_cond, prime
 
+    def get_encoder_kv(self, prime, fp16=False, sample=False):
+        """prior.py:285-301: lyric tokens -> encoder activations -> projection -> LayerNorm (fp32), half when fp16."""
+        if self.n_tokens != 0 and self.use_tokens:
+            N = prime.shape[0]
+            prime_acts = self.prime_prior(prime, None, None, None, fp16=fp16)
+            assert tuple(prime_acts.shape) == (N, self.prime_loss_dims, self.prime_acts_width)
+            assert prime_acts.dtype == t.float
+            encoder_kv = self.prime_state_ln(self.prime_state_proj(prime_acts))
+            assert encoder_kv.dtype == t.float
+            if sample and fp16:
+                encoder_kv = encoder_kv.half()
+            return encoder_kv
+        return None
+
     def sample(self, n_samples, z=None, z_conds=None, y=None, fp16=False, temp=1.0, top_k=0, top_p=0.0, chunk_size=None,
                sample_tokens=None, seed=0, sample_base=0):
         """prior.py:245-283.  seed / sample_base (extensions): the random stream of global sample index
@@ -182,11 +208,13 @@ class SimplePrior(nn.Module):
                 z = self.prior.primed_sample(n_samples, z, x_cond, y_cond, chunk_size=chunk_size,
                                              sample_tokens=sample_tokens, **kw)
                 z = self.prior_postprocess(z)
-            elif no_past_context:
-                z = self.prior.sample(n_samples, x_cond, y_cond, None, sample_tokens=sample_tokens, **kw)
             else:
-                z = self.prior.primed_sample(n_samples, z, x_cond, y_cond, None, chunk_size=chunk_size,
-                                             sample_tokens=sample_tokens, **kw)
+                encoder_kv = self.get_encoder_kv(prime, fp16=fp16, sample=True)
+                if no_past_context:
+                    z = self.prior.sample(n_samples, x_cond, y_cond, encoder_kv, sample_tokens=sample_tokens, **kw)
+                else:
+                    z = self.prior.primed_sample(n_samples, z, x_cond, y_cond, encoder_kv, chunk_size=chunk_size,
+                                                 sample_tokens=sample_tokens, **kw)
             if sample_tokens is None:
                 assert tuple(z.shape) == (N, *self.z_shape)
         return z

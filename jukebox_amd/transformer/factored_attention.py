@@ -17,9 +17,13 @@ class FactoredAttention(nn.Module):
                  encoder_dims=None, prime_len=None):
         super().__init__()
         assert n_state % n_head == 0
-        assert attn_func in (0, 1, 2, 3, 7), f"attn_func {attn_func} has no HIP sampling path yet"
+        assert attn_func in (0, 1, 2, 3, 6, 7), f"attn_func {attn_func} has no HIP sampling path"
         self.n_in, self.n_ctx, self.n_state, self.n_head = n_in, n_ctx, n_state, n_head
-        self.c_attn = Conv1D(n_in, n_state * 3, init_scale=init_scale)
+        if attn_func == 6:           # cross attention to the lyric encoder (factored_attention.py:46-48)
+            self.c_attn = Conv1D(n_in, n_state, init_scale=init_scale)
+            self.c_enc_kv = Conv1D(n_in, n_state * 2, init_scale=init_scale)
+        else:
+            self.c_attn = Conv1D(n_in, n_state * 3, init_scale=init_scale)
         self.c_proj = Conv1D(n_state, n_in, zero_out, init_scale=init_scale)
         self.attn_func = attn_func
         self.blocks = blocks
@@ -40,6 +44,8 @@ class FactoredAttention(nn.Module):
         return (self.prime_len // self.blocks + 1) * self.blocks
 
     def _cap(self):
+        if self.attn_func == 6:
+            return self.encoder_dims
         return self._prime_len if self.attn_func == 7 else self.n_ctx
 
     def _suff_cache_len(self):
@@ -48,9 +54,19 @@ class FactoredAttention(nn.Module):
 
     def forward(self, x, encoder_kv=None, sample=False):
         assert sample, "only the sampling-mode forward is implemented on the HIP path"
-        assert encoder_kv is None
         N, ql, _ = x.shape
         S = self.n_state
+        if self.attn_func == 6:
+            # decode_qkv :273-287 -- k/v = c_enc_kv(encoder_kv) once at sample_t == 0, query from c_attn, no mask
+            assert encoder_kv is not None and encoder_kv.shape[1] == self.encoder_dims
+            if self.sample_t == 0:
+                kv = self.c_enc_kv(encoder_kv.to(x.dtype).contiguous())
+                self.cache = {"key": kv[..., :S].contiguous(), "value": kv[..., S:].contiguous()}
+            q = self.c_attn(x.contiguous())
+            a = H.attn_prefill(6, q.contiguous(), self.cache["key"], self.cache["value"], self.n_head, 0, self.sample_t)
+            self.sample_t += ql
+            return self.c_proj(a)
+        assert encoder_kv is None
         if "key" not in self.cache or self.cache["key"].shape[0] != N or self.cache["key"].dtype != x.dtype:
             self.cache = {"key": t.zeros((N, self._cap(), S), dtype=x.dtype, device=x.device),
                           "value": t.zeros((N, self._cap(), S), dtype=x.dtype, device=x.device)}

@@ -70,7 +70,7 @@ class Transformer(nn.Module):
         assert sample, "only the sampling-mode forward is implemented on the HIP path"
         x = x.half() if fp16 else x.float()
         for l in self._attn_mods:
-            x = l(x, encoder_kv=None, sample=True)
+            x = l(x, encoder_kv=encoder_kv if l.attn_func == 6 else None, sample=True)
         return x if fp16_out else x.float()
 
     def check_cache(self, n_samples, sample_t, fp16):

@@ -110,10 +110,17 @@ class SimplePrior:
                                                      x_cond=(self.x_cond or self.y_cond), y_cond=True,
                                                      prime_len=self.n_tokens, **common)
         else:
-            assert not (self.n_tokens != 0 and hps["use_tokens"]), "separate lyric encoder: SURVEY 8f item 3"
+            self.use_tokens = self.n_tokens != 0 and bool(hps["use_tokens"])
+            if self.use_tokens:                     # prior.py:104-117
+                self.prime_prior = ConditionalAutoregressive2D(
+                    sd, "prime_prior.", (self.n_tokens,), hps["n_vocab"], width=hps["prime_width"], depth=hps["prime_depth"],
+                    heads=hps["prime_heads"], attn_order=hps["prime_attn_order"], blocks=hps["prime_blocks"],
+                    m_attn=hps["prime_m_attn"], m_mlp=hps["prime_m_mlp"], res_scale=hps["prime_res_scale"],
+                    x_cond=False, y_cond=False, only_encode=True)
             self.prior = ConditionalAutoregressive2D(sd, "prior.", (self.n_ctx,), l_bins,
                                                      x_cond=(self.x_cond or self.y_cond), y_cond=self.y_cond,
-                                                     encoder_dims=0, merged_decoder=hps["merged_decoder"], **common)
+                                                     encoder_dims=self.n_tokens if self.use_tokens else 0,
+                                                     merged_decoder=hps["merged_decoder"], **common)
 
     def get_cond(self, z_conds, y):
         """prior.py:234-243."""
@@ -144,7 +151,19 @@ class SimplePrior:
             # prior_postprocess :187-203 -- drop lyric part, un-shift, clamp at 0
             out = out[:, self.n_tokens:] - self.prior_bins_shift[1]
             return np.clip(out, 0, None)
+        encoder_kv = self.get_encoder_kv(prime, fp16)
         if no_past:
-            return self.prior.sample(n_samples, x_cond, y_cond, None, sample_tokens=sample_tokens, **kw)
-        return self.prior.primed_sample(n_samples, z, x_cond, y_cond, None, chunk_size=chunk_size,
+            return self.prior.sample(n_samples, x_cond, y_cond, encoder_kv, sample_tokens=sample_tokens, **kw)
+        return self.prior.primed_sample(n_samples, z, x_cond, y_cond, encoder_kv, chunk_size=chunk_size,
                                         sample_tokens=sample_tokens, **kw)
+
+    def get_encoder_kv(self, prime, fp16=False):
+        """prior.py:285-301."""
+        if not getattr(self, "use_tokens", False):
+            return None
+        from .ops import conv1d, r16
+        acts = self.prime_prior.forward_logits(np.asarray(prime), None, None, fp16=fp16)
+        sd = self.sd
+        ekv = layer_norm(conv1d(acts, sd["prime_state_proj.w"], sd["prime_state_proj.b"]),
+                         sd["prime_state_ln.weight"], sd["prime_state_ln.bias"]).astype(F32)
+        return r16(ekv, fp16)

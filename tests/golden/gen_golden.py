@@ -141,7 +141,13 @@ TINY_UP0 = Hyperparams(level=0)
 TINY_UP0.update(TINY_UP)
 TINY_UP1 = Hyperparams(level=1, cond_res_scale=True)
 TINY_UP1.update(TINY_UP)
-HPARAMS_REGISTRY.update(tiny_vqvae=TINY_VQVAE, tiny_top=TINY_TOP, tiny_up0=TINY_UP0, tiny_up1=TINY_UP1)
+# separated encoder-decoder top prior (the prior_5b_lyrics structure: lyric encoder + cross-attention layers, merged_decoder)
+TINY_SEP = Hyperparams(level=2, n_ctx=48, prior_width=32, prior_depth=10, heads=2, attn_order=8, blocks=8, init_scale=1.0,
+                       labels=True, labels_v3=True, use_tokens=True, n_tokens=16, n_vocab=79, single_enc_dec=False,
+                       merged_decoder=True, prime_loss_fraction=0.4, prime_width=16, prime_depth=3, prime_heads=2,
+                       prime_attn_order=2, prime_blocks=4, prime_init_scale=1.0)
+TINY_SEP.update(TINY_LABELS)
+HPARAMS_REGISTRY.update(tiny_vqvae=TINY_VQVAE, tiny_top=TINY_TOP, tiny_up0=TINY_UP0, tiny_up1=TINY_UP1, tiny_sep=TINY_SEP)
 
 
 def build_tiny():
@@ -178,7 +184,7 @@ def make_labels(prior, n, seed):
 def gen_vqvae_and_priors():
     vq, priors = build_tiny()
     hps_dump = {}
-    for nm in ["tiny_vqvae", "tiny_up0", "tiny_up1", "tiny_top"]:
+    for nm in ["tiny_vqvae", "tiny_up0", "tiny_up1", "tiny_top", "tiny_sep"]:
         kw = dict(restore_vqvae="") if nm == "tiny_vqvae" else dict(restore_prior="")
         H = setup_hparams(nm, kw)
         hps_dump[nm] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in H.items()}
@@ -241,6 +247,29 @@ def gen_vqvae_and_priors():
         out.update({f"{nm}.z_cond": zc.numpy(), f"{nm}.y": y.numpy(), f"{nm}.x_cond": x_cond.numpy(),
                     f"{nm}.y_cond": y_cond.numpy(), f"{nm}.z": z.numpy(), f"{nm}.z_primed": zp.numpy()})
     save("priors", **out)
+
+    # ---- separated encoder-decoder prior: lyric encoder -> encoder_kv -> cross-attention decoder ----
+    t.manual_seed(14)
+    sep = make_prior(setup_hparams("tiny_sep", dict(restore_prior="")), vq, "cpu")
+    # cross-attention c_proj is zero-initialised (transformer.py:131): randomise so the path is exercised
+    for l in sep.prior.transformer._attn_mods:
+        if l.attn_func == 6:
+            t.nn.init.normal_(l.attn.c_proj.w, std=0.02)
+            t.nn.init.normal_(l.mlp.c_proj.w, std=0.02)
+    lab = make_labels(sep, n, 77)
+    so = npd(sep.state_dict(), "sd.")
+    so["labels_y"] = lab["y"].numpy()
+    for j, info in enumerate(lab["info"]):
+        so[f"full_tokens{j}"] = np.array(info["full_tokens"], dtype=np.int64)
+    y = sep.get_y(lab, 0)
+    x_cond, y_cond, prime = sep.get_cond(None, y)
+    ekv = sep.get_encoder_kv(prime, fp16=False, sample=True)
+    z_raw, preds = sep.prior.sample(n, x_cond, y_cond, ekv, top_k=1, get_preds=True)
+    z_a = sep.sample(n, z=t.zeros(n, 0, dtype=t.long), y=y, top_k=1)
+    z_p = sep.sample(n, z=z_a[:, :20].contiguous(), y=y, top_k=1, chunk_size=6)
+    so.update({"y0": y.numpy(), "encoder_kv": ekv.numpy(), "x_cond": x_cond.numpy(), "y_cond": y_cond.numpy(),
+               "preds": preds.numpy(), "z_raw": z_raw.numpy(), "z_ancestral": z_a.numpy(), "z_primed": z_p.numpy()})
+    save("prior_sep", **so)
 
     # ---- end-to-end 3-level ancestral (window loop of sample.py, greedy) ----
     hps = Hyperparams(n_samples=n, sample_length=4608, hop_fraction=[0.5, 0.5, 0.125], sr=22050, name="unused")

@@ -39,6 +39,15 @@ def test_state_dicts_load_strict(tiny_hps):
               if not k.startswith(("labels_y", "full_tokens"))}
         assert set(sd) == set(p.state_dict()), set(sd) ^ set(p.state_dict())
         p.load_state_dict(sd, strict=True)
+    # separated encoder-decoder structure (prior_5b_lyrics): prime_prior.*, prime_state_proj/ln, prime_x_out, c_enc_kv
+    from jukebox_amd.make_models import make_prior
+    h = Hyperparams(tiny_hps["tiny_sep"])
+    h.y_bins = tuple(h.y_bins)
+    sep = make_prior(h, vq, "cpu")
+    gs = load_golden("prior_sep")
+    sd = {k: torch.from_numpy(v) for k, v in sub_state(gs, "sd.").items()}
+    assert set(sd) == set(sep.state_dict()), set(sd) ^ set(sep.state_dict())
+    sep.load_state_dict(sd, strict=True)
     top = priors[2]
     assert top.n_ctx == 48 and top.raw_to_tokens == 64 and top.prior.input_dims == 64 and top.prior.bins == 79 + 64
     assert priors[0].cond_downsample == 4 and priors[0].raw_to_tokens == 4

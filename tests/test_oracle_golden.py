@@ -209,3 +209,27 @@ def test_alignment_matches_reference(tiny_hps):
     for j in range(3):
         assert al[j].shape == e[f"alignment{j}"].shape
         assert np.abs(al[j] - e[f"alignment{j}"]).max() < 1e-6
+
+
+def _sep_prior(tiny_hps):
+    g = load_golden("prior_sep")
+    vq = tiny_hps["tiny_vqvae"]
+    hops = np.cumprod([s ** d for s, d in zip(vq["strides_t"], vq["downs_t"])])
+    vq_shapes = [vq["sample_length"] // h for h in hops]
+    hps = tiny_hps["tiny_sep"]
+    z_shapes = [(zs * hps["n_ctx"] // vq_shapes[hps["level"]],) for zs in vq_shapes]
+    return g, SimplePrior(sub_state(g, "sd."), hps, z_shapes, vq["l_bins"], vq["downs_t"], vq["strides_t"])
+
+
+def test_separated_encoder_decoder_prior(tiny_hps):
+    """prior_5b_lyrics structure: lyric encoder (only_encode) -> prime_state_proj + LN -> cross-attention layers (func 6),
+    merged_decoder (no cond add after the transformer, untied x_out)."""
+    g, sep = _sep_prior(tiny_hps)
+    x_cond, y_cond, prime = sep.get_cond(None, g["y0"])
+    ekv = sep.get_encoder_kv(prime)
+    assert np.abs(ekv - g["encoder_kv"]).max() < 2e-5
+    z, preds = sep.prior.sample(3, x_cond, y_cond, ekv, top_k=1, get_preds=True)
+    assert np.abs(preds - g["preds"]).max() < 5e-5
+    assert np.array_equal(z, g["z_raw"])
+    assert np.array_equal(sep.sample(3, z=np.zeros((3, 0), np.int64), y=g["y0"], top_k=1), g["z_ancestral"])
+    assert np.array_equal(sep.sample(3, z=g["z_ancestral"][:, :20], y=g["y0"], top_k=1, chunk_size=6), g["z_primed"])

@@ -11,6 +11,8 @@ from jukebox_amd.engine import PriorEngine, attn_funcs
 CFGS = {
     "1b": dict(seq_len=6528, bins=2127, width=2048, depth=72, heads=2, attn_order=12, blocks=64, prime_len=384, y_cond=True),
     "up": dict(seq_len=8192, bins=2048, width=1920, depth=72, heads=1, attn_order=2, blocks=128, y_cond=True),
+    "5b": dict(seq_len=8192, bins=2048, width=4800, depth=79, heads=8, attn_order=10, blocks=128, y_cond=True,
+               encoder_dims=512, add_cond_after=False),
     "small": dict(seq_len=8192, bins=1024, width=1024, depth=48, heads=1, attn_order=2, blocks=64, y_cond=False),
 }
 
@@ -22,9 +24,14 @@ def random_state(cfg, dev, scale=0.02):
     r = lambda *s, sc=scale: torch.randn(*s, device=dev, generator=g) * sc
     sd = {"x_emb.weight": r(B, W), "pos_emb.pos_emb": r(T, W, sc=0.01), "start_token": r(1, W, sc=0.01)}
     sd["x_out.weight"] = sd["x_emb.weight"]
+    funcs = attn_funcs(cfg["attn_order"], D)
     for d in range(D):
         p = f"transformer._attn_mods.{d}."
-        sd[p + "attn.c_attn.w"], sd[p + "attn.c_attn.b"] = r(W, 3 * S), torch.zeros(3 * S, device=dev)
+        if funcs[d] == 6:
+            sd[p + "attn.c_attn.w"], sd[p + "attn.c_attn.b"] = r(W, S), torch.zeros(S, device=dev)
+            sd[p + "attn.c_enc_kv.w"], sd[p + "attn.c_enc_kv.b"] = r(W, 2 * S), torch.zeros(2 * S, device=dev)
+        else:
+            sd[p + "attn.c_attn.w"], sd[p + "attn.c_attn.b"] = r(W, 3 * S), torch.zeros(3 * S, device=dev)
         sd[p + "attn.c_proj.w"], sd[p + "attn.c_proj.b"] = r(S, W), torch.zeros(W, device=dev)
         sd[p + "mlp.c_fc.w"], sd[p + "mlp.c_fc.b"] = r(W, W), torch.zeros(W, device=dev)
         sd[p + "mlp.c_proj.w"], sd[p + "mlp.c_proj.b"] = r(W, W), torch.zeros(W, device=dev)
@@ -43,7 +50,7 @@ def step_bytes(cfg, N, t, esz):
     kv = 0
     for f in attn_funcs(cfg["attn_order"], D):
         ln = {0: t + 1, 1: t % bc + 1 if bc else 0, 2: t // bc + 1 if bc else 0, 3: bc if bc and t >= bc else 0,
-              7: min(t + 1, pl)}[f]
+              7: min(t + 1, pl), 6: cfg.get("encoder_dims", 0)}[f]
         kv += ln * S * 2 * esz * N + S * 2 * esz * N
     return D * per_layer_w + kv + B * W * 4
 
@@ -65,6 +72,8 @@ def main():
     xc = torch.randn(a.batch, cfg["seq_len"], cfg["width"], device=dev) * 0.01
     eng.set_cond(xc, y)
     eng.set_sampling(temp=0.99, seed=1)
+    if cfg.get("encoder_dims"):
+        eng.set_encoder_kv(torch.randn(a.batch, cfg["encoder_dims"], cfg["width"], device=dev) * 0.1)
     del sd
     torch.cuda.synchronize()
     print(f"model={a.model} N={a.batch} dtype={'f32' if a.fp32 else 'f16'} weights={eng.weight_bytes() / 1e9:.2f} GB "
