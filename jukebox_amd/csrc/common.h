@@ -130,15 +130,28 @@ template <typename T> __device__ __forceinline__ float jb_apply_act(float v, int
     return v;
 }
 
+// Wave-wide (64-lane) reductions without the LDS crossbar: four DPP steps reduce each 16-lane row in the VALU
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row results are read with
+// v_readlane and combined.  A __shfl_xor butterfly is six dependent ds_bpermute round trips (~100+ cycles each).
+template <int CTRL> __device__ __forceinline__ float jb_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float jb_readlane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float jb_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += jb_dpp<0xB1>(v);
+    v += jb_dpp<0x4E>(v);
+    v += jb_dpp<0x141>(v);
+    v += jb_dpp<0x140>(v);
+    return (jb_readlane(v, 0) + jb_readlane(v, 16)) + (jb_readlane(v, 32) + jb_readlane(v, 48));
 }
 __device__ __forceinline__ float jb_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, jb_dpp<0xB1>(v));
+    v = fmaxf(v, jb_dpp<0x4E>(v));
+    v = fmaxf(v, jb_dpp<0x141>(v));
+    v = fmaxf(v, jb_dpp<0x140>(v));
+    return fmaxf(fmaxf(jb_readlane(v, 0), jb_readlane(v, 16)), fmaxf(jb_readlane(v, 32), jb_readlane(v, 48)));
 }
 
 __device__ __forceinline__ float jb_load_any(const void* p, int dtype, int64_t i) {

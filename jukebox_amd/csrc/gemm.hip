@@ -124,6 +124,23 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& p, f32x4 acc, in
     }
 }
 
+// One output element (decode GEMV epilogue, spread over all threads of the workgroup).
+template <typename T>
+__device__ __forceinline__ void epilogue_store1(const EpiParams& p, float x, int64_t orow, int j, int64_t cache_row,
+                                                float bias_v, float res_v) {
+    if (p.bias) x += jb_round<T>(bias_v);
+    x = jb_round<T>(x);
+    x = jb_apply_act<T>(x, p.act);
+    if (p.res) x = (p.res_scale == 1.0f) ? jb_round<T>(res_v + x) : jb_round<T>(res_v + jb_round<T>(p.res_scale * x));
+    if (!p.qkv_split) {
+        ((T*)p.out)[orow * p.ldo + j] = (T)x;
+    } else {
+        const int part = j / p.S, jj = j - part * p.S;
+        if (part == 0) ((T*)p.out)[orow * p.ldo + jj] = (T)x;
+        else if (cache_row >= 0) ((T*)(part == 1 ? p.kcache : p.vcache))[cache_row * p.S + jj] = (T)x;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct GemmParams {
     const void* A; int64_t lda;
@@ -332,45 +349,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
             if (kt0 + i < kt1) wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)(kt0 + i) * (64 * E)));
         }
     }
+    // Epilogue operands of THIS thread's output elements (the MT 16x16 tiles are spread over all threads: flat index
+    // i = (mt, r, l) is element r of fragment lane l of tile mt), requested now so they are long home when the sums
+    // are ready.
+    constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);      // elements per thread
     int t = 0;
-    float rpre[MT][4], bpre[4];
-    const int jb = jt * 16 + g * 4;
-    if (FAST || wave == 0) {
-        if (p.epi.qkv_split) t = *p.t_dev;
-        if (FAST) {   // J % 4 == 0, aligned: one vector load each, clamped rows, no per-element branches
-            const int jc = min(jb, p.epi.J - 4);
-            if (p.epi.bias) {
-                f32x4 b4 = *reinterpret_cast<const f32x4*>(p.epi.bias + jc);
+    if (p.epi.qkv_split) t = *p.t_dev;
+    float e_bias[EPT], e_res[EPT];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bpre[r] = b4[r];
-            }
-            if (p.epi.res) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const T* rp = (const T*)p.epi.res + (int64_t)min(mt * 16 + c, p.n_rows - 1) * p.epi.ldr + jc;
-                    if constexpr (sizeof(T) == 2) {
-                        f16x4 r4 = *reinterpret_cast<const f16x4*>(rp);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rpre[mt][r] = (float)r4[r];
-                    } else {
-                        f32x4 r4 = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rpre[mt][r] = r4[r];
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bpre[r] = (p.epi.bias && jb + r < p.epi.J) ? p.epi.bias[jb + r] : 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int row = mt * 16 + c;
-                    rpre[mt][r] = (p.epi.res && row < p.n_rows && jb + r < p.epi.J)
-                                      ? (float)((const T*)p.epi.res)[(int64_t)row * p.epi.ldr + jb + r] : 0.f;
-                }
-        }
+    for (int u = 0; u < EPT; ++u) {
+        const int i = threadIdx.x + u * NW * 64;
+        const int row = (i >> 8) * 16 + (i & 15), j = jt * 16 + ((i & 63) >> 4) * 4 + ((i >> 6) & 3);
+        const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
+        e_bias[u] = p.epi.bias ? p.epi.bias[jc] : 0.f;
+        e_res[u] = p.epi.res ? (float)((const T*)p.epi.res)[(int64_t)rc * p.epi.ldr + jc] : 0.f;
     }
 
     // Cross-kernel prefetch: one dword per 128-byte line of the NEXT projection's weight image.  HBM is ~7 % busy in
@@ -418,12 +410,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
                 for (int i = 0; i < NV; ++i) sm[j] += (lane + 64 * i < nvec) ? frag_sum<T>(xv[j][i]) : 0.f;
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int j = 0; j < RW; ++j) sm[j] += __shfl_xor(sm[j], o, 64);
-#pragma unroll
             for (int j = 0; j < RW; ++j) {
-                mean[j] = sm[j] / (float)p.K;
+                mean[j] = jb_wave_sum(sm[j]) / (float)p.K;
                 sq[j] = 0.f;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
@@ -434,12 +422,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
                 }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int j = 0; j < RW; ++j) sq[j] += __shfl_xor(sq[j], o, 64);
-#pragma unroll
             for (int j = 0; j < RW; ++j) {
-                rstd[j] = 1.0f / sqrtf(sq[j] / (float)p.K + p.ln_eps);
+                rstd[j] = 1.0f / sqrtf(jb_wave_sum(sq[j]) / (float)p.K + p.ln_eps);
                 const int r = rb + j * NW;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
@@ -598,17 +582,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     __syncthreads();
     JB_STAMP(6);
     asm volatile("" ::"v"(pf_sum));
-    if (wave != 0) return;
-
+    {
+        const float* sa = reinterpret_cast<const float*>(s_acc);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int row = mt * 16 + c;
-        if (row >= p.n_rows) continue;
-        f32x4 v = s_acc[mt * 64 + lane];
+        for (int u = 0; u < EPT; ++u) {
+            const int i = threadIdx.x + u * NW * 64;
+            const int mt = i >> 8, r = (i >> 6) & 3, l = i & 63;
+            const int row = mt * 16 + (l & 15), j = jt * 16 + (l >> 4) * 4 + r;
+            if (i >= MT * 256 || row >= p.n_rows || j >= p.epi.J) continue;
+            float v = 0.f;
 #pragma unroll
-        for (int w = 1; w < NW; ++w) v += s_acc[(w * MT + mt) * 64 + lane];
-        int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
-        if (jb < p.epi.J) epilogue_store<T>(p.epi, v, row, jb, cache_row, bpre, rpre[mt]);
+            for (int w = 0; w < NW; ++w) v += sa[((w * MT + mt) * 64 + l) * 4 + r];
+            const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
+            epilogue_store1<T>(p.epi, v, row, j, cache_row, e_bias[u], e_res[u]);
+        }
     }
     JB_STAMP(7);
 }
