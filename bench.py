@@ -213,7 +213,7 @@ def main():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else device)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     assert all(int(z.shape[1]) == sample_length // p.raw_to_tokens for z, p in zip(zs, priors))

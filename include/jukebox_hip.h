@@ -30,6 +30,12 @@ typedef enum {
 const char* jb_last_error(void);
 int jb_version(void);
 
+/* HIP streams in explicit priority classes (numerically lower = higher priority; the range is device dependent).
+ * Used by the level pipeline: streams of different classes land on different hardware queues and really overlap. */
+int jb_stream_priority_range(int* least /* host */, int* greatest /* host */);
+int jb_stream_create(int priority, void** stream /* host, out */);
+int jb_stream_destroy(void* stream);
+
 /* Bytes of the MFMA-fragment-ordered weight image for a K x J matrix of `dtype`
  * (K padded to 32 (f16) / 16 (f32), J padded to 16). */
 int64_t jb_packed_weight_bytes(int K, int J, int dtype);

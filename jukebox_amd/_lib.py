@@ -60,6 +60,9 @@ class EngineCfg(C.Structure):
 _SIGS = {
     "jb_last_error": (C.c_char_p, []),
     "jb_version": (i32, []),
+    "jb_stream_priority_range": (i32, [C.POINTER(i32), C.POINTER(i32)]),
+    "jb_stream_create": (i32, [i32, C.POINTER(vp)]),
+    "jb_stream_destroy": (i32, [vp]),
     "jb_packed_weight_bytes": (i64, [i32, i32, i32]),
     "jb_pack_weight": (i32, [vp, i32, i64, i64, i32, i32, vp, i32, vp]),
     "jb_layernorm_fwd": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, f32, vp]),
@@ -130,3 +133,23 @@ def ptr(t):
 def stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def priority_streams(classes, device=None):
+    """torch-visible raw HIP streams, one per entry of `classes` (HIP priority values, clamped to the device range;
+    numerically lower = higher priority).  Returns (streams, raw_handles); destroy with destroy_streams."""
+    import torch
+    least, greatest = i32(), i32()
+    check(lib().jb_stream_priority_range(C.byref(least), C.byref(greatest)))
+    streams, raw = [], []
+    for c in classes:
+        h = vp()
+        check(lib().jb_stream_create(max(greatest.value, min(least.value, c)), C.byref(h)))
+        raw.append(h)
+        streams.append(torch.cuda.ExternalStream(h.value, device=device))
+    return streams, raw
+
+
+def destroy_streams(raw):
+    for h in raw:
+        lib().jb_stream_destroy(h)

@@ -97,11 +97,18 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     errors = []
     levels = sorted(sample_levels, reverse=True)
     current = torch_cuda_current_stream(device)
+    # One stream per level.  Measured on MI355X / ROCm 7.2 (tools/bench_concurrent.py): two normal-priority streams can
+    # land on one hardware queue and serialise completely, whereas torch's pooled high-priority streams plus one
+    # normal-priority stream ran three decode chains concurrently at 1.3x the single-chain step time.  The two
+    # upsampler levels (the long poles) therefore get high priority, the top level normal priority.
+    order = sorted(levels)                                 # lowest level first
+    prios = [-1, -1, 0, 0]
+    stream_of = {level: t.cuda.Stream(device=device, priority=prios[min(i, 3)]) for i, level in enumerate(order)}
 
     def worker(level):
         try:
             prior = priors[level]
-            stream = t.cuda.Stream(device=device)
+            stream = stream_of[level]
             stream.wait_stream(current)
             with t.cuda.stream(stream):
                 total_length = hps.sample_length // prior.raw_to_tokens
@@ -144,6 +151,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         th.start()
     for th in threads:
         th.join()
+    t.cuda.synchronize(device)
     if errors:
         raise errors[0]
     return zs_local

@@ -35,8 +35,8 @@ def setup_dist_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), init_method="env://", rank=rank,
-                                world_size=world)
+        backend = backend or os.environ.get("JB_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend, init_method="env://", rank=rank, world_size=world)
     return rank, local_rank, device
 
 
@@ -50,6 +50,11 @@ def shard_range(n_samples, rank=None, world=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _host_staged():
+    """gloo cannot move GPU tensors: stage through the host (tests on a single-GPU box; RCCL moves them directly)."""
+    return dist.get_backend() == "gloo"
+
+
 def broadcast_tensor(x, src=0):
     """Broadcast a tensor whose shape/dtype the other ranks may not know yet (rank `src` passes the tensor, the
     others pass None).  Used for labels `y` and primed codes `zs`."""
@@ -58,7 +63,7 @@ def broadcast_tensor(x, src=0):
     rank = dist_adapter.get_rank()
     dev = x.device if x is not None else (torch.device("cuda", torch.cuda.current_device())
                                           if torch.cuda.is_available() else torch.device("cpu"))
-    meta = torch.zeros(8, dtype=torch.int64, device=dev)
+    meta = torch.zeros(8, dtype=torch.int64, device="cpu" if _host_staged() else dev)
     if rank == src:
         assert x.dtype in (torch.int64, torch.float32)
         meta[0], meta[1] = x.dim(), 0 if x.dtype == torch.int64 else 1
@@ -69,6 +74,10 @@ def broadcast_tensor(x, src=0):
     if rank != src:
         x = torch.empty(shape, dtype=torch.int64 if code == 0 else torch.float32, device=dev)
     x = x.contiguous()
+    if _host_staged() and x.is_cuda:
+        h = x.cpu()
+        dist.broadcast(h, src)
+        return h.to(x.device)
     dist.broadcast(x, src)
     return x
 
@@ -81,8 +90,10 @@ def gather_shards(x_local, n_samples):
         return x_local
     sizes = [shard_range(n_samples, r, world) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((mx, *x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+    dev = x_local.device
+    staged = _host_staged() and x_local.is_cuda
+    pad = torch.zeros((mx, *x_local.shape[1:]), dtype=x_local.dtype, device="cpu" if staged else dev)
     pad[: x_local.shape[0]] = x_local
     outs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad)
-    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], dim=0)
+    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], dim=0).to(dev)
