@@ -12,8 +12,6 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define JB_WAVE 64
-
 // ---- host-side error plumbing --------------------------------------------------------------
 void jb_set_error(const std::string& msg);
 #define JB_REQUIRE(cond, msg)                                              \
@@ -44,8 +42,6 @@ void jb_set_error(const std::string& msg);
             return JB_ERR_HIP;                                             \
         }                                                                  \
     } while (0)
-
-static inline int jb_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- per-dtype MFMA fragment description ---------------------------------------------------
 // One MFMA "k-tile" holds KT contraction elements; lane l owns E consecutive ones starting at
@@ -114,8 +110,6 @@ __device__ __forceinline__ typename Frag<T>::vec keep_frag(bool keep, typename F
 template <typename T> __device__ __forceinline__ float jb_round(float x);
 template <> __device__ __forceinline__ float jb_round<float>(float x) { return x; }
 template <> __device__ __forceinline__ float jb_round<f16>(float x) { return (float)(f16)x; }
-
-__device__ __forceinline__ float jb_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // quick_gelu (jukebox/transformer/ops.py:33-35): x * sigmoid(1.702 x); each op rounds in half mode.
 template <typename T> __device__ __forceinline__ float jb_quick_gelu(float x) {

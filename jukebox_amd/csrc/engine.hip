@@ -16,13 +16,10 @@ struct JbEngine {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t capture_stream = nullptr;   // the legacy default stream cannot be captured: record on a private one
-    int launches_per_step = 0;
 };
 
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 __global__ void inc_int_kernel(int* p) { *p += 1; }
-
-static size_t esize(int dtype) { return dtype == JB_F16 ? 2 : 4; }
 
 extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers, void** handle) {
     JB_REQUIRE(cfg && layers && handle, "null pointer");
@@ -82,10 +79,8 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
     JB_TRY(jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
                     c.xc_n_stride, c.xc_t_stride, N, W, 0, c.t_dev, 1, s));
     const bool pf = c.prefetch_next_weights != 0;
-    const int64_t esz = c.dtype == JB_F16 ? 2 : 4;
     const int64_t by_attn = jb_packed_weight_bytes(W, 3 * S, c.dtype), by_proj = jb_packed_weight_bytes(S, W, c.dtype);
     const int64_t by_fc = jb_packed_weight_bytes(W, M, c.dtype), by_proj2 = jb_packed_weight_bytes(M, W, c.dtype);
-    (void)esz;
     for (int l = 0; l < c.n_layers; ++l) {
         const jb_layer& L = e->layers[l];
         jb_gemv_args g = {};
