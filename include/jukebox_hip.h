@@ -99,8 +99,17 @@ typedef struct jb_gemv_args {
     int qkv_split, S;
     void* kcache; void* vcache; int cache_cap; const int* t_dev;
     const void* prefetch; int64_t prefetch_bytes;   /* optional: memory the NEXT launch will stream (touched early, values unused) */
+    /* Folded LayerNorm (ln_gamma == ln_beta == NULL, ln_fold_c1 != NULL): LN(x)·W + b is evaluated as
+     *     rstd[n] * (x[n]·W' - mean[n] * c1[j]) + b'[j],   W' = diag(gamma)·W,  c1 = column sums of W' as stored,
+     *     b' = beta·W + b,
+     * so the projection multiplies the RAW rows (no normalised copy is staged) and the fp32 row statistics are formed
+     * from the same operand fragments while the weight stream is in flight.  The caller passes W = packed W',
+     * bias = b', ln_fold_c1 = c1 (J floats).  Only where jb_gemv_ln_fold_supported() says so. */
+    const float* ln_fold_c1;
 } jb_gemv_args;
 int jb_gemv(const jb_gemv_args* args /* host */, void* stream);
+/* 1 if jb_gemv accepts ln_fold_c1 for this problem (whole k-tiles, the rows' operand fragments fit in registers). */
+int jb_gemv_ln_fold_supported(int dtype, int K, int J, int n_rows);
 
 /* Single-query cached attention for the decode step: one workgroup per (sample, head); the key
  * set is derived on the device from *t_dev and the pattern, softmax in fp32.
@@ -177,6 +186,10 @@ typedef struct jb_layer {
      * c_enc_kv is given as its key and value halves, each n_in x n_state, with the (2*n_state) bias; the caches hold
      * the projected encoder states, cache_cap = encoder length. */
     const void *w_enc_k, *w_enc_v; const float* b_enc_kv;
+    /* optional folded-LayerNorm images of c_attn and c_fc for the decode step (see jb_gemv_args.ln_fold_c1): packed
+     * diag(gamma)·W, beta·W + b, column sums.  NULL = the decode step normalises rows in the projection kernel.
+     * Prefill always uses w_attn / w_fc with an explicit LayerNorm. */
+    const void *w_attn_f, *w_fc_f; const float *b_attn_f, *b_fc_f, *c1_attn, *c1_fc;
 } jb_layer;
 
 typedef struct jb_engine_cfg {

@@ -30,7 +30,8 @@ class GemvArgs(C.Structure):
                 ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
                 ("W", vp), ("bias", vp), ("K", i32), ("J", i32), ("out", vp), ("ldo", i64),
                 ("res", vp), ("ldr", i64), ("act", i32), ("qkv_split", i32), ("S", i32),
-                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp), ("prefetch", vp), ("prefetch_bytes", i64)]
+                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp), ("prefetch", vp), ("prefetch_bytes", i64),
+                ("ln_fold_c1", vp)]
 
 
 class SampleParams(C.Structure):
@@ -41,7 +42,8 @@ class Layer(C.Structure):
     _fields_ = [("attn_func", i32), ("w_attn", vp), ("w_proj", vp), ("w_fc", vp), ("w_proj2", vp),
                 ("b_attn", vp), ("b_proj", vp), ("b_fc", vp), ("b_proj2", vp),
                 ("ln0_g", vp), ("ln0_b", vp), ("ln1_g", vp), ("ln1_b", vp),
-                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("w_enc_k", vp), ("w_enc_v", vp), ("b_enc_kv", vp)]
+                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("w_enc_k", vp), ("w_enc_v", vp), ("b_enc_kv", vp),
+                ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp)]
 
 
 class EngineCfg(C.Structure):
@@ -68,6 +70,7 @@ _SIGS = {
     "jb_layernorm_fwd": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, f32, vp]),
     "jb_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "jb_gemv": (i32, [C.POINTER(GemvArgs), vp]),
+    "jb_gemv_ln_fold_supported": (i32, [i32, i32, i32, i32]),
     "jb_attn_decode": (i32, [i32, i32, vp, i64, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "jb_tune_attn_decode": (None, [i32, i32]),
     "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -41,6 +41,15 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
         JB_REQUIRE(L.w_attn && L.w_proj && L.w_fc && L.w_proj2 && L.b_attn && L.b_proj && L.b_fc && L.b_proj2 &&
                        L.ln0_g && L.ln0_b && L.ln1_g && L.ln1_b && L.kcache && L.vcache && L.cache_cap > 0,
                    "incomplete layer descriptor");
+        const int j_attn = L.attn_func == 6 ? cfg->n_state : 3 * cfg->n_state;
+        JB_REQUIRE((!L.w_attn_f && !L.b_attn_f && !L.c1_attn) ||
+                       (L.w_attn_f && L.b_attn_f && L.c1_attn &&
+                        jb_gemv_ln_fold_supported(cfg->dtype, cfg->width, j_attn, cfg->n_batch)),
+                   "folded LayerNorm image of c_attn is incomplete or unsupported for this shape");
+        JB_REQUIRE((!L.w_fc_f && !L.b_fc_f && !L.c1_fc) ||
+                       (L.w_fc_f && L.b_fc_f && L.c1_fc &&
+                        jb_gemv_ln_fold_supported(cfg->dtype, cfg->width, cfg->n_mlp, cfg->n_batch)),
+                   "folded LayerNorm image of mlp.c_fc is incomplete or unsupported for this shape");
     }
     JB_REQUIRE(!cfg->rec_out || (cfg->rec_layer >= 0 && cfg->rec_layer < cfg->n_layers && cfg->rec_keys > 0 &&
                                  cfg->rec_head >= 0 && cfg->rec_head < cfg->n_head), "bad attention recording request");
@@ -72,6 +81,19 @@ extern "C" int jb_engine_launches_per_step(void* handle) {
         if (rc__ != JB_OK) return rc__; \
     } while (0)
 
+// LayerNorm + projection of the decode step (which = 0: ln_0 + attn.c_attn, 1: ln_1 + mlp.c_fc): the folded image when the
+// layer carries one (jb_gemv_args.ln_fold_c1), else gamma / beta for the in-kernel normalisation.
+static void fill_ln_proj(jb_gemv_args& g, const jb_engine_cfg& c, const jb_layer& L, int which) {
+    g.dtype = c.dtype; g.n_rows = c.n_batch; g.ldx = c.width; g.K = c.width; g.ln_eps = c.ln_eps;
+    const void* wf = which == 0 ? L.w_attn_f : L.w_fc_f;
+    if (wf) {
+        g.W = wf; g.bias = which == 0 ? L.b_attn_f : L.b_fc_f; g.ln_fold_c1 = which == 0 ? L.c1_attn : L.c1_fc;
+    } else {
+        g.W = which == 0 ? L.w_attn : L.w_fc; g.bias = which == 0 ? L.b_attn : L.b_fc;
+        g.ln_gamma = which == 0 ? L.ln0_g : L.ln1_g; g.ln_beta = which == 0 ? L.ln0_b : L.ln1_b;
+    }
+}
+
 // One decode step at position *t_dev; everything position-dependent is read on the device.
 static int enqueue_step(JbEngine* e, hipStream_t s) {
     const jb_engine_cfg& c = e->cfg;
@@ -84,11 +106,10 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
     for (int l = 0; l < c.n_layers; ++l) {
         const jb_layer& L = e->layers[l];
         jb_gemv_args g = {};
-        g.dtype = c.dtype;
         if (pf) { g.prefetch = L.w_proj; g.prefetch_bytes = by_proj; }
         // a7/a8/a9: ln_0 + c_attn, k/v appended at *t_dev
-        g.x = c.x_a; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln0_g; g.ln_beta = L.ln0_b; g.ln_eps = c.ln_eps;
-        g.W = L.w_attn; g.bias = L.b_attn; g.K = W; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
+        fill_ln_proj(g, c, L, 0);
+        g.x = c.x_a; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
         if (L.attn_func == JB_ATTN_CROSS) {
             g.J = S;                         // query only; k/v come from the encoder (set_encoder_kv)
         } else {
@@ -106,8 +127,8 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
         JB_TRY(jb_gemv(&g, s));
         // ln_1 + mlp.c_fc + quick_gelu
         g = {};
-        g.dtype = c.dtype; g.x = c.x_b; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln1_g; g.ln_beta = L.ln1_b; g.ln_eps = c.ln_eps;
-        g.W = L.w_fc; g.bias = L.b_fc; g.K = W; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
+        fill_ln_proj(g, c, L, 1);
+        g.x = c.x_b; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
         if (pf) { g.prefetch = L.w_proj2; g.prefetch_bytes = by_proj2; }
         JB_TRY(jb_gemv(&g, s));
         // mlp.c_proj + residual: x_a = x_b + m   (h = x + a + m, transformer.py:82-83)
@@ -283,13 +304,13 @@ extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, voi
             for (int l = 0; l < c.n_layers; ++l) {
                 const jb_layer& L = e->layers[l];
                 jb_gemv_args g = {};
-                g.dtype = c.dtype; g.x = c.x_a; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln0_g; g.ln_beta = L.ln0_b; g.ln_eps = c.ln_eps;
-                g.W = L.w_attn; g.bias = L.b_attn; g.K = W; g.J = 3 * S; g.out = c.q; g.ldo = S;
+                fill_ln_proj(g, c, L, 0);
+                g.x = c.x_a; g.J = 3 * S; g.out = c.q; g.ldo = S;
                 g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
                 JB_TRY(jb_gemv(&g, s));
                 g = {};
-                g.dtype = c.dtype; g.x = c.x_b; g.ldx = W; g.n_rows = N; g.ln_gamma = L.ln1_g; g.ln_beta = L.ln1_b; g.ln_eps = c.ln_eps;
-                g.W = L.w_fc; g.bias = L.b_fc; g.K = W; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
+                fill_ln_proj(g, c, L, 1);
+                g.x = c.x_b; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
                 JB_TRY(jb_gemv(&g, s));
             }
         return JB_OK;

@@ -288,6 +288,7 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
 struct GemvParams {
     const void* x; int64_t ldx; int n_rows;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const float* ln_c1;                         // folded LayerNorm: column sums of the stored (gamma-scaled) weights
     const void* W; int K, nkt;
     int vec_x, lds_pitch, fast;
     const void* pf_ptr; long long pf_bytes;     // next kernel's weights: touched early so they are in the memory-side cache
@@ -600,6 +601,135 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     JB_STAMP(7);
 }
 
+// Folded-LayerNorm projection (jb_gemv_args.ln_fold_c1): LN(x)·W + b = rstd·(x·W' - mean·c1) + b' with W' = diag(gamma)·W.
+// The MFMA B operands are the RAW activation rows, read straight from global memory in fragment layout, so nothing is
+// staged or normalised on the critical path.  The fp32 row statistics ride on the matrix cores too: per k-tile one extra
+// MFMA against an all-ones fragment gives sum(x) of the 16 rows, and the fragment against itself gives the Gram matrix
+// whose diagonal is sum(x^2) (f16 products are exact in the fp32 accumulator).  The per-wave partial sums join the
+// partial tiles in the single LDS exchange before the epilogue, where mean / rstd meet the accumulators.
+// A wave keeps all of its k-tiles' fragments in registers: needs ceil(nkt / NW) <= NF.
+template <typename T, int MT, int NW, int NF>
+__global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
+    using V = typename Frag<T>::vec;
+    constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    f32x4* s_acc = reinterpret_cast<f32x4*>(s_dyn);                                   // [NW][MT][64]
+    float* s_sum = reinterpret_cast<float*>(s_dyn + NW * MT * 64 * sizeof(f32x4));   // [NW][MT*16]
+    float* s_sq = s_sum + NW * MT * 16;                                              // [NW][MT*16]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int jt = blockIdx.x;
+    const T* x = (const T*)p.x;
+    const int kt0 = (wave * p.nkt) / NW, kt1 = ((wave + 1) * p.nkt) / NW;
+    const T* wbase = (const T*)p.W + ((int64_t)jt * p.nkt) * (64 * E) + (int64_t)lane * E;
+
+    // ---- every request of this workgroup, issued back to back ----
+    V xf[NF][MT];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int k0 = min(kt0 + i, p.nkt - 1) * KT + g * E;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            xf[i][mt] = ld_frag<T>(x + (int64_t)min(mt * 16 + c, p.n_rows - 1) * p.ldx + k0);
+    }
+    V wf[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+        wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)min(kt0 + i, p.nkt - 1) * (64 * E)));
+    constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);
+    int t = 0;
+    if (p.epi.qkv_split) t = *p.t_dev;
+    float e_bias[EPT], e_res[EPT], e_c1[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = threadIdx.x + u * NW * 64;
+        const int row = (i >> 8) * 16 + (i & 15), j = jt * 16 + ((i & 63) >> 4) * 4 + ((i >> 6) & 3);
+        const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
+        e_bias[u] = p.epi.bias ? p.epi.bias[jc] : 0.f;
+        e_c1[u] = p.ln_c1[jc];
+        e_res[u] = p.epi.res ? (float)((const T*)p.epi.res)[(int64_t)rc * p.epi.ldr + jc] : 0.f;
+    }
+
+    // ---- projection and row statistics, all on MFMA (tiles past kt1 are neutralised by zeroing the activations) ----
+    V ones;
+#pragma unroll
+    for (int e = 0; e < E; ++e) ones[e] = (T)1.0f;
+    f32x4 acc[MT], a1[MT], a2[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = a1[mt] = a2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const V xm = keep_frag<T>(kt0 + i < kt1, xf[i][mt]);
+            acc[mt] = jb_mfma(wf[i], xm, acc[mt]);      // D[j][row] += sum_k W'[k][j] x[row][k]
+            a1[mt] = jb_mfma(ones, xm, a1[mt]);         // D[*][row] += sum_k x[row][k]
+            a2[mt] = jb_mfma(xm, xm, a2[mt]);           // D[r'][row] += sum_k x[r'][k] x[row][k]
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
+        if (g == 0) s_sum[wave * (MT * 16) + mt * 16 + c] = a1[mt][0];
+        if (g == (c >> 2)) {                            // this lane holds the Gram diagonal of row c in register c & 3
+            const int r = c & 3;
+            s_sq[wave * (MT * 16) + mt * 16 + c] = r == 0 ? a2[mt][0] : (r == 1 ? a2[mt][1] : (r == 2 ? a2[mt][2] : a2[mt][3]));
+        }
+    }
+    __syncthreads();
+    const float* sa = reinterpret_cast<const float*>(s_acc);
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = threadIdx.x + u * NW * 64;
+        const int mt = i >> 8, r = (i >> 6) & 3, l = i & 63;
+        const int row = mt * 16 + (l & 15), j = jt * 16 + (l >> 4) * 4 + r;
+        if (i >= MT * 256 || row >= p.n_rows || j >= p.epi.J) continue;
+        float v = 0.f, sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            v += sa[((w * MT + mt) * 64 + l) * 4 + r];
+            sm += s_sum[w * (MT * 16) + row];
+            sq += s_sq[w * (MT * 16) + row];
+        }
+        const float mean = sm / (float)p.K;
+        const float var = fmaxf(sq / (float)p.K - mean * mean, 0.f);
+        v = (v - mean * e_c1[u]) / sqrtf(var + p.ln_eps);
+        const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
+        epilogue_store1<T>(p.epi, v, row, j, cache_row, e_bias[u], e_res[u]);
+    }
+}
+
+// k-tiles a wave must hold for the folded-LayerNorm kernel, or 0 when the problem is outside its envelope.
+static int lnf_shape(int dtype, int K, int J, int n_rows, int* nw_out) {
+    const int KT = dtype == JB_F16 ? 32 : 16, E = dtype == JB_F16 ? 8 : 4;
+    if (K <= 0 || J < 4 || K % KT != 0 || J % 4 != 0 || K < E || n_rows < 1 || n_rows > 32) return 0;
+    const int nkt = K / KT, nw = nkt >= 32 ? 8 : 4;
+    const int per_wave = (nkt + nw - 1) / nw;
+    *nw_out = nw;
+    return per_wave <= 8 ? 8 : (per_wave <= 16 ? 16 : 0);
+}
+
+extern "C" int jb_gemv_ln_fold_supported(int dtype, int K, int J, int n_rows) {
+    int nw;
+    return (dtype == JB_F32 || dtype == JB_F16) && lnf_shape(dtype, K, J, n_rows, &nw) != 0;
+}
+
+template <typename T, int MT, int NW>
+static int launch_gemv_lnf_nf(const GemvParams& p, int njt, int nf, hipStream_t s) {
+    const size_t lds = (size_t)NW * MT * 64 * sizeof(f32x4) + (size_t)2 * NW * MT * 16 * sizeof(float);
+    if (nf == 8) gemv_lnf_kernel<T, MT, NW, 8><<<njt, NW * 64, lds, s>>>(p);
+    else gemv_lnf_kernel<T, MT, NW, 16><<<njt, NW * 64, lds, s>>>(p);
+    return JB_OK;
+}
+
+template <typename T>
+static int launch_gemv_lnf(const GemvParams& p, int njt, int nf, int nw, hipStream_t s) {
+    const int mt = (p.n_rows + 15) / 16;
+    if (nw == 8) return mt == 1 ? launch_gemv_lnf_nf<T, 1, 8>(p, njt, nf, s) : launch_gemv_lnf_nf<T, 2, 8>(p, njt, nf, s);
+    return mt == 1 ? launch_gemv_lnf_nf<T, 1, 4>(p, njt, nf, s) : launch_gemv_lnf_nf<T, 2, 4>(p, njt, nf, s);
+}
+
 template <typename T, int MT, int NW, bool LNS, bool FAST, int NV>
 static int launch_gemv_fast(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
     static bool configured = false;
@@ -680,7 +810,7 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     int njt, Edummy;
     packed_dims(a->K, a->J, a->dtype, &p.nkt, &njt, &Edummy);
     p.x = a->x; p.ldx = a->ldx; p.n_rows = a->n_rows;
-    p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_eps = a->ln_eps;
+    p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_c1 = a->ln_fold_c1;
     p.W = a->W; p.K = a->K;
     p.vec_x = (a->ldx % E == 0) && aligned_to(a->x, 16);
     p.t_dev = a->t_dev;
@@ -702,8 +832,18 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
     p.epi.cache_cap = a->cache_cap;
     p.epi.vec_out = !a->qkv_split && (a->ldo % 4 == 0) && aligned_to(a->out, 4 * esz);
-    int rc = a->dtype == JB_F16 ? launch_gemv<f16>(p, njt, a->ln_gamma != nullptr, (hipStream_t)stream)
+    int rc;
+    if (a->ln_fold_c1) {
+        JB_REQUIRE(!a->ln_gamma && !a->ln_beta, "ln_fold_c1 excludes ln_gamma / ln_beta (gamma and beta are folded into W and bias)");
+        int nw = 0;
+        const int nf = lnf_shape(a->dtype, a->K, a->J, a->n_rows, &nw);
+        JB_REQUIRE(nf != 0 && p.fast, "folded LayerNorm is not available for this shape / alignment (jb_gemv_ln_fold_supported)");
+        rc = a->dtype == JB_F16 ? launch_gemv_lnf<f16>(p, njt, nf, nw, (hipStream_t)stream)
+                                : launch_gemv_lnf<float>(p, njt, nf, nw, (hipStream_t)stream);
+    } else {
+        rc = a->dtype == JB_F16 ? launch_gemv<f16>(p, njt, a->ln_gamma != nullptr, (hipStream_t)stream)
                                 : launch_gemv<float>(p, njt, a->ln_gamma != nullptr, (hipStream_t)stream);
+    }
     if (rc != JB_OK) return rc;
     JB_CHECK_LAUNCH();
     return JB_OK;

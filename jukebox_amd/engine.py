@@ -40,7 +40,8 @@ class PriorEngine:
 
     def __init__(self, sd, prefix, *, n_batch, seq_len, bins, width, depth, heads, attn_order, blocks=None,
                  m_attn=0.25, m_mlp=1.0, prime_len=None, y_cond=False, add_cond_after=True, fp16=True,
-                 chunk_cap=256, want_preds=False, record=None, encoder_dims=0, only_encode=False, device="cuda"):
+                 chunk_cap=256, want_preds=False, record=None, encoder_dims=0, only_encode=False, fold_ln=None,
+                 device="cuda"):
         L.lib()
         self.device = torch.device(device)
         self.N, self.T, self.bins, self.W = n_batch, seq_len, bins, width
@@ -52,6 +53,12 @@ class PriorEngine:
         self.funcs = attn_funcs(attn_order, depth)
         self.y_cond, self.add_cond_after = y_cond, add_cond_after
         self.chunk_cap = min(chunk_cap, seq_len)
+        # Decode step: LayerNorm folded into c_attn / c_fc (hip_ops.FoldedLN).  Default: on for fp16 engines; the fp32
+        # engine (the parity mode) normalises rows explicitly, operation for operation as the reference.  JB_FOLD_LN=0/1
+        # overrides both.
+        if fold_ln is None:
+            fold_ln = bool(int(os.environ["JB_FOLD_LN"])) if "JB_FOLD_LN" in os.environ else fp16
+        self.fold_ln = bool(fold_ln) and not only_encode
         dev, dt = self.device, self.dtype
         g = lambda name: sd[prefix + name].to(dev).contiguous()
         f32 = lambda name: g(name).float().contiguous()
@@ -92,6 +99,16 @@ class PriorEngine:
             lc.b_attn, lc.b_proj, lc.b_fc, lc.b_proj2 = (b.data_ptr() for b in bs)
             lc.ln0_g, lc.ln0_b, lc.ln1_g, lc.ln1_b = (t.data_ptr() for t in lns)
             lc.kcache, lc.vcache, lc.cache_cap = kc.data_ptr(), vc.data_ptr(), cap
+            if self.fold_ln:
+                j_attn = S if func == 6 else 3 * S
+                if H.ln_fold_supported(dt, W, j_attn, N):
+                    f = H.FoldedLN(g(p + "attn.c_attn.w"), bs[0], lns[0], lns[1], dt)
+                    lc.w_attn_f, lc.b_attn_f, lc.c1_attn = f.pw.ptr, f.bias.data_ptr(), f.c1.data_ptr()
+                    self._keep.append(f)
+                if H.ln_fold_supported(dt, W, M, N):
+                    f = H.FoldedLN(g(p + "mlp.c_fc.w"), bs[2], lns[2], lns[3], dt)
+                    lc.w_fc_f, lc.b_fc_f, lc.c1_fc = f.pw.ptr, f.bias.data_ptr(), f.c1.data_ptr()
+                    self._keep.append(f)
             if func == 6:
                 lc.w_enc_k, lc.w_enc_v, lc.b_enc_kv = enc[0].ptr, enc[1].ptr, b_enc.data_ptr()
 

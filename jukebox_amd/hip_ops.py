@@ -47,6 +47,25 @@ def pack_conv1d_w(w, dtype):
     return PackedWeight(pack_weight(w, K, J, J, 1, dtype), K, J, dtype)
 
 
+class FoldedLN:
+    """LayerNorm folded into the Conv1D that follows it (jb_gemv_args.ln_fold_c1): LN(x)·W + b is evaluated as
+    rstd·(x·W' - mean·c1) + b' with W' = diag(gamma)·W (packed, engine dtype), c1 = column sums of W' as stored,
+    b' = beta·W + b.  `w` is Conv1D.w (n_in, n_out); W is first rounded to the engine dtype, as the reference's
+    `w.type_as(x)` does (jukebox/transformer/ops.py:99)."""
+
+    def __init__(self, w, b, gamma, beta, dtype):
+        K, J = w.shape
+        w_used = w.to(dtype).double()
+        wf = (gamma.double()[:, None] * w_used).to(dtype).contiguous()
+        self.pw = PackedWeight(pack_weight(wf, K, J, J, 1, dtype), K, J, dtype)
+        self.c1 = wf.double().sum(0).float().contiguous()
+        self.bias = (beta.double() @ w_used + b.double()).float().contiguous()
+
+
+def ln_fold_supported(dtype, K, J, n_rows):
+    return bool(L.lib().jb_gemv_ln_fold_supported(L.dtype_code(dtype), K, J, n_rows))
+
+
 def pack_linear_w(w, dtype):
     """nn.Linear.weight (out, in): logical [k=in][j=out]."""
     J, K = w.shape
@@ -143,8 +162,12 @@ def tap_view(pw, taps):
     return v
 
 
-def gemv(x, pw, bias=None, ln=None, res=None, act=L.ACT_NONE, out=None, eps=1e-5):
-    """Decode-step skinny GEMM (see jb_gemv).  x: (n_rows<=64, K)."""
+def gemv(x, pw, bias=None, ln=None, res=None, act=L.ACT_NONE, out=None, eps=1e-5, ln_fold=None):
+    """Decode-step skinny GEMM (see jb_gemv).  x: (n_rows<=64, K).  ln = (gamma, beta): normalise the rows in the
+    kernel; ln_fold = FoldedLN: the folded form (pw / bias are taken from it)."""
+    if ln_fold is not None:
+        assert ln is None and bias is None and pw is None
+        pw, bias = ln_fold.pw, ln_fold.bias
     _chk_cuda(x, bias, res, out)
     if out is None:
         out = torch.empty((x.shape[0], pw.J), dtype=x.dtype, device=x.device)
@@ -153,6 +176,8 @@ def gemv(x, pw, bias=None, ln=None, res=None, act=L.ACT_NONE, out=None, eps=1e-5
     a.x, a.ldx, a.n_rows = x.data_ptr(), x.stride(0), x.shape[0]
     if ln is not None:
         a.ln_gamma, a.ln_beta, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), eps
+    if ln_fold is not None:
+        a.ln_fold_c1, a.ln_eps = ln_fold.c1.data_ptr(), eps
     a.W, a.bias, a.K, a.J = pw.ptr, L.ptr(bias), pw.K, pw.J
     a.out, a.ldo = out.data_ptr(), out.stride(0)
     a.res, a.ldr = L.ptr(res), (res.stride(0) if res is not None else 0)

@@ -43,10 +43,12 @@ CFG_B = dict(seq_len=120, bins=80, width=32, depth=48, heads=2, attn_order=12, b
 CFG_C = dict(seq_len=40, bins=96, width=48, depth=3, heads=3, attn_order=0, blocks=None, y_cond=True)
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_golden_a_fp32(PE, use_graph):
+@pytest.mark.parametrize("use_graph,fold_ln", [(False, False), (True, False), (True, True)])
+def test_golden_a_fp32(PE, use_graph, fold_ln):
+    """fold_ln: the decode step's folded-LayerNorm projections (default only in fp16 engines) in exact fp32 arithmetic."""
     g = load_golden("autoregressive")
-    eng = PE(to_dev(sub_state(g, "a.")), "", n_batch=3, fp16=False, want_preds=True, **CFG_A)
+    eng = PE(to_dev(sub_state(g, "a.")), "", n_batch=3, fp16=False, want_preds=True, fold_ln=fold_ln, **CFG_A)
+    assert eng.fold_ln == fold_ln and bool(eng.layers_c[0].w_attn_f) == fold_ln and bool(eng.layers_c[5].c1_fc) == fold_ln
     eng.set_cond(torch.from_numpy(g["a.x_cond"]), torch.from_numpy(g["a.y_cond"]))
     eng.set_sampling(temp=1.0, top_k=1)
     eng.decode(0, 64, use_graph=use_graph)
@@ -61,9 +63,11 @@ def test_golden_a_fp32(PE, use_graph):
     check_tokens(eng.tokens.cpu().numpy()[:, :20], g["a.z20"], g["a.preds"])
 
 
-def test_golden_a_fp16(PE):
+@pytest.mark.parametrize("fold_ln", [None, False])
+def test_golden_a_fp16(PE, fold_ln):
     g = load_golden("autoregressive")
-    eng = PE(to_dev(sub_state(g, "a.")), "", n_batch=3, fp16=True, want_preds=True, **CFG_A)
+    eng = PE(to_dev(sub_state(g, "a.")), "", n_batch=3, fp16=True, want_preds=True, fold_ln=fold_ln, **CFG_A)
+    assert eng.fold_ln == (fold_ln is None)            # fp16 engines fold by default
     eng.set_cond(torch.from_numpy(g["a.x_cond"]), torch.from_numpy(g["a.y_cond"]))
     eng.set_sampling(temp=1.0, top_k=1)
     eng.decode(0, 64)

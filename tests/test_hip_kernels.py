@@ -147,6 +147,55 @@ def test_gemv_ln_epilogues(H, name, dt, tol, rows, K, J):
 
 
 @pytest.mark.parametrize("name,dt,tol", DT)
+@pytest.mark.parametrize("rows,K,J", [(16, 1920, 1440), (16, 256, 96), (32, 2048, 64), (3, 512, 132), (20, 1024, 20), (1, 32, 4)])
+def test_gemv_ln_folded(H, name, dt, tol, rows, K, J):
+    """Folded LayerNorm (jb_gemv_args.ln_fold_c1): rstd*(x.W' - mean*c1) + b' against LayerNorm -> Conv1D done the
+    reference's way (ops.py:14-24,97-101), on rows with a mean several times their spread."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(rows * 7 + K)
+    f16 = dt == torch.float16
+    r = (lambda x: h16(x)) if f16 else (lambda x: x)
+    x = r(rng.standard_normal((rows, K)).astype(np.float32) * 1.5 + rng.standard_normal((rows, 1)).astype(np.float32) * 4)
+    W = r((0.1 * rng.standard_normal((K, J))).astype(np.float32))
+    b = rng.standard_normal(J).astype(np.float32)
+    g = (1 + 0.2 * rng.standard_normal(K)).astype(np.float32)
+    be = (0.2 * rng.standard_normal(K)).astype(np.float32)
+    assert H.ln_fold_supported(dt, K, J, rows)
+    f = H.FoldedLN(dev(W), dev(b), dev(g), dev(be), dt)
+    got = H.gemv(dev(x, dt), None, ln_fold=f, act=L.ACT_QUICK_GELU).float().cpu().numpy()
+    x64 = x.astype(np.float64)
+    m, v = x64.mean(-1, keepdims=True), x64.var(-1, keepdims=True)
+    pre = ((x64 - m) / np.sqrt(v + 1e-5) * g + be) @ W.astype(np.float64) + b
+    exact = pre / (1 + np.exp(-1.702 * pre))
+    want = O.quick_gelu(r(r(O.layer_norm(x, g, be)) @ W + r(b)), fp16=f16)
+    assert relerr(got, want) < tol
+    # the folded form skips the rounding of the normalised rows, so it is at least as close to exact arithmetic
+    assert relerr(got, exact) < max(tol, 1.5 * relerr(want, exact))
+    # and agrees with the in-kernel normalisation path of the same library
+    if rows * K * (2 if f16 else 4) < 100 * 1024:          # the in-kernel path stages the rows in LDS
+        cls = H.gemv(dev(x, dt), H.pack_conv1d_w(dev(W), dt), bias=dev(b), ln=(dev(g), dev(be)), act=L.ACT_QUICK_GELU)
+        assert relerr(got, cls.float().cpu().numpy()) < tol
+
+
+def test_gemv_ln_folded_rejects_unsupported_shapes(H):
+    from jukebox_amd import _lib as L
+    assert not H.ln_fold_supported(torch.float16, 100, 64, 16)        # K not a whole number of k-tiles
+    assert not H.ln_fold_supported(torch.float16, 8192, 64, 16)       # fragments of a row do not fit in registers
+    assert not H.ln_fold_supported(torch.float32, 256, 64, 48)        # more than 32 rows
+    x = torch.zeros((16, 128), dtype=torch.float16, device="cuda")
+    f = H.FoldedLN(torch.zeros((128, 64), device="cuda"), torch.zeros(64, device="cuda"), torch.ones(128, device="cuda"),
+                   torch.zeros(128, device="cuda"), torch.float16)
+    with pytest.raises(L.JukeboxHipError, match="ln_fold_c1 excludes"):
+        a = L.GemvArgs()
+        out = torch.empty((16, 64), dtype=torch.float16, device="cuda")
+        a.dtype, a.x, a.ldx, a.n_rows = L.F16, x.data_ptr(), 128, 16
+        a.W, a.bias, a.K, a.J, a.out, a.ldo = f.pw.ptr, f.bias.data_ptr(), 128, 64, out.data_ptr(), 64
+        a.ln_fold_c1, a.ln_gamma, a.ln_beta = f.c1.data_ptr(), f.c1.data_ptr(), f.c1.data_ptr()
+        import ctypes as C
+        L.check(L.lib().jb_gemv(C.byref(a), L.stream()))
+
+
+@pytest.mark.parametrize("name,dt,tol", DT)
 def test_gemv_qkv_append(H, name, dt, tol):
     import ctypes as C
     from jukebox_amd import _lib as L
