@@ -127,7 +127,7 @@ def projection_roofline(eng, t0, n_steps):
             traffic = int(pmc["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
-    return dict(bound="hbm", kernel="gemv_kernel<f16, LN-fused> (attn.c_attn / mlp.c_fc of the decode step)",
+    return dict(bound="hbm", kernel="gemv_lnf_kernel<f16> (LayerNorm-folded attn.c_attn / mlp.c_fc of the decode step)",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                 traffic=traffic, avg_launch_us=round(us, 3), launches_timed=launches, bytes_per_launch=int(abytes))
 

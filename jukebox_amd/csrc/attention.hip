@@ -269,6 +269,121 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     }
 }
 
+// Channel-split variant of the kernel above: grid.z workgroups per (sample, head), each owning `pc` value channels.
+// One CU can pull ~130 GB/s, so a single workgroup reading a whole 128-key K and V set (245 KB at d = 480) spends
+// longer on its own L1 fill than the rest of the chip would need for everything; here every part recomputes the (cheap,
+// MFMA) scores from the full keys but reads and accumulates only its slice of V.  The PV lanes are laid out as
+// (key group g, channel chunk c): lane (g, c) multiplies ITS four keys g*4 + r -- whose probabilities the score MFMA
+// left in its own registers -- into 8 channels, so no probability ever goes through LDS, and the four key groups are
+// summed once per wave after the last tile.  Softmax statistics are identical in all parts (same arithmetic on the
+// same inputs), so the parts never talk to each other.
+template <int ND32>
+__global__ __launch_bounds__(512) void attn_decode_mfma_parts_kernel(int func, const f16* __restrict__ q, int64_t ldq,
+                                                                     const f16* __restrict__ kc, const f16* __restrict__ vc,
+                                                                     int cap, f16* __restrict__ out, int64_t ldo, int n_head,
+                                                                     int bc, const int* __restrict__ t_dev, int pc) {
+    constexpr int d = ND32 * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nw = blockDim.x >> 6;
+    float* s_ml = smem;                      // [nw][2]
+    float* s_o = smem + 2 * nw;              // [nw][pc]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int n = blockIdx.x, h = blockIdx.y, part = blockIdx.z;
+    const int S = n_head * d;
+    const int t = *t_dev;
+    const KeySet ks = decode_key_set(func, t, bc, cap);
+    f16* o = out + (int64_t)n * ldo + h * d + part * pc;
+    if (ks.count == 0) {
+        for (int i = threadIdx.x; i < pc; i += blockDim.x) o[i] = (f16)0;
+        return;
+    }
+    const float scale = 1.0f / sqrtf(sqrtf((float)d));
+    const float scale2 = scale * scale;
+    const f16* qrow = q + (int64_t)n * ldq + h * d;
+    f16x8 qf[ND32];
+#pragma unroll
+    for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+    const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
+    const int nchunk = pc >> 3;
+    const f16* vbase = vc + ((int64_t)n * cap) * S + h * d + part * pc + min(c, nchunk - 1) * 8;
+
+    float m_w = -INFINITY, l_w = 0.f;
+    float of[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) of[e] = 0.f;
+
+    const int ntiles = (ks.count + 15) >> 4;
+    for (int tt = wave; tt < ntiles; tt += nw) {
+        const int kbase_i = tt * 16;
+        const int ki = min(kbase_i + c, ks.count - 1);
+        const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * S + g * 8;
+        f16x8 kf[ND32];
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) kf[dt] = ld_frag<f16>(kr + dt * 32);
+        f16x8 vv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int vi = min(kbase_i + g * 4 + r, ks.count - 1);
+            vv[r] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * S);
+        }
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) sc = jb_mfma(kf[dt], qf[dt], sc);
+        float pv[4], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = kbase_i + g * 4 + r < ks.count;
+            pv[r] = ok ? jb_round<f16>(jb_round<f16>(sc[r]) * scale2) : -INFINITY;
+            mx = fmaxf(mx, pv[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_w, mx);
+        const float alpha = expf(m_w - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pv[r] = (pv[r] == -INFINITY) ? 0.f : expf(pv[r] - m_new);
+            ps += pv[r];
+        }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l_w = l_w * alpha + ps;
+        m_w = m_new;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) of[e] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pr = jb_round<f16>(pv[r]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) of[e] += pr * (float)vv[r][e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        of[e] += __shfl_xor(of[e], 16, 64);
+        of[e] += __shfl_xor(of[e], 32, 64);
+    }
+    if (lane == 0) { s_ml[2 * wave] = m_w; s_ml[2 * wave + 1] = l_w; }
+    if (g == 0 && c < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_o[wave * pc + c * 8 + e] = of[e];
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);
+    float lsum = 0.f;
+    for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] * expf(s_ml[2 * w] - m);
+    const float inv = 1.0f / lsum;
+    for (int i = threadIdx.x; i < pc; i += blockDim.x) {
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += s_o[w * pc + i] * expf(s_ml[2 * w] - m);
+        o[i] = (f16)(a * inv);
+    }
+}
+
 // launch shape of the decode attention: threads per (sample, head) workgroup and key/value row pairs in flight per wave
 static int g_dec_threads = 512, g_dec_kb = 4, g_dec_mfma = 1;
 extern "C" void jb_tune_attn_decode(int threads, int kb) {
@@ -276,6 +391,8 @@ extern "C" void jb_tune_attn_decode(int threads, int kb) {
     if (kb > 0) g_dec_kb = kb;
     g_dec_mfma = kb >= 0;          // kb < 0 selects the generic (vector-ALU QK^T) kernel for every dtype
 }
+static int g_dec_parts = 1;
+extern "C" void jb_tune_attn_decode_parts(int enable) { g_dec_parts = enable != 0; }
 
 extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache,
                               const void* vcache, int cache_cap, void* out, int64_t ldo, int n_batch, int n_head,
@@ -296,6 +413,29 @@ extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t l
     hipStream_t s = (hipStream_t)stream;
     if (dtype == JB_F16 && g_dec_mfma && d_head % 32 == 0 && d_head <= 512 && ldq % 8 == 0 && (n_head * d_head) % 8 == 0) {
         const int nwm = 8;
+        int parts = 1;
+        while (d_head / parts > 128) parts *= 2;
+        if (g_dec_parts && d_head % parts == 0 && (d_head / parts) % 8 == 0) {
+            const int pc = d_head / parts;
+            dim3 pgrid(n_batch, n_head, parts);
+            size_t ldsp = (size_t)(2 * nwm + nwm * pc) * sizeof(float);
+#define JB_LAUNCH_DECP(ND)                                                                                             \
+    attn_decode_mfma_parts_kernel<ND><<<pgrid, nwm * 64, ldsp, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,    \
+                                                                  (const f16*)vcache, cache_cap, (f16*)out, ldo, n_head, \
+                                                                  block_ctx, t_dev, pc)
+            switch (d_head / 32) {
+                case 1: JB_LAUNCH_DECP(1); break;
+                case 2: JB_LAUNCH_DECP(2); break;
+                case 4: JB_LAUNCH_DECP(4); break;
+                case 8: JB_LAUNCH_DECP(8); break;
+                case 15: JB_LAUNCH_DECP(15); break;
+                case 16: JB_LAUNCH_DECP(16); break;
+                default: goto generic;
+            }
+#undef JB_LAUNCH_DECP
+            JB_CHECK_LAUNCH();
+            return JB_OK;
+        }
         size_t ldsm = (size_t)(2 * nwm + 16 * nwm + nwm * d_head) * sizeof(float);
 #define JB_LAUNCH_DECM(ND)                                                                                      \
     attn_decode_mfma_kernel<ND><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,    \

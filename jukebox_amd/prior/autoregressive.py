@@ -161,7 +161,19 @@ class ConditionalAutoregressive2D(nn.Module):
             assert n_prime < sample_tokens
             eng.tokens[:, :n_prime] = x_prime
             eng.prefill(0, n_prime)
-        eng.decode(n_prime, sample_tokens - n_prime)
+        tap = getattr(self, "decode_tap", None)
+        if tap is None:
+            eng.decode(n_prime, sample_tokens - n_prime)
+        else:
+            # (every, fn): hand the token buffer to fn after every `every` enqueued decode steps, so that a consumer on
+            # another stream can start on a partial window (jukebox_amd.sample._sample_levels_pipelined)
+            every, fn = tap
+            pos = n_prime
+            while pos < sample_tokens:
+                n = min(int(every), sample_tokens - pos)
+                eng.decode(pos, n)
+                fn(eng.tokens, pos, pos + n)
+                pos += n
         x = eng.tokens[:, :sample_tokens].clone()
         x = self.postprocess(x, sample_tokens)
         if get_preds:

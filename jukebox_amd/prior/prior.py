@@ -196,6 +196,7 @@ class SimplePrior(nn.Module):
             name = {True: "Ancestral", False: "Primed"}[no_past_context]
             print_once(f"{name} sampling {n_samples} samples with temp={temp}, top_k={top_k}, top_p={top_p}")
         kw = dict(fp16=fp16, temp=temp, top_k=top_k, top_p=top_p, seed=seed, sample_base=sample_base)
+        self.prior.decode_tap = self._decode_tap()
         with t.no_grad():
             x_cond, y_cond, prime = self.get_cond(z_conds, y)
             if self.single_enc_dec:
@@ -217,4 +218,23 @@ class SimplePrior(nn.Module):
                                                  sample_tokens=sample_tokens, **kw)
             if sample_tokens is None:
                 assert tuple(z.shape) == (N, *self.z_shape)
+        self.prior.decode_tap = None
         return z
+
+    def _decode_tap(self):
+        """window_tap = (every, cb): cb(lo, hi, tokens) receives the window's music tokens [lo, hi) (window-relative,
+        already through prior_postprocess) as soon as their decode steps are enqueued -- an extension used by the level
+        pipeline; None (the default) samples the window in one piece."""
+        wt = getattr(self, "window_tap", None)
+        if wt is None:
+            return None
+        every, cb = wt
+        off = self.n_tokens if self.single_enc_dec else 0
+        shift = int(self.prior_bins_shift[-1]) if self.single_enc_dec else 0
+
+        def fn(tokens, lo, hi):
+            tok = tokens[:, lo:hi]
+            if self.single_enc_dec:
+                tok = t.clamp(tok - shift, min=0)                  # prior_postprocess on the music part
+            cb(lo - off, hi - off, tok)
+        return every, fn

@@ -5,6 +5,7 @@ Extensions for MI355X nodes: `n_samples` is sharded across the ranks of one node
 broadcasts the label matrices (and primed codes) over RCCL, every rank samples its contiguous slice with per-sample
 random streams, and the generated codes are all-gathered once per level.  The reference runs
 the whole job redundantly on every rank with identical seeds (sample.py:110-113)."""
+import contextlib
 import os
 
 import torch as t
@@ -44,7 +45,9 @@ def sample_single_window(zs, labels, sampling_kwargs, level, prior, start, hps):
         return zs
     z_conds = prior.get_z_conds(zs, start, end)
     y = prior.get_y(labels, start)
-    empty_cache()
+    if not hps.get("keep_priors_resident", False):
+        empty_cache()       # sample.py:47; releasing cached blocks synchronises the whole device, which would stall the
+                            # other levels' streams in resident / pipelined mode (and 288 GB make it unnecessary)
     kwargs = dict(sampling_kwargs)
     max_batch_size = kwargs.pop("max_batch_size")
     sample_base = kwargs.pop("sample_base", 0)
@@ -93,24 +96,42 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     import threading
     cond = threading.Condition()
     progress = {l: int(z.shape[1]) for l, z in enumerate(zs_local)}
+    # Codes of every sampled level as they appear (written once, at absolute positions): a window publishes its tokens
+    # every `pipeline_chunk` decode steps, so the level below starts on a PARTIAL upper window -- its first window needs
+    # only the first n_ctx / cond_downsample upper codes, not the upper level's whole first window.
+    chunk = int(hps.get("pipeline_chunk", 256))
+    zbuf = {}
+    for l in sample_levels:
+        zbuf[l] = t.zeros((zs_local[l].shape[0], hps.sample_length // priors[l].raw_to_tokens), dtype=t.long, device=device)
+        zbuf[l][:, :zs_local[l].shape[1]] = zs_local[l]
     ready_event = {}
     errors = []
     levels = sorted(sample_levels, reverse=True)
-    current = torch_cuda_current_stream(device)
+    on_gpu = str(device).startswith("cuda")            # on CPU (host-logic tests) the schedule runs without streams
+    current = torch_cuda_current_stream(device) if on_gpu else None
     # One stream per level.  Measured on MI355X / ROCm 7.2 (tools/bench_concurrent.py): two normal-priority streams can
     # land on one hardware queue and serialise completely, whereas torch's pooled high-priority streams plus one
     # normal-priority stream ran three decode chains concurrently at 1.3x the single-chain step time.  The two
     # upsampler levels (the long poles) therefore get high priority, the top level normal priority.
     order = sorted(levels)                                 # lowest level first
     prios = [-1, -1, 0, 0]
-    stream_of = {level: t.cuda.Stream(device=device, priority=prios[min(i, 3)]) for i, level in enumerate(order)}
+    stream_of = {level: t.cuda.Stream(device=device, priority=prios[min(i, 3)]) if on_gpu else None
+                 for i, level in enumerate(order)}
+
+    def new_event(stream):
+        if not on_gpu:
+            return None
+        ev = t.cuda.Event()
+        ev.record(stream)
+        return ev
 
     def worker(level):
         try:
             prior = priors[level]
             stream = stream_of[level]
-            stream.wait_stream(current)
-            with t.cuda.stream(stream):
+            if on_gpu:
+                stream.wait_stream(current)
+            with (t.cuda.stream(stream) if on_gpu else contextlib.nullcontext()):
                 total_length = hps.sample_length // prior.raw_to_tokens
                 hop_length = int(hps.hop_fraction[level] * prior.n_ctx)
                 kw = dict(sampling_kwargs[level])
@@ -129,16 +150,39 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                     k = dict(kw)
                     if sample_tokens is not None:
                         k["sample_tokens"] = sample_tokens
-                    out = sample_single_window(list(zs_local), lab, k, level, prior, start, local_hps)
-                    ev = t.cuda.Event()
-                    ev.record(stream)
+                    view = list(zs_local)
+                    if (level + 1) in zbuf:
+                        view[level + 1] = zbuf[level + 1]          # only [start/cd, end/cd) is read: published above
+                    known = int(zs_local[level].shape[1])
+                    tapped = local_hps.n_samples <= k["max_batch_size"] and chunk > 0
+
+                    def publish(lo, hi, tok, start=start, known=known):
+                        # window-relative music tokens [lo, hi), all new (the primed part is never decoded)
+                        assert start + lo >= known
+                        zbuf[level][:, start + lo:start + hi] = tok
+                        ev = new_event(stream)
+                        with cond:
+                            progress[level] = start + hi
+                            ready_event[level] = ev
+                            cond.notify_all()
+
+                    prior.window_tap = (chunk, publish) if tapped else None
+                    try:
+                        out = sample_single_window(view, lab, k, level, prior, start, local_hps)
+                    finally:
+                        prior.window_tap = None
+                    new_len = int(out[level].shape[1])
+                    if not tapped:
+                        zbuf[level][:, known:new_len] = out[level][:, known:new_len]
+                    ev = new_event(stream)
                     with cond:
                         zs_local[level] = out[level]
-                        progress[level] = int(out[level].shape[1])
+                        progress[level] = new_len
                         ready_event[level] = ev
                         cond.notify_all()
                 callback = getattr(_sample, "level_done", None)
-                stream.synchronize()
+                if on_gpu:
+                    stream.synchronize()
                 if callable(callback):
                     callback(level)
         except BaseException as e:          # noqa: BLE001 -- re-raised in the caller
@@ -151,7 +195,8 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         th.start()
     for th in threads:
         th.join()
-    t.cuda.synchronize(device)
+    if on_gpu:
+        t.cuda.synchronize(device)
     if errors:
         raise errors[0]
     return zs_local
@@ -176,7 +221,7 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
     xs = {}
     alignments = None
     pipelined = bool(hps.get("pipeline_levels", False)) and hps.get("keep_priors_resident", False) \
-        and len(sample_levels) > 1 and local_hps.n_samples > 0 and str(device).startswith("cuda")
+        and len(sample_levels) > 1 and local_hps.n_samples > 0
     if pipelined:
         for level in sample_levels:
             priors[level].to(device)

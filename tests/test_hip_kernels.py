@@ -265,7 +265,7 @@ def _np_attention(func, q, K, V, H_, bc, prime_r, qpos, fp16):
 
 @pytest.mark.parametrize("name,dt,tol", [("f32", torch.float32, 1e-5), ("f16", torch.float16, 4e-3)])
 @pytest.mark.parametrize("func", [0, 1, 2, 3, 7])
-@pytest.mark.parametrize("H_,d", [(2, 16), (1, 120), (2, 256)])
+@pytest.mark.parametrize("H_,d", [(2, 16), (1, 120), (2, 256), (2, 64)])
 def test_attn_decode(H, name, dt, tol, func, H_, d):
     rng = np.random.default_rng(func * 10 + d)
     N, T, bc, prime_r = 3, 96, 8, 24
@@ -282,6 +282,28 @@ def test_attn_decode(H, name, dt, tol, func, H_, d):
         got = H.attn_decode(func, dev(q[:, 0], dt), kc, vc, H_, bc, t_dev, T).float().cpu().numpy()
         want = _np_attention(func, q, K, V, H_, bc, prime_r, [t], fp16)[:, 0]
         assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (func, t)
+
+
+@pytest.mark.parametrize("parts", [1, 0])
+@pytest.mark.parametrize("func", [1, 2, 3])
+def test_attn_decode_upsampler_shape(H, func, parts):
+    """fp16 MFMA decode attention at the upsamplers' head size (1 head of 480) and block length 128, with the
+    channel-split launch (4 workgroups of 120 channels per sample) and without."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(func)
+    N, T, bc, d = 2, 512, 128, 480
+    K, V = h16(rng.standard_normal((N, T, d)).astype(np.float32)), h16(rng.standard_normal((N, T, d)).astype(np.float32))
+    kc, vc = dev(K, torch.float16), dev(V, torch.float16)
+    L.lib().jb_tune_attn_decode_parts(parts)
+    try:
+        for t in (0, 1, 127, 128, 130, 300, 511):
+            q = h16(rng.standard_normal((N, 1, d)).astype(np.float32))
+            t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+            got = H.attn_decode(func, dev(q[:, 0], torch.float16), kc, vc, 1, bc, t_dev, T).float().cpu().numpy()
+            want = _np_attention(func, q, K, V, 1, bc, None, [t], True)[:, 0]
+            assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max()), (func, t)
+    finally:
+        L.lib().jb_tune_attn_decode_parts(1)
 
 
 @pytest.mark.parametrize("name,dt,tol", [("f32", torch.float32, 2e-5), ("f16", torch.float16, 6e-3)])

@@ -149,13 +149,16 @@ def test_pipelined_levels_equal_sequential(models):
                    info=[dict(full_tokens=list(map(int, g[f"p{i}.full_tokens{j}"]))) for j in range(n)]) for i in range(3)]
     sk = [dict(temp=0.99, fp16=True, chunk_size=8, max_batch_size=3) for _ in range(3)]
     outs = []
-    for pipe in (False, True):
+    # pipeline_chunk: decode steps between two publications of a window's codes to the level below (0: whole windows);
+    # 5 does not divide the windows, so a lower window starts in the middle of an upper one
+    for pipe, chunk in ((False, 0), (True, 0), (True, 5), (True, 256)):
         hps = Hyperparams(n_samples=n, sample_length=4608, hop_fraction=[0.5, 0.5, 0.125], sr=22050, name="unused",
-                          keep_priors_resident=True, pipeline_levels=pipe)
+                          keep_priors_resident=True, pipeline_levels=pipe, pipeline_chunk=chunk)
         zs = S.ancestral_sample(labels, sk, priors, hps, save=False)
         outs.append([z.cpu().numpy() for z in zs])
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
 
 
 def test_alignment_matches_reference(models):

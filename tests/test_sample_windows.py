@@ -18,6 +18,7 @@ from jukebox_amd import sample as S
 from jukebox_amd.hparams import Hyperparams
 
 BINS = 2048
+LOG = []            # (level, window start) in call order, all priors
 
 
 def f(level, sample_ids, pos):
@@ -32,6 +33,7 @@ class DummyPrior:
         self.x_cond = level != levels - 1
         self.n_tokens = 0
         self.calls = []
+        self.after_publish = None
 
     def to(self, device):
         return self
@@ -69,6 +71,15 @@ class DummyPrior:
         assert t.equal(ids, t.arange(int(ids[0]), int(ids[0]) + n_samples))
         assert int(ids[0]) >= sample_base
         self.calls.append((start, z.shape[1], n_tok))
+        LOG.append((self.level, start))
+        tap = getattr(self, "window_tap", None)
+        if tap is not None:                      # the level pipeline's partial-window publication (SimplePrior._decode_tap)
+            every, cb = tap
+            for lo in range(z.shape[1], n_tok, every):
+                hi = min(lo + every, n_tok)
+                cb(lo, hi, want[:, lo:hi])
+                if self.after_publish is not None:
+                    self.after_publish(self, start + hi)
         return want
 
     def decode(self, zs, start_level=None, bs_chunks=1):
@@ -106,6 +117,47 @@ def test_ancestral_windows_three_levels():
     assert all(c[1] == (0 if c[0] == 0 else 8192 - 1024) for c in top_calls)
     # lower levels: hop n/2
     assert sorted(set(c[0] for c in priors[1].calls))[:3] == [0, 4096, 8192]
+
+
+@pytest.mark.parametrize("chunk", [0, 256, 1000])
+def test_pipelined_levels_on_cpu(chunk):
+    """The level pipeline (one host thread per level, partial-window publication every `pipeline_chunk` steps) visits the
+    same windows with the same conditioning as the sequential loop; with publication on, a lower level starts while
+    the upper level's first window is still being sampled."""
+    import threading
+    top = 8192 + 2 * 1024
+    priors, hps, labels, sk = make_setup(n_samples=3, top_tokens=top)
+    hps.keep_priors_resident, hps.pipeline_levels, hps.pipeline_chunk = True, True, chunk
+    sk[2]["max_batch_size"] = 3              # partial publication needs the window in one sub-batch
+    started = {1: threading.Event(), 0: threading.Event()}
+    seen = {}
+
+    def after_publish(prior, n_done):
+        # the top level's first window has published the codes level 1's first window needs: wait for level 1 to start
+        # before finishing the window (only possible when publication is partial)
+        if prior.level == 2 and n_done >= 2048 and n_done < 8192 and "l1" not in seen:
+            seen["l1"] = started[1].wait(timeout=20)
+        if prior.level == 1 and n_done >= 2048 and n_done < 8192 and "l0" not in seen:
+            seen["l0"] = started[0].wait(timeout=20)
+
+    for p in priors:
+        p.after_publish = after_publish if chunk else None
+        orig = p.sample
+
+        def wrapped(*a, _orig=orig, _p=p, **k):
+            if _p.level in started:
+                started[_p.level].set()
+            return _orig(*a, **k)
+        p.sample = wrapped
+    zs = S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
+    check_levels(zs, 3, top)
+    if chunk:
+        assert seen == {"l1": True, "l0": True}, seen
+    # same windows as the sequential schedule
+    ref_priors, ref_hps, _, _ = make_setup(n_samples=3, top_tokens=top)
+    S.ancestral_sample(labels, sk, ref_priors, ref_hps, save=False, device="cpu")
+    for a, b in zip(priors, ref_priors):
+        assert sorted(a.calls) == sorted(b.calls)
 
 
 def test_primed_continue_and_partial_window():
