@@ -124,8 +124,9 @@ int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const v
  * the generic kernel of jb_attn_decode (defaults 512 / 4; a value <= 0 keeps the current one).  kb < 0 disables the
  * fp16 MFMA fast path (QK^T on MFMA) so that the generic kernel runs for every dtype. */
 void jb_tune_attn_decode(int threads, int kb);
-/* fp16 MFMA fast path: 1 (default) = channel-split workgroups (several per (sample, head), each owning <= 128 value
- * channels), 0 = one workgroup per (sample, head). */
+/* fp16 MFMA fast path: 0 (default) = one workgroup per (sample, head); 1 = channel-split workgroups (several per
+ * (sample, head), each owning <= 128 value channels and recomputing the scores) -- slower on MI355X at the released
+ * model sizes, kept as a tuning knob. */
 void jb_tune_attn_decode_parts(int enable);
 
 /* Chunked-prefill attention (q_l > 1) on MFMA with LDS-staged k/v tiles and online softmax:

@@ -303,7 +303,7 @@ def test_attn_decode_upsampler_shape(H, func, parts):
             want = _np_attention(func, q, K, V, 1, bc, None, [t], True)[:, 0]
             assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max()), (func, t)
     finally:
-        L.lib().jb_tune_attn_decode_parts(1)
+        L.lib().jb_tune_attn_decode_parts(0)
 
 
 @pytest.mark.parametrize("name,dt,tol", [("f32", torch.float32, 2e-5), ("f16", torch.float16, 6e-3)])
