@@ -83,6 +83,9 @@ typedef struct jb_gemm_args {
     void* kcache; void* vcache; int cache_cap, cache_t0;
 } jb_gemm_args;
 int jb_gemm(const jb_gemm_args* args /* host */, void* stream);
+/* Flat problems (one tap, unit strides) of at least `min_rows` output rows use the LDS-staged 256x128-tile kernel
+ * (default 1024; < 0: never). */
+void jb_tune_gemm_lds(int min_rows);
 
 /* Weight-streaming skinny GEMM for the decode step (n_rows <= 64): out = act(LN?(x) @ W + b) (+ res),
  * one workgroup per 16 output columns, waves split K.  With ln_gamma != NULL the LayerNorm of

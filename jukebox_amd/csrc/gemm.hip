@@ -242,6 +242,110 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
+// LDS-staged GEMM for "flat" problems (one tap, unit strides: output row q reads input row q) -- the prefill
+// projections.  gemm_kernel above feeds every MFMA operand straight from L1: 32 FLOP per L1 byte, so the texture path
+// saturates at a few percent of the matrix cores.  Here a block of 4 waves owns a 256-row x 128-column tile; per
+// k-tile the block copies the 256 x KT activation panel (rows padded by one 16-byte slot: conflict-free fragment
+// reads) and the 8 packed weight fragments into LDS once, and each wave multiplies its 64 rows against all 128
+// columns (4 x 8 = 32 accumulator tiles, 12 fragment reads per 32 MFMAs).  Global loads for k-tile kt+1 are issued
+// before the MFMAs of k-tile kt and parked in the other LDS stage afterwards: one barrier per k-tile.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_lds_kernel(GemmParams p) {
+    using V = typename Frag<T>::vec;
+    constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
+    constexpr int BM = 256, BJ = 8;                    // rows, 16-column tiles per block
+    constexpr int XP = KT + E;                         // LDS row pitch (elements)
+    constexpr int SEG = KT / E;                        // 16-byte segments per activation row per k-tile (4)
+    constexpr int XL = BM * SEG / 256;                 // activation vectors per thread per k-tile (4)
+    constexpr int WL = BJ * 64 / 256;                  // weight vectors per thread per k-tile (2)
+    constexpr int STAGE = BM * XP + BJ * 64 * E;       // elements per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    T* s_base = reinterpret_cast<T*>(s_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int jt0 = blockIdx.y * BJ;
+
+    const T* xsrc[XL];
+    int xdst[XL];
+#pragma unroll
+    for (int u = 0; u < XL; ++u) {
+        const int idx = tid + u * 256, row = idx / SEG, seg = idx - row * SEG;
+        const int64_t q = m0 + row < p.m_total ? m0 + row : p.m_total - 1;      // clamped: rows past the end are never stored
+        xsrc[u] = (const T*)p.A + q * p.lda + seg * E;
+        xdst[u] = row * XP + seg * E;
+    }
+    const T* wsrc[WL];
+    int wdst[WL];
+#pragma unroll
+    for (int u = 0; u < WL; ++u) {
+        const int idx = tid + u * 256, jt = idx >> 6, ln = idx & 63;
+        wsrc[u] = (const T*)p.W + ((int64_t)min(jt0 + jt, p.njt - 1) * p.nkt * 64 + ln) * E;
+        wdst[u] = BM * XP + (jt * 64 + ln) * E;
+    }
+    V xr[XL], wr[WL];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < XL; ++u) xr[u] = ld_frag<T>(xsrc[u] + (int64_t)kt * KT);
+#pragma unroll
+        for (int u = 0; u < WL; ++u) wr[u] = ld_frag<T>(wsrc[u] + (int64_t)kt * (64 * E));
+    };
+    auto park = [&](int stage) {
+        T* sb = s_base + stage * STAGE;
+#pragma unroll
+        for (int u = 0; u < XL; ++u) *reinterpret_cast<V*>(sb + xdst[u]) = xr[u];
+#pragma unroll
+        for (int u = 0; u < WL; ++u) *reinterpret_cast<V*>(sb + wdst[u]) = wr[u];
+    };
+
+    f32x4 acc[BJ][4];
+#pragma unroll
+    for (int a = 0; a < BJ; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int kt = 0; kt < p.nkt; ++kt) {
+        const bool more = kt + 1 < p.nkt;
+        if (more) fetch(kt + 1);
+        const T* sb = s_base + (kt & 1) * STAGE;
+        V af[4], wf[BJ];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const V*>(sb + (wave * 64 + mt * 16 + c) * XP + g * E);
+#pragma unroll
+        for (int jt = 0; jt < BJ; ++jt) wf[jt] = *reinterpret_cast<const V*>(sb + BM * XP + (jt * 64 + lane) * E);
+#pragma unroll
+        for (int jt = 0; jt < BJ; ++jt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[jt][mt] = jb_mfma(wf[jt], af[mt], acc[jt][mt]);
+        if (more) park((kt + 1) & 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int64_t q = m0 + wave * 64 + mt * 16 + c;
+        if (q >= p.m_total) continue;
+        const int n = (int)(q / p.t_out), t = (int)(q - (int64_t)n * p.t_out);
+        int64_t cache_row = -1;
+        if (p.epi.qkv_split) {
+            const int ct = p.cache_t0 + t;
+            if (ct < p.epi.cache_cap) cache_row = (int64_t)n * p.epi.cache_cap + ct;
+        }
+#pragma unroll
+        for (int jt = 0; jt < BJ; ++jt) {
+            const int jb = (jt0 + jt) * 16 + g * 4;
+            if (jb < p.epi.J) epilogue_store<T>(p.epi, acc[jt][mt], q, jb, cache_row);
+        }
+    }
+}
+
+// rows from which jb_gemm takes the LDS-staged kernel for flat problems (< 0: never); jb_tune_gemm_lds
+static int g_gemm_lds_min_rows = 1024;
+extern "C" void jb_tune_gemm_lds(int min_rows) { g_gemm_lds_min_rows = min_rows; }
+
 static inline bool aligned_to(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
 extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
@@ -275,6 +379,16 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     const int KT = a->dtype == JB_F16 ? 32 : 16;
     const bool fast = p.vec_a && (a->K % KT == 0);
     hipStream_t st = (hipStream_t)stream;
+    const bool flat = a->n_taps == 1 && a->shift[0] == 0 && a->in_stride == 1 && a->out_stride == 1 && a->out_offset == 0 &&
+                      a->t_in == a->t_out && a->in_seq_stride == a->t_in && a->out_seq_stride == a->t_out && !a->pre_relu;
+    if (flat && fast && g_gemm_lds_min_rows >= 0 && p.m_total >= g_gemm_lds_min_rows) {
+        dim3 lgrid((unsigned)((p.m_total + 255) / 256), (unsigned)((p.njt + 7) / 8));
+        const size_t lds = 2 * (size_t)(256 * (KT + E) + 8 * 64 * E) * esz;
+        if (a->dtype == JB_F16) gemm_lds_kernel<f16><<<lgrid, 256, lds, st>>>(p);
+        else gemm_lds_kernel<float><<<lgrid, 256, lds, st>>>(p);
+        JB_CHECK_LAUNCH();
+        return JB_OK;
+    }
     if (a->dtype == JB_F16) {
         if (fast) gemm_kernel<f16, true><<<grid, 256, 0, st>>>(p); else gemm_kernel<f16, false><<<grid, 256, 0, st>>>(p);
     } else {

@@ -84,6 +84,45 @@ def test_gemm_epilogues(H, name, dt, tol):
     assert relerr(got, want) < tol
 
 
+@pytest.mark.parametrize("name,dt,tol", DT)
+@pytest.mark.parametrize("M,K,J", [(1300, 256, 264), (600, 96, 72), (256, 32, 128), (2048, 1920, 480)])
+def test_gemm_lds_flat(H, name, dt, tol, M, K, J):
+    """The LDS-staged kernel jb_gemm takes for flat problems (prefill projections), forced on at any size: row and
+    column tails, every epilogue, and the q / k-cache / v-cache split at a cache offset."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(M + K)
+    f16 = dt == torch.float16
+    r = (lambda x: h16(x)) if f16 else (lambda x: x)
+    A = r(rng.standard_normal((M, K)).astype(np.float32))
+    W = r((rng.standard_normal((K, J)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(J).astype(np.float32)
+    R = r(rng.standard_normal((M, J)).astype(np.float32))
+    pw = H.pack_conv1d_w(dev(W), dt)
+    L.lib().jb_tune_gemm_lds(1)
+    try:
+        got = H.gemm(dev(A, dt), pw, bias=dev(b), act=L.ACT_QUICK_GELU).float().cpu().numpy()
+        assert relerr(got, O.quick_gelu(r(A @ W + r(b)), fp16=f16)) < tol
+        got = H.gemm(dev(A, dt), pw, bias=dev(b), res=dev(R, dt)).float().cpu().numpy()
+        assert relerr(got, r(R + r(A @ W + r(b)))) < tol
+        L.lib().jb_tune_gemm_lds(-1)                      # same call through the direct-from-L1 kernel
+        old = H.gemm(dev(A, dt), pw, bias=dev(b), res=dev(R, dt)).float().cpu().numpy()
+        assert np.array_equal(got, old)                   # same k order, same rounding points
+        L.lib().jb_tune_gemm_lds(1)
+        if J % 3 == 0:
+            n_seq, S, cap, t0 = 4, J // 3, M // 4 + 9, 5
+            kc = torch.zeros((n_seq, cap, S), dtype=dt, device="cuda")
+            vc = torch.zeros((n_seq, cap, S), dtype=dt, device="cuda")
+            q = H.gemm_qkv(dev(A, dt), pw, dev(b), n_seq, M // 4, S, kc, vc, t0).float().cpu().numpy()
+            want = r(A @ W + r(b))
+            assert relerr(q, want[:, :S]) < tol
+            kcn = kc.float().cpu().numpy()[:, t0:t0 + M // 4].reshape(M, S)
+            vcn = vc.float().cpu().numpy()[:, t0:t0 + M // 4].reshape(M, S)
+            assert relerr(kcn, want[:, S:2 * S]) < tol and relerr(vcn, want[:, 2 * S:]) < tol
+            assert float(kc[:, :t0].abs().max()) == 0 and float(kc[:, t0 + M // 4:].abs().max()) == 0
+    finally:
+        L.lib().jb_tune_gemm_lds(1024)
+
+
 def test_conv_stack_ops_fp32(H):
     """Dilated k=3 conv, strided k=4 conv and transposed conv on channels-last rows vs torch-free numpy NCT."""
     rng = np.random.default_rng(2)
