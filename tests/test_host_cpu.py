@@ -122,3 +122,33 @@ def test_two_rank_gloo_exchange(tmp_path):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_released_parameter_trees():
+    """'Checkpoints load unchanged' at the released sizes: the mirror's modules for every entry of MODELS['1b_lyrics'],
+    ['5b'] and ['5b_lyrics'] (VQ-VAE, both upsamplers, the three top-level priors), built on the meta device, expose
+    exactly the reference's state_dict -- same keys in the same order, same shapes, same dtypes (fp16_params models
+    store half Conv1D weights).  The expected trees come from the unmodified reference (tests/golden/gen_state_keys.py)."""
+    import json
+    import torch
+    from jukebox_amd.hparams import setup_hparams
+    from jukebox_amd.make_models import MODELS, make_prior, make_vqvae
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys.json")))
+
+    def tree(m):
+        return [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+
+    with torch.device("meta"):
+        vq_name = MODELS["5b"][0]
+        vq = make_vqvae(setup_hparams(vq_name, dict(sample_length=1048576, restore_vqvae="")), "meta")
+        got = {vq_name: tree(vq)}
+        for model in ("1b_lyrics", "5b", "5b_lyrics"):
+            assert MODELS[model][0] == vq_name
+            for nm in MODELS[model][1:]:
+                if nm not in got:
+                    got[nm] = tree(make_prior(setup_hparams(nm, dict(restore_prior="")), vq, "meta"))
+    assert sorted(got) == sorted(want)
+    for nm in want:
+        assert len(got[nm]) == len(want[nm]), (nm, len(got[nm]), len(want[nm]))
+        for g, w in zip(got[nm], want[nm]):
+            assert g == w, (nm, g, w)
