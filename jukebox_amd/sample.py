@@ -330,3 +330,122 @@ def default_sampling_kwargs(model):
     top = dict(temp=0.99, fp16=True, chunk_size=32, max_batch_size=16) if model == "1b_lyrics" else \
         dict(temp=0.99, fp16=True, chunk_size=16, max_batch_size=3)
     return [dict(lower), dict(lower), top]
+
+
+def load_audio(path, sr, duration, offset=0.0, mono=True):
+    """utils/io.py load_audio for the prompt files of `primed` mode: (channels, duration) float32 in [-1, 1].
+    WAV only (scipy; the reference decodes any container with PyAV, which is not installed); a file at another sample
+    rate is resampled with scipy's polyphase filter, which is close to, not identical with, the reference's resampler."""
+    import numpy as np
+    from scipy.io import wavfile
+    file_sr, data = wavfile.read(path)
+    if data.dtype.kind == "i":
+        data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
+    elif data.dtype.kind == "u":                         # 8-bit PCM is unsigned
+        data = (data.astype(np.float32) - 128.0) / 128.0
+    data = data.astype(np.float32)
+    if data.ndim == 1:
+        data = data[:, None]
+    if file_sr != sr:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(int(sr), int(file_sr))
+        data = resample_poly(data, int(sr) // g, int(file_sr) // g, axis=0).astype(np.float32)
+    start = int(offset * sr)
+    data = data[start:start + duration]
+    assert data.shape[0] == duration, f"{path}: {data.shape[0]} samples after offset, {duration} needed for the prompt"
+    if mono:
+        data = data.mean(axis=1, keepdims=True)
+    return np.ascontiguousarray(data.T)
+
+
+def load_prompts(audio_files, duration, hps, device="cuda"):
+    """sample.py:150-162: `duration` samples of each file as (n_samples, duration, 1), files repeated to fill the batch."""
+    xs = [load_audio(f, sr=hps.sr, duration=duration, offset=0.0, mono=True).T for f in audio_files]
+    while len(xs) < hps.n_samples:
+        xs.extend(xs)
+    xs = xs[:hps.n_samples]
+    return t.stack([t.from_numpy(x) for x in xs]).to(device, non_blocking=True)
+
+
+# sample.py:192-222 presets (artist / genre per item); the lyric sheets of the reference (jukebox/lyricdict.py) are not
+# redistributed here -- pass `metas` to save_samples for real lyrics.  Default text: P. B. Shelley, 1818 (public domain).
+_DEFAULT_LYRICS = ("I met a traveller from an antique land,\nWho said: Two vast and trunkless legs of stone\n"
+                   "Stand in the desert. Near them, on the sand,\nHalf sunk a shattered visage lies")
+_PRESETS = (("Alan Jackson", "Country"), ("Joe Bonamassa", "Blues Rock"), ("Frank Sinatra", "Classic Pop"),
+            ("Ella Fitzgerald", "Jazz"), ("Céline Dion", "Pop"))
+
+
+def save_samples(model, device, hps, sample_hps, metas=None):
+    """sample.py:178-262: build the models, label the batch, dispatch on sample_hps.mode
+    (ancestral | continue | upsample | primed).  Returns the codes `zs` (the reference returns None)."""
+    from .make_models import make_model
+    print_once(str(hps))
+    vqvae, priors = make_model(model, device, hps)
+    assert hps.sample_length // priors[-2].raw_to_tokens >= priors[-2].n_ctx, \
+        "Upsampling needs atleast one ctx in get_z_conds. Please choose a longer sample length"
+    total_length = hps.total_sample_length_in_seconds * hps.sr
+    if metas is None:
+        metas = [dict(artist=a, genre=g, lyrics=_DEFAULT_LYRICS, total_length=total_length, offset=0) for a, g in _PRESETS]
+    metas = list(metas)
+    while len(metas) < hps.n_samples:
+        metas.extend(metas)
+    metas = metas[:hps.n_samples]
+    labels = [prior.labeller.get_batch_labels(metas, device) for prior in priors]
+    for label in labels:
+        assert label["y"].shape[0] == hps.n_samples
+    sampling_kwargs = default_sampling_kwargs(model)
+    top_raw_to_tokens = priors[-1].raw_to_tokens
+    prompt_s = sample_hps.get("prompt_length_in_seconds")
+    mode = sample_hps.mode
+    if mode == "ancestral":
+        return ancestral_sample(labels, sampling_kwargs, priors, hps, device=device)
+    if mode in ("continue", "upsample"):
+        assert sample_hps.get("codes_file") is not None
+        duration = None if prompt_s is None else (int(prompt_s * hps.sr) // top_raw_to_tokens) * top_raw_to_tokens
+        zs = load_codes(sample_hps.codes_file, duration, priors, hps, device=device)
+        fn = continue_sample if mode == "continue" else upsample
+        return fn(zs, labels, sampling_kwargs, priors, hps, device=device)
+    if mode == "primed":
+        assert sample_hps.get("audio_file") is not None
+        assert prompt_s is not None
+        duration = (int(prompt_s * hps.sr) // top_raw_to_tokens) * top_raw_to_tokens
+        x = load_prompts(sample_hps.audio_file.split(","), duration, hps, device=device)
+        return primed_sample(x, labels, sampling_kwargs, priors, hps, device=device)
+    raise ValueError(f"Unknown sample mode {mode}.")
+
+
+def run(model, mode="ancestral", codes_file=None, audio_file=None, prompt_length_in_seconds=None, port=29500, **kwargs):
+    """sample.py:264-271.  Ranks come from the torchrun environment (one process per GPU) instead of MPI; `port` is
+    accepted for compatibility (the rendezvous port is torchrun's MASTER_PORT)."""
+    from .utils.dist_utils import setup_dist_from_env
+    rank, local_rank, device = setup_dist_from_env()
+    hps = Hyperparams(**kwargs)
+    sample_hps = Hyperparams(dict(mode=mode, codes_file=codes_file, audio_file=audio_file,
+                                  prompt_length_in_seconds=prompt_length_in_seconds))
+    with t.no_grad():
+        return save_samples(model, device, hps, sample_hps)
+
+
+def _argv_kwargs(argv):
+    """`--key=value` / `--key value` pairs with Python-literal values (what fire.Fire(run) accepts for this script)."""
+    import ast
+    out, i = {}, 0
+    while i < len(argv):
+        assert argv[i].startswith("--"), f"expected --key=value, got {argv[i]}"
+        if "=" in argv[i]:
+            k, v = argv[i][2:].split("=", 1)
+        else:
+            k, v = argv[i][2:], argv[i + 1]
+            i += 1
+        try:
+            out[k] = ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            out[k] = v
+        i += 1
+    return out
+
+
+if __name__ == "__main__":
+    import sys
+    run(**_argv_kwargs(sys.argv[1:]))

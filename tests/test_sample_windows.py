@@ -211,3 +211,67 @@ def test_sharded_sampler_two_gloo_ranks(tmp_path):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+class _DummyLabeller:
+    def get_batch_labels(self, metas, device="cpu"):
+        n = len(metas)
+        y = t.zeros((n, 5), dtype=t.long)
+        y[:, 0] = t.tensor([m["total_length"] for m in metas])
+        y[:, 1] = t.tensor([m["offset"] for m in metas])
+        y[:, 3] = t.arange(n)
+        return dict(y=y.to(device), info=[dict(full_tokens=[]) for _ in metas])
+
+
+@pytest.mark.parametrize("mode", ["ancestral", "continue", "upsample", "primed"])
+def test_save_samples_modes(mode, tmp_path, monkeypatch):
+    """save_samples / run plumbing (sample.py:178-271): preset metas tiled to the batch, mode dispatch, prompt-length
+    rounding to the top level's hop, codes file and prompt audio loading -- with the fake priors standing in for models."""
+    import numpy as np
+    from scipy.io import wavfile
+    from jukebox_amd import make_models
+    n, top = 3, 8192 + 1024
+    priors, hps, labels, sk = make_setup(n, top)
+    for p in priors:
+        p.labeller = _DummyLabeller()
+        p.encode = lambda x, start_level=0, end_level=3, bs_chunks=1: [
+            f(l, t.arange(x.shape[0]), t.arange(x.shape[1] // (8 * 4 ** l))) for l in range(start_level, end_level)]
+    monkeypatch.setattr(S, "default_sampling_kwargs", lambda model: [dict(max_batch_size=3) for _ in range(3)])
+
+    def fake_make_model(model, device, h, levels=None):
+        h.sample_length = top * 128
+        return None, priors
+    monkeypatch.setattr(make_models, "make_model", fake_make_model)
+    hps = Hyperparams(n_samples=n, sr=44100, total_sample_length_in_seconds=600, hop_fraction=[0.5, 0.5, 0.125],
+                      name=str(tmp_path / "out"), levels=3)
+    prompt_s = 2000 * 128 / 44100 + 0.001                 # rounds down to 2000 top-level tokens
+    ids = t.arange(n)
+    sample_hps = Hyperparams(mode=mode, prompt_length_in_seconds=None, codes_file=None, audio_file=None)
+    if mode in ("continue", "upsample"):
+        given = 3000 if mode == "continue" else top
+        zs0 = [f(l, ids, t.arange(given * 4 ** (2 - l))) for l in range(3)]
+        if mode == "upsample":
+            zs0 = [zs0[0][:, :0], zs0[1][:, :0], zs0[2]]      # only the top level exists
+        t.save(dict(zs=zs0), tmp_path / "codes.pth.tar")
+        sample_hps.codes_file = str(tmp_path / "codes.pth.tar")
+        if mode == "continue":
+            sample_hps.prompt_length_in_seconds = prompt_s
+    if mode == "primed":
+        rng = np.random.default_rng(0)
+        wav = (rng.uniform(-0.5, 0.5, (2000 * 128 + 4000, 2)) * 32767).astype(np.int16)
+        for i in range(2):
+            wavfile.write(tmp_path / f"p{i}.wav", 44100, wav)
+        sample_hps.audio_file = f"{tmp_path}/p0.wav,{tmp_path}/p1.wav"
+        sample_hps.prompt_length_in_seconds = prompt_s
+        x = S.load_prompts(sample_hps.audio_file.split(","), 2000 * 128, hps, device="cpu")
+        assert tuple(x.shape) == (n, 2000 * 128, 1) and x.dtype == t.float32
+        assert np.allclose(x[0, :, 0].numpy(), wav[:2000 * 128].astype(np.float32).mean(1) / 32768.0, atol=1e-7)
+        assert t.equal(x[0], x[2])                        # files repeat to fill the batch
+    zs = S.save_samples("1b_lyrics", "cpu", hps, sample_hps)
+    check_levels(zs, n, top)
+    if mode == "continue":                                # the codes were cut to the prompt length before continuing
+        assert min(c[1] for c in priors[2].calls) == 2000
+    if mode == "upsample":
+        assert priors[2].calls == []
+    with pytest.raises(ValueError, match="Unknown sample mode"):
+        S.save_samples("1b_lyrics", "cpu", hps, Hyperparams(mode="nope"))
