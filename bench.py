@@ -203,8 +203,13 @@ def main():
     def one_step():
         return S.ancestral_sample(labels, sk, priors, hps, save=False, device=device)
 
+    # Warm-up passes are untimed: they run the same three-level job on 6 s of audio (every kernel, graph capture and
+    # allocation of the timed step, 1/3 of its length) so that `--warmup W` does not cost W x 5 minutes.
+    warm_len = min(sample_length, int(6.0 * sr) // hop * hop) if not tiny else sample_length
+    warm_hps = Hyperparams(hps)
+    warm_hps.sample_length = warm_len
     for _ in range(a.warmup):
-        one_step()
+        S.ancestral_sample(labels, sk, priors, warm_hps, save=False, device=device)
     level_t.clear()
     if world > 1:
         torch.distributed.barrier()
