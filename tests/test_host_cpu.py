@@ -152,3 +152,30 @@ def test_released_parameter_trees():
         assert len(got[nm]) == len(want[nm]), (nm, len(got[nm]), len(want[nm]))
         for g, w in zip(got[nm], want[nm]):
             assert g == w, (nm, g, w)
+
+
+def test_no_cpu_fallback_and_reference_error_messages(tiny_hps, monkeypatch):
+    """The product path has no CPU route: sampling a prior that sits on the CPU raises, a missing shared library raises
+    when first needed, and the argument checks keep the reference's assert messages (prior.py:248-252,
+    autoregressive.py:205-216)."""
+    from jukebox_amd import _lib as L
+    vq, priors = _tiny_models(tiny_hps)
+    top = priors[2]
+    n = 3
+    y = torch.zeros((n, 4 + top.y_emb.max_bow_genre_size + top.n_tokens), dtype=torch.long)
+    y[:, 0], y[:, 2] = 10 ** 6, top.sample_length
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        top.sample(n, z=torch.zeros((n, 0), dtype=torch.long), y=y, top_k=1)
+    with pytest.raises(AssertionError, match=r"Expected shape \(3,\*\*\), got shape"):
+        top.sample(n, z=torch.zeros((n + 1, 0), dtype=torch.long), y=y)
+    with pytest.raises(AssertionError, match=r"Expected shape \(3,\*\*\), got shape"):
+        top.sample(n, z=torch.zeros((n, 0), dtype=torch.long), y=y[:2])
+    # host wrappers refuse CPU tensors instead of computing on them
+    from jukebox_amd import hip_ops as H
+    with pytest.raises((L.JukeboxHipError, AssertionError, RuntimeError)):
+        H.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+    # a missing library is an error at first use, not a silent fallback
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", os.path.join(ROOT, "jukebox_amd", "csrc", "does_not_exist.so"))
+    with pytest.raises(L.JukeboxHipError, match="no CPU fallback"):
+        L.lib()
