@@ -114,6 +114,27 @@ int jb_gemv(const jb_gemv_args* args /* host */, void* stream);
 /* 1 if jb_gemv accepts ln_fold_c1 for this problem (whole k-tiles, the rows' operand fragments fit in registers). */
 int jb_gemv_ln_fold_supported(int dtype, int K, int J, int n_rows);
 
+/* EXPERIMENTAL (decode step with jb_engine_cfg.fused_pairs): two dependent projections in one launch, fp16, n_rows <= 16.
+ *   part A (J_a/16 workgroups):  out_a = res + in1 . Wa + bias_a                   -- a residual row, tile by tile; each
+ *                                tile publishes its per-row (sum, sum of squares) into `stats`, tagged with *epoch_dev;
+ *   part B (J_b/16 workgroups):  out_b = act(rstd * ([in0 | in1] . Wb + k_b - mean * c1_b) + bias_b)
+ *                                with mean / rstd of the out_a rows (LayerNorm folded: Wb = [diag(gamma).W ; Wa.diag(gamma).W],
+ *                                k_b = bias_a . diag(gamma).W, c1_b = column sums of diag(gamma).W, bias_b = beta.W + b).
+ * stats: J_a/16 x 16 x 2 64-bit words, zero-initialised; *epoch_dev must differ between successive launches that
+ * share a stats buffer (never 0).  *error_flag is set if a part-B workgroup gave up waiting for statistics. */
+typedef struct jb_gemv_pair_args {
+    int n_rows;
+    const void* in1; int64_t ld1; int K1;
+    const void* Wa; const float* bias_a; const void* res; int64_t ldr; void* out_a; int64_t ldo_a; int J_a;
+    const void* in0; int64_t ld0; int K0;
+    const void* Wb; const float* k_b; const float* c1_b; const float* bias_b; int J_b; int act;
+    void* out_b; int64_t ldo_b;
+    int qkv_split, S; void* kcache; void* vcache; int cache_cap; const int* t_dev;
+    float ln_eps;
+    void* stats; const unsigned* epoch_dev; int* error_flag;
+} jb_gemv_pair_args;
+int jb_gemv_pair(const jb_gemv_pair_args* args /* host */, void* stream);
+
 /* Single-query cached attention for the decode step: one workgroup per (sample, head); the key
  * set is derived on the device from *t_dev and the pattern, softmax in fp32.
  * Replaces FactoredAttention.forward(sample=True) with q_l == 1: factored_qkv/prime_qkv cache slicing +
@@ -197,6 +218,11 @@ typedef struct jb_layer {
      * diag(gamma)·W, beta·W + b, column sums.  NULL = the decode step normalises rows in the projection kernel.
      * Prefill always uses w_attn / w_fc with an explicit LayerNorm. */
     const void *w_attn_f, *w_fc_f; const float *b_attn_f, *b_fc_f, *c1_attn, *c1_fc;
+    /* EXPERIMENTAL, jb_engine_cfg.fused_pairs (see jb_gemv_pair): packed [diag(g1).Wfc ; Wproj.diag(g1).Wfc]
+     * (K = width + n_state, J = n_mlp) with k_f = b_proj.diag(g1).Wfc, and -- except in the last layer -- packed
+     * [diag(g0').Wattn' ; Wproj2.diag(g0').Wattn'] of the NEXT layer (K = width + n_mlp, J = 3 n_state) with
+     * k_a = b_proj2.diag(g0').Wattn'; stats_1 / stats_2: (width/16) x 16 x 2 64-bit words each, zeroed. */
+    const void *w_pf, *w_2a; const float *k_f, *k_a; void *stats_1, *stats_2;
 } jb_layer;
 
 typedef struct jb_engine_cfg {
@@ -211,6 +237,10 @@ typedef struct jb_engine_cfg {
     const void* encoder_kv; int enc_len;                   /* [n][enc_len][width], engine dtype (cross-attention models) */
     float* hidden_out; int64_t hidden_n_stride;            /* optional: final hidden states of prefilled positions, fp32 [n][seq_len][width] */
     int prefetch_next_weights;                             /* decode step: each projection touches the next one's weights */
+    /* EXPERIMENTAL: decode step with 3 launches per layer (attention | c_proj + c_fc | mlp.c_proj + next c_attn), fp16,
+     * n_batch <= 16, no cross-attention layers; needs the folded images and jb_layer.w_pf / w_2a of every layer.
+     * epoch_dev: device counter, >= 1, advanced by the engine every step; pair_error: device flag (see jb_gemv_pair). */
+    int fused_pairs; unsigned* epoch_dev; int* pair_error;
     /* decode-step work buffers */
     void *x_a, *x_b, *q, *att, *mlp;                        /* engine dtype: [n][W],[n][W],[n][S],[n][S],[n][M] */
     float *xf, *logits;                                    /* [n][W], [n][bins] */

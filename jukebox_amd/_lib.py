@@ -34,6 +34,16 @@ class GemvArgs(C.Structure):
                 ("ln_fold_c1", vp)]
 
 
+class GemvPairArgs(C.Structure):
+    _fields_ = [("n_rows", i32), ("in1", vp), ("ld1", i64), ("K1", i32),
+                ("Wa", vp), ("bias_a", vp), ("res", vp), ("ldr", i64), ("out_a", vp), ("ldo_a", i64), ("J_a", i32),
+                ("in0", vp), ("ld0", i64), ("K0", i32),
+                ("Wb", vp), ("k_b", vp), ("c1_b", vp), ("bias_b", vp), ("J_b", i32), ("act", i32),
+                ("out_b", vp), ("ldo_b", i64),
+                ("qkv_split", i32), ("S", i32), ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp),
+                ("ln_eps", f32), ("stats", vp), ("epoch_dev", vp), ("error_flag", vp)]
+
+
 class SampleParams(C.Structure):
     _fields_ = [("temp", f32), ("top_k", i32), ("top_p", f32), ("sample_base", i32), ("seed", C.c_uint64)]
 
@@ -43,7 +53,8 @@ class Layer(C.Structure):
                 ("b_attn", vp), ("b_proj", vp), ("b_fc", vp), ("b_proj2", vp),
                 ("ln0_g", vp), ("ln0_b", vp), ("ln1_g", vp), ("ln1_b", vp),
                 ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("w_enc_k", vp), ("w_enc_v", vp), ("b_enc_kv", vp),
-                ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp)]
+                ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp),
+                ("w_pf", vp), ("w_2a", vp), ("k_f", vp), ("k_a", vp), ("stats_1", vp), ("stats_2", vp)]
 
 
 class EngineCfg(C.Structure):
@@ -51,7 +62,7 @@ class EngineCfg(C.Structure):
                 ("n_layers", i32), ("seq_len", i32), ("block_ctx", i32), ("bins", i32), ("ln_eps", f32),
                 ("x_emb", vp), ("pos_emb", vp), ("x_out_packed", vp), ("start", vp), ("start_stride", i64),
                 ("x_cond", vp), ("xc_n_stride", i64), ("xc_t_stride", i64), ("add_cond_after", i32), ("encoder_kv", vp), ("enc_len", i32), ("hidden_out", vp), ("hidden_n_stride", i64),
-                ("prefetch_next_weights", i32),
+                ("prefetch_next_weights", i32), ("fused_pairs", i32), ("epoch_dev", vp), ("pair_error", vp),
                 ("x_a", vp), ("x_b", vp), ("q", vp), ("att", vp), ("mlp", vp), ("xf", vp), ("logits", vp),
                 ("chunk_cap", i32), ("c_xa", vp), ("c_xb", vp), ("c_h", vp), ("c_q", vp), ("c_att", vp),
                 ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
@@ -71,6 +82,7 @@ _SIGS = {
     "jb_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "jb_gemv": (i32, [C.POINTER(GemvArgs), vp]),
     "jb_gemv_ln_fold_supported": (i32, [i32, i32, i32, i32]),
+    "jb_gemv_pair": (i32, [C.POINTER(GemvPairArgs), vp]),
     "jb_attn_decode": (i32, [i32, i32, vp, i64, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "jb_tune_attn_decode": (None, [i32, i32]),
     "jb_tune_attn_decode_parts": (None, [i32]),

@@ -20,6 +20,7 @@ struct JbEngine {
 
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 __global__ void inc_int_kernel(int* p) { *p += 1; }
+__global__ void inc_step_kernel(int* t, unsigned* epoch) { *t += 1; *epoch += 1; }
 
 extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers, void** handle) {
     JB_REQUIRE(cfg && layers && handle, "null pointer");
@@ -51,6 +52,18 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
                         jb_gemv_ln_fold_supported(cfg->dtype, cfg->width, cfg->n_mlp, cfg->n_batch)),
                    "folded LayerNorm image of mlp.c_fc is incomplete or unsupported for this shape");
     }
+    if (cfg->fused_pairs) {
+        JB_REQUIRE(cfg->dtype == JB_F16 && cfg->n_batch <= 16 && cfg->epoch_dev && cfg->pair_error,
+                   "fused_pairs needs an fp16 engine with n_batch <= 16, epoch_dev and pair_error");
+        JB_REQUIRE(cfg->width % 32 == 0 && cfg->n_state % 32 == 0 && cfg->n_mlp % 32 == 0 && cfg->width <= 2048 &&
+                       cfg->n_mlp <= 2048 && cfg->width + cfg->n_mlp <= 4096, "fused_pairs: unsupported dims");
+        for (int l = 0; l < cfg->n_layers; ++l) {
+            const jb_layer& L = layers[l];
+            JB_REQUIRE(L.attn_func != 6, "fused_pairs: cross-attention layers are not supported");
+            JB_REQUIRE(L.w_attn_f && L.w_fc_f && L.w_pf && L.k_f && L.stats_1 && L.stats_2 &&
+                           (l + 1 == cfg->n_layers || (L.w_2a && L.k_a)), "fused_pairs: incomplete layer images");
+        }
+    }
     JB_REQUIRE(!cfg->rec_out || (cfg->rec_layer >= 0 && cfg->rec_layer < cfg->n_layers && cfg->rec_keys > 0 &&
                                  cfg->rec_head >= 0 && cfg->rec_head < cfg->n_head), "bad attention recording request");
     JbEngine* e = new JbEngine();
@@ -72,7 +85,8 @@ extern "C" int jb_engine_destroy(void* handle) {
 
 extern "C" int jb_engine_launches_per_step(void* handle) {
     if (!handle) return 0;
-    return 5 * ((JbEngine*)handle)->cfg.n_layers + 5;
+    const jb_engine_cfg& c = ((JbEngine*)handle)->cfg;
+    return c.fused_pairs ? 3 * c.n_layers + 6 : 5 * c.n_layers + 5;
 }
 
 #define JB_TRY(call)                \
@@ -94,8 +108,65 @@ static void fill_ln_proj(jb_gemv_args& g, const jb_engine_cfg& c, const jb_layer
     }
 }
 
+// EXPERIMENTAL decode step with 3 launches per layer (cfg.fused_pairs; see jb_gemv_pair):
+//   embed | c_attn(0) | L x [attention | c_proj + c_fc | mlp.c_proj + c_attn(next)] | (+cond) | logits | sample | t, epoch += 1
+static int enqueue_step_pairs(JbEngine* e, hipStream_t s) {
+    const jb_engine_cfg& c = e->cfg;
+    const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
+    JB_TRY(jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
+                    c.xc_n_stride, c.xc_t_stride, N, W, 0, c.t_dev, 1, s));
+    {
+        const jb_layer& L = e->layers[0];
+        jb_gemv_args g = {};
+        fill_ln_proj(g, c, L, 0);
+        g.x = c.x_a; g.out = c.q; g.ldo = S; g.J = 3 * S;
+        g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
+        JB_TRY(jb_gemv(&g, s));
+    }
+    for (int l = 0; l < c.n_layers; ++l) {
+        const jb_layer& L = e->layers[l];
+        JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
+                              c.block_ctx, c.t_dev, c.seq_len, s));
+        jb_gemv_pair_args a = {};
+        a.n_rows = N; a.ln_eps = c.ln_eps; a.epoch_dev = c.epoch_dev; a.error_flag = c.pair_error; a.t_dev = c.t_dev;
+        // x_b = x_a + att.Wproj + b  |  mlp = gelu(LN1(x_b).Wfc + b) from (x_a, att)
+        a.in1 = c.att; a.ld1 = S; a.K1 = S;
+        a.Wa = L.w_proj; a.bias_a = L.b_proj; a.res = c.x_a; a.ldr = W; a.out_a = c.x_b; a.ldo_a = W; a.J_a = W;
+        a.in0 = c.x_a; a.ld0 = W; a.K0 = W;
+        a.Wb = L.w_pf; a.k_b = L.k_f; a.c1_b = L.c1_fc; a.bias_b = L.b_fc_f; a.J_b = M; a.act = JB_ACT_QUICK_GELU;
+        a.out_b = c.mlp; a.ldo_b = M; a.stats = L.stats_1;
+        JB_TRY(jb_gemv_pair(&a, s));
+        // x_a = x_b + mlp.Wproj2 + b  |  q, k, v of the next layer = LN0'(x_a).Wattn' + b from (x_b, mlp)
+        a = {};
+        a.n_rows = N; a.ln_eps = c.ln_eps; a.epoch_dev = c.epoch_dev; a.error_flag = c.pair_error; a.t_dev = c.t_dev;
+        a.in1 = c.mlp; a.ld1 = M; a.K1 = M;
+        a.Wa = L.w_proj2; a.bias_a = L.b_proj2; a.res = c.x_b; a.ldr = W; a.out_a = c.x_a; a.ldo_a = W; a.J_a = W;
+        a.stats = L.stats_2;
+        if (l + 1 < c.n_layers) {
+            const jb_layer& Ln = e->layers[l + 1];
+            a.in0 = c.x_b; a.ld0 = W; a.K0 = W;
+            a.Wb = L.w_2a; a.k_b = L.k_a; a.c1_b = Ln.c1_attn; a.bias_b = Ln.b_attn_f; a.J_b = 3 * S; a.act = JB_ACT_NONE;
+            a.out_b = c.q; a.ldo_b = S;
+            a.qkv_split = 1; a.S = S; a.kcache = Ln.kcache; a.vcache = Ln.vcache; a.cache_cap = Ln.cache_cap;
+        }
+        JB_TRY(jb_gemv_pair(&a, s));
+    }
+    JB_TRY(jb_final_add(c.dtype, c.x_a, c.xf, 0, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride, c.xc_t_stride, N, W,
+                        0, c.t_dev, 1, s));
+    jb_gemv_args g = {};
+    g.dtype = JB_F32; g.x = c.xf; g.ldx = W; g.n_rows = N; g.W = c.x_out_packed; g.K = W; g.J = c.bins;
+    g.out = c.logits; g.ldo = c.bins;
+    JB_TRY(jb_gemv(&g, s));
+    JB_TRY(jb_sample_logits(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds,
+                            c.preds_n_stride, s));
+    inc_step_kernel<<<1, 1, 0, s>>>(c.t_dev, c.epoch_dev);
+    JB_CHECK_LAUNCH();
+    return JB_OK;
+}
+
 // One decode step at position *t_dev; everything position-dependent is read on the device.
 static int enqueue_step(JbEngine* e, hipStream_t s) {
+    if (e->cfg.fused_pairs) return enqueue_step_pairs(e, s);
     const jb_engine_cfg& c = e->cfg;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
     JB_TRY(jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,

@@ -907,6 +907,197 @@ static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
     return nw == 8 ? launch_gemv_nw<T, 8, false>(p, njt, lds, s) : launch_gemv_nw<T, 4, false>(p, njt, lds, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (off by default, jb_engine_cfg.fused_pairs): two dependent projections of the decode step in ONE launch.
+//
+// With LayerNorm folded, the projection after a residual add can be formed from the operands of the add:
+//     x_b = x + a.Wp + bp            (part A: residual-row tiles)
+//     LN(x_b).Wf + bf = rstd * (x.W' + a.(Wp.W') + bp.W' - mean * c1) + b'      (part B: projection tiles)
+// Part B needs x_b only through its row statistics.  Workgroups [0, nA) each produce one 16-column tile of the residual
+// row and publish the tile's per-row (sum, sum of squares) as two self-tagged 64-bit words (value | step tag, written
+// with agent-scope sc1 stores: visible across the 8 XCD L2s, verified by tools/grid_sync_probe.hip).  Workgroups
+// [nA, nA+nB) stream their larger weight slice -- [W' ; Wp.W'] packed as one K0+K1 matrix -- over the concatenated
+// input [x | a] meanwhile, then collect the nA partials (an optimistic fetch is issued with the first loads and
+// re-polled only where the tag is stale), normalise in the epilogue and apply bias / quick_gelu / the q-k-v split.
+// Workgroups are dispatched in block order, so a resident part-B workgroup never waits for a part-A workgroup that
+// cannot be scheduled; the poll is bounded and reports through *error_flag instead of hanging.
+struct PairParams {
+    int n_rows, nA, nB;
+    const f16* in1; int64_t ld1; int nkt1;
+    const f16* Wa; const float* bias_a; const f16* res; int64_t ldr; f16* out_a; int64_t ldo_a; int J_a;
+    const f16* in0; int64_t ld0; int nkt0;
+    const f16* Wb; const float* k_b; const float* c1_b;
+    float ln_eps;
+    unsigned long long* stats; const unsigned* epoch_dev; int* error_flag;
+    const int* t_dev;
+    EpiParams epi;       // part B output
+};
+
+__device__ __forceinline__ unsigned long long jb_tagged(float v, unsigned tag) {
+    return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+__global__ __launch_bounds__(512) void gemv_pair_kernel(PairParams p) {
+    using V = f16x8;
+    constexpr int E = 8, KT = 32, NW = 8;
+    __shared__ __attribute__((aligned(16))) f32x4 s_acc[NW * 64];
+    __shared__ float s_red[16 * 32];
+    __shared__ float s_tot[32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int rowc = min(c, p.n_rows - 1);
+    const unsigned epoch = *p.epoch_dev;
+    // this thread's output element (threads < 256): row = lane & 15, column = tile*16 + (lane >> 4)*4 + wave
+    const int erow = c, ecol = g * 4 + (wave & 3);
+
+    if (blockIdx.x < p.nA) {
+        // ---------------- part A: out_a tile = res + in1 . Wa + bias_a, statistics of the stored tile ----------------
+        const int jt = blockIdx.x;
+        const int kt0 = (wave * p.nkt1) / NW, kt1 = ((wave + 1) * p.nkt1) / NW;
+        V xf[8], wf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kt = min(kt0 + i, p.nkt1 - 1);
+            xf[i] = ld_frag<f16>(p.in1 + (int64_t)rowc * p.ld1 + kt * KT + g * E);
+            wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(p.Wa + (((int64_t)jt * p.nkt1 + kt) * 64 + lane) * E));
+        }
+        const int j = jt * 16 + ecol;
+        const float e_bias = p.bias_a ? p.bias_a[j] : 0.f;
+        const float e_res = (float)p.res[(int64_t)rowc * p.ldr + j];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = jb_mfma(wf[i], keep_frag<f16>(kt0 + i < kt1, xf[i]), acc);
+        s_acc[wave * 64 + lane] = acc;
+        __syncthreads();
+        float s1 = 0.f, s2 = 0.f;
+        if (tid < 256) {
+            const float* sa = reinterpret_cast<const float*>(s_acc);
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += sa[(w * 64 + lane) * 4 + (wave & 3)];
+            if (p.bias_a) v += jb_round<f16>(e_bias);
+            v = jb_round<f16>(v);
+            v = jb_round<f16>(e_res + v);
+            if (erow < p.n_rows) {
+                p.out_a[(int64_t)erow * p.ldo_a + j] = (f16)v;
+                s1 = v; s2 = v * v;
+            }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (g == 0) { s_red[(wave * 16 + c) * 2] = s1; s_red[(wave * 16 + c) * 2 + 1] = s2; }
+        }
+        __syncthreads();
+        if (tid < 32) {                      // tid = row*2 + which
+            const int row = tid >> 1, which = tid & 1;
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot += s_red[(w * 16 + row) * 2 + which];
+            __hip_atomic_store(p.stats + ((int64_t)jt * 16 + row) * 2 + which, jb_tagged(tot, epoch), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    // ---------------- part B: out_b tile = act(rstd * (in0.Wb[:K0] + in1.Wb[K0:] + k - mean*c1) + bias) ----------------
+    const int jt = blockIdx.x - p.nA;
+    const int nkt = p.nkt0 + p.nkt1;
+    const int kt0 = (wave * nkt) / NW, kt1 = ((wave + 1) * nkt) / NW;
+    V xf[16], wf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int kt = min(kt0 + i, nkt - 1);
+        const f16* src = kt < p.nkt0 ? p.in0 + (int64_t)rowc * p.ld0 + kt * KT : p.in1 + (int64_t)rowc * p.ld1 + (kt - p.nkt0) * KT;
+        xf[i] = ld_frag<f16>(src + g * E);
+        wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(p.Wb + (((int64_t)jt * nkt + kt) * 64 + lane) * E));
+    }
+    const int j = jt * 16 + ecol, jc = min(j, p.epi.J - 1);
+    const float e_bias = p.epi.bias ? p.epi.bias[jc] : 0.f;
+    const float e_c1 = p.c1_b[jc];
+    const float e_k = p.k_b ? p.k_b[jc] : 0.f;
+    int t = 0;
+    if (p.epi.qkv_split) t = *p.t_dev;
+    // optimistic fetch of the statistics slots this thread sums: (row, which) = tid & 31, tiles (tid >> 5) + 16 u
+    const int rw = tid & 31, tile0 = tid >> 5;
+    unsigned long long sv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int tile = min(tile0 + 16 * u, p.nA - 1);
+        sv[u] = __hip_atomic_load(p.stats + (int64_t)tile * 32 + rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc = jb_mfma(wf[i], keep_frag<f16>(kt0 + i < kt1, xf[i]), acc);
+    s_acc[wave * 64 + lane] = acc;
+    float part = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int tile = tile0 + 16 * u;
+        if (tile < p.nA) {
+            unsigned spins = 0;
+            while ((unsigned)(sv[u] >> 32) != epoch) {
+                if (++spins > (1u << 20)) { *p.error_flag = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+                sv[u] = __hip_atomic_load(p.stats + (int64_t)tile * 32 + rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            part += __uint_as_float((unsigned)sv[u]);
+        }
+    }
+    s_red[tile0 * 32 + rw] = part;
+    __syncthreads();
+    if (tid < 32) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += s_red[k * 32 + tid];
+        s_tot[tid] = tot;
+    }
+    __syncthreads();
+    if (tid < 256 && erow < p.n_rows && j < p.epi.J) {
+        const float* sa = reinterpret_cast<const float*>(s_acc);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += sa[(w * 64 + lane) * 4 + (wave & 3)];
+        const float inv_k = 1.0f / (float)p.J_a;
+        const float mean = s_tot[erow * 2] * inv_k;
+        const float var = fmaxf(s_tot[erow * 2 + 1] * inv_k - mean * mean, 0.f);
+        v = (v + e_k - mean * e_c1) / sqrtf(var + p.ln_eps);
+        const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)erow * p.epi.cache_cap + t : -1;
+        epilogue_store1<f16>(p.epi, v, erow, j, cache_row, e_bias, 0.f);
+    }
+}
+
+extern "C" int jb_gemv_pair(const jb_gemv_pair_args* a, void* stream) {
+    JB_REQUIRE(a && a->in1 && a->Wa && a->res && a->out_a && a->stats && a->epoch_dev && a->error_flag, "null pointer");
+    JB_REQUIRE(a->n_rows >= 1 && a->n_rows <= 16, "n_rows must be 1..16");
+    JB_REQUIRE(a->K1 > 0 && a->K1 % 32 == 0 && a->K1 <= 2048, "K1 must be a multiple of 32, <= 2048");
+    JB_REQUIRE(a->J_a > 0 && a->J_a % 16 == 0 && a->J_a / 16 <= 128, "J_a must be a multiple of 16, <= 2048");
+    JB_REQUIRE(a->ld1 % 8 == 0 && a->ldr % 1 == 0 && aligned_to(a->in1, 16), "in1 rows must be 16-byte aligned");
+    PairParams p = {};
+    p.n_rows = a->n_rows; p.nA = a->J_a / 16;
+    p.in1 = (const f16*)a->in1; p.ld1 = a->ld1; p.nkt1 = a->K1 / 32;
+    p.Wa = (const f16*)a->Wa; p.bias_a = a->bias_a; p.res = (const f16*)a->res; p.ldr = a->ldr;
+    p.out_a = (f16*)a->out_a; p.ldo_a = a->ldo_a; p.J_a = a->J_a;
+    p.stats = (unsigned long long*)a->stats; p.epoch_dev = a->epoch_dev; p.error_flag = a->error_flag;
+    p.ln_eps = a->ln_eps; p.t_dev = a->t_dev;
+    p.nB = 0;
+    if (a->J_b > 0) {
+        JB_REQUIRE(a->in0 && a->Wb && a->c1_b && a->out_b, "null pointer (part B)");
+        JB_REQUIRE(a->K0 > 0 && a->K0 % 32 == 0 && a->K0 + a->K1 <= 4096, "K0 must be a multiple of 32, K0 + K1 <= 4096");
+        JB_REQUIRE(a->ld0 % 8 == 0 && aligned_to(a->in0, 16), "in0 rows must be 16-byte aligned");
+        JB_REQUIRE(!a->qkv_split || (a->S > 0 && a->J_b == 3 * a->S && a->kcache && a->vcache && a->t_dev), "bad qkv split");
+        p.nB = (a->J_b + 15) / 16;
+        p.in0 = (const f16*)a->in0; p.ld0 = a->ld0; p.nkt0 = a->K0 / 32;
+        p.Wb = (const f16*)a->Wb; p.k_b = a->k_b; p.c1_b = a->c1_b;
+        p.epi.bias = a->bias_b; p.epi.out = a->out_b; p.epi.ldo = a->ldo_b; p.epi.res = nullptr; p.epi.ldr = 0;
+        p.epi.J = a->J_b; p.epi.act = a->act; p.epi.res_scale = 1.0f;
+        p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
+        p.epi.cache_cap = a->cache_cap; p.epi.vec_out = 0;
+    }
+    gemv_pair_kernel<<<p.nA + p.nB, 512, 0, (hipStream_t)stream>>>(p);
+    JB_CHECK_LAUNCH();
+    return JB_OK;
+}
+
 #ifdef JB_TIMING
 long long* jb_dbg_ptr = nullptr;
 extern "C" void jb_set_dbg(long long* p) { jb_dbg_ptr = p; }

@@ -41,7 +41,7 @@ class PriorEngine:
     def __init__(self, sd, prefix, *, n_batch, seq_len, bins, width, depth, heads, attn_order, blocks=None,
                  m_attn=0.25, m_mlp=1.0, prime_len=None, y_cond=False, add_cond_after=True, fp16=True,
                  chunk_cap=256, want_preds=False, record=None, encoder_dims=0, only_encode=False, fold_ln=None,
-                 device="cuda"):
+                 fused_pairs=None, device="cuda"):
         L.lib()
         self.device = torch.device(device)
         self.N, self.T, self.bins, self.W = n_batch, seq_len, bins, width
@@ -59,6 +59,12 @@ class PriorEngine:
         if fold_ln is None:
             fold_ln = bool(int(os.environ["JB_FOLD_LN"])) if "JB_FOLD_LN" in os.environ else fp16
         self.fold_ln = bool(fold_ln) and not only_encode
+        # EXPERIMENTAL (JB_FUSED_PAIRS=1): decode step with 3 launches per layer (jb_gemv_pair).  A part-B workgroup
+        # waits in-kernel for part-A workgroups of the same launch, so at most ONE engine per GPU may run in this mode
+        # while other streams keep the chip busy (two such kernels oversubscribing the CUs could wait on each other).
+        if fused_pairs is None:
+            fused_pairs = bool(int(os.environ.get("JB_FUSED_PAIRS", "0")))
+        self.fused_pairs = bool(fused_pairs) and self.fold_ln and fp16 and n_batch <= 16
         dev, dt = self.device, self.dtype
         g = lambda name: sd[prefix + name].to(dev).contiguous()
         f32 = lambda name: g(name).float().contiguous()
@@ -99,16 +105,33 @@ class PriorEngine:
             lc.b_attn, lc.b_proj, lc.b_fc, lc.b_proj2 = (b.data_ptr() for b in bs)
             lc.ln0_g, lc.ln0_b, lc.ln1_g, lc.ln1_b = (t.data_ptr() for t in lns)
             lc.kcache, lc.vcache, lc.cache_cap = kc.data_ptr(), vc.data_ptr(), cap
+            f_attn = f_fc = None
             if self.fold_ln:
                 j_attn = S if func == 6 else 3 * S
                 if H.ln_fold_supported(dt, W, j_attn, N):
-                    f = H.FoldedLN(g(p + "attn.c_attn.w"), bs[0], lns[0], lns[1], dt)
+                    f_attn = f = H.FoldedLN(g(p + "attn.c_attn.w"), bs[0], lns[0], lns[1], dt)
                     lc.w_attn_f, lc.b_attn_f, lc.c1_attn = f.pw.ptr, f.bias.data_ptr(), f.c1.data_ptr()
                     self._keep.append(f)
                 if H.ln_fold_supported(dt, W, M, N):
-                    f = H.FoldedLN(g(p + "mlp.c_fc.w"), bs[2], lns[2], lns[3], dt)
+                    f_fc = f = H.FoldedLN(g(p + "mlp.c_fc.w"), bs[2], lns[2], lns[3], dt)
                     lc.w_fc_f, lc.b_fc_f, lc.c1_fc = f.pw.ptr, f.bias.data_ptr(), f.c1.data_ptr()
                     self._keep.append(f)
+            if self.fused_pairs:
+                if func == 6 or f_attn is None or f_fc is None:
+                    raise L.JukeboxHipError("fused_pairs needs folded c_attn / c_fc images and no cross-attention layers")
+                pf = H.FusedPair(f_fc, g(p + "attn.c_proj.w"), bs[1], dt)          # c_proj + c_fc
+                stats = torch.zeros((2, W // 16, 16, 2), dtype=torch.int64, device=dev)
+                lc.w_pf, lc.k_f = pf.pw.ptr, pf.k.data_ptr()
+                lc.stats_1, lc.stats_2 = stats[0].data_ptr(), stats[1].data_ptr()
+                self._keep += [pf, stats]
+                if d > 0:                                                           # mlp.c_proj of layer d-1 + this c_attn
+                    pp = f"transformer._attn_mods.{d - 1}."
+                    pa = H.FusedPair(f_attn, g(pp + "mlp.c_proj.w"), f32(pp + "mlp.c_proj.b"), dt)
+                    self.layers_c[d - 1].w_2a, self.layers_c[d - 1].k_a = pa.pw.ptr, pa.k.data_ptr()
+                    self._keep.append(pa)
+            for f in (f_attn, f_fc):
+                if f is not None:
+                    f.wf = None                                                     # the unpacked image is bind-time only
             if func == 6:
                 lc.w_enc_k, lc.w_enc_v, lc.b_enc_kv = enc[0].ptr, enc[1].ptr, b_enc.data_ptr()
 
@@ -120,6 +143,8 @@ class PriorEngine:
                         c_mlp=e(N * Cc, M))
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.epoch = torch.ones(1, dtype=torch.int32, device=dev)        # fused_pairs: tag of the current step (never 0)
+        self.pair_error = torch.zeros(1, dtype=torch.int32, device=dev)
         self.preds = e(N, T, bins, dtype=torch.float32) if want_preds else None
         if want_preds:
             self.buf["c_xf"] = e(N * Cc, W, dtype=torch.float32)
@@ -171,6 +196,8 @@ class PriorEngine:
             c.xc_t_stride = self.x_cond.stride(1) if self.x_cond.shape[1] > 1 else 0
         c.add_cond_after = int(self.add_cond_after)
         c.prefetch_next_weights = int(os.environ.get("JB_PREFETCH", "0"))
+        c.fused_pairs = int(self.fused_pairs)
+        c.epoch_dev, c.pair_error = self.epoch.data_ptr(), self.pair_error.data_ptr()
         b = self.buf
         for k in ("x_a", "x_b", "q", "att", "mlp", "xf", "logits", "c_xa", "c_xb", "c_h", "c_q", "c_att", "c_mlp"):
             setattr(c, k, b[k].data_ptr())

@@ -57,9 +57,50 @@ class FoldedLN:
         K, J = w.shape
         w_used = w.to(dtype).double()
         wf = (gamma.double()[:, None] * w_used).to(dtype).contiguous()
+        self.wf = wf                                           # unpacked diag(gamma)·W (kept for FusedPair images)
         self.pw = PackedWeight(pack_weight(wf, K, J, J, 1, dtype), K, J, dtype)
         self.c1 = wf.double().sum(0).float().contiguous()
         self.bias = (beta.double() @ w_used + b.double()).float().contiguous()
+
+
+class FusedPair:
+    """EXPERIMENTAL image for jb_gemv_pair part B: the projection behind a residual add, taken from the operands of
+    the add.  `folded` is the FoldedLN of that projection (W' = diag(gamma)·W); the residual add is
+    out = res + in1·w_prev + b_prev (w_prev: Conv1D.w (K1, K0)).  Packs [W' ; w_prev·W'] as one (K0 + K1) x J matrix
+    and k = b_prev·W'; c1 / bias stay those of `folded`."""
+
+    def __init__(self, folded, w_prev, b_prev, dtype):
+        wf = folded.wf
+        K0, J = wf.shape
+        K1 = w_prev.shape[0]
+        assert w_prev.shape[1] == K0
+        prod = (w_prev.to(dtype).float() @ wf.float()).to(dtype)
+        cat = torch.cat([wf, prod], 0).contiguous()
+        self.pw = PackedWeight(pack_weight(cat, K0 + K1, J, J, 1, dtype), K0 + K1, J, dtype)
+        self.k = (b_prev.float() @ wf.float()).contiguous()
+        self.K0, self.K1, self.J = K0, K1, J
+
+
+def gemv_pair(in1, w_a, bias_a, res, in0, folded, pair, stats, epoch, error, act=L.ACT_NONE, eps=1e-5):
+    """jb_gemv_pair (EXPERIMENTAL): returns (out_a, out_b) = (res + in1·Wa + bias_a, act(LN(out_a)·W + b)) with the
+    second taken from (in0, in1) and the folded / fused images."""
+    _chk_cuda(in1, res, in0, stats, epoch, error)
+    n = in1.shape[0]
+    out_a = torch.empty_like(res)
+    out_b = torch.empty((n, pair.J), dtype=in1.dtype, device=in1.device)
+    a = L.GemvPairArgs()
+    a.n_rows = n
+    a.in1, a.ld1, a.K1 = in1.data_ptr(), in1.stride(0), in1.shape[1]
+    a.Wa, a.bias_a, a.res, a.ldr = w_a.ptr, L.ptr(bias_a), res.data_ptr(), res.stride(0)
+    a.out_a, a.ldo_a, a.J_a = out_a.data_ptr(), out_a.stride(0), res.shape[1]
+    a.in0, a.ld0, a.K0 = in0.data_ptr(), in0.stride(0), in0.shape[1]
+    a.Wb, a.k_b, a.c1_b, a.bias_b, a.J_b, a.act = pair.pw.ptr, pair.k.data_ptr(), folded.c1.data_ptr(), \
+        folded.bias.data_ptr(), pair.J, act
+    a.out_b, a.ldo_b = out_b.data_ptr(), out_b.stride(0)
+    a.ln_eps = eps
+    a.stats, a.epoch_dev, a.error_flag = stats.data_ptr(), epoch.data_ptr(), error.data_ptr()
+    L.check(L.lib().jb_gemv_pair(C.byref(a), L.stream()))
+    return out_a, out_b
 
 
 def ln_fold_supported(dtype, K, J, n_rows):

@@ -52,12 +52,13 @@ def test_struct_layouts_match_header():
     src = textwrap.dedent("""
         #include <stdio.h>
         #include "jukebox_hip.h"
-        int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(jb_gemm_args), sizeof(jb_gemv_args),
-                                sizeof(jb_sample_params), sizeof(jb_layer), sizeof(jb_engine_cfg)); return 0; }
+        int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(jb_gemm_args), sizeof(jb_gemv_args),
+                                sizeof(jb_sample_params), sizeof(jb_layer), sizeof(jb_engine_cfg),
+                                sizeof(jb_gemv_pair_args)); return 0; }
     """)
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
     assert sizes == [C.sizeof(L.GemmArgs), C.sizeof(L.GemvArgs), C.sizeof(L.SampleParams), C.sizeof(L.Layer),
-                     C.sizeof(L.EngineCfg)]
+                     C.sizeof(L.EngineCfg), C.sizeof(L.GemvPairArgs)]
