@@ -101,6 +101,7 @@ class ConditionalAutoregressive2D(nn.Module):
                                              m_mlp=self.m_mlp, prime_len=self.prime_len, y_cond=self.y_cond,
                                              add_cond_after=self.add_cond_after_transformer, fp16=fp16,
                                              chunk_cap=chunk_cap, want_preds=want_preds,
+                                             fused_pairs=getattr(self, "fused_pairs", None),
                                              device=self.x_emb.weight.device)
         return self._engines[key]
 

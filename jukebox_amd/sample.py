@@ -114,6 +114,13 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # normal-priority stream ran three decode chains concurrently at 1.3x the single-chain step time.  The two
     # upsampler levels (the long poles) therefore get high priority, the top level normal priority.
     order = sorted(levels)                                 # lowest level first
+    if os.environ.get("JB_FUSED_PAIRS") == "1":
+        # experimental 3-launch decode layer: its kernels wait in-kernel on workgroups of the same launch, so at most one
+        # of the concurrently running engines may use it -- the long pole (lowest level)
+        for level in levels:
+            ar = getattr(priors[level], "prior", None)
+            if ar is not None:
+                ar.fused_pairs = level == order[0]
     prios = [-1, -1, 0, 0]
     stream_of = {level: t.cuda.Stream(device=device, priority=prios[min(i, 3)]) if on_gpu else None
                  for i, level in enumerate(order)}
