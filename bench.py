@@ -78,39 +78,43 @@ def synthetic_labels(priors, n_samples, total_length, device):
 
 
 def cpu_baseline(prior, n_batch, steps, total_decode_steps, audio_seconds):
-    """The numpy oracle (oracle/, a line-by-line CPU restatement of the reference) timed on this box's host cores on
-    a bounded sample: `steps` decode steps of the level-0 upsampler's transformer at batch n_batch, fp32.  The BLAS
-    thread count is chosen by a short sweep (skinny 16-row matmuls do not scale to hundreds of threads)."""
-    from oracle.transformer import Transformer as OracleTransformer
-    from threadpoolctl import threadpool_limits
+    """CPU port of the decode step (oracle/torch_port.py: the oracle's algorithm on the torch CPU kernels the reference
+    itself would run on; pinned to the numpy oracle by tests/test_oracle_golden.py) timed on this box's host cores on a
+    bounded sample: `steps` decode steps of the level-0 upsampler's transformer at batch n_batch, fp32.  The thread count
+    is chosen by a short sweep (16-row matmuls do not scale to hundreds of threads).  Calibration against the unmodified
+    reference in the build container (8 cores, tests/golden/time_reference_cpu.py): reference 182 ms, this port 131 ms,
+    numpy oracle 469 ms per step -- the port is the faster (conservative) stand-in."""
+    from oracle.torch_port import TorchDecodeStack
     ar = prior.prior
     sd = {k: v.detach().float().cpu().numpy() for k, v in ar.transformer.state_dict().items()}
-    tr = OracleTransformer(sd, "", n_in=ar.width, n_ctx=ar.input_dims, n_head=ar.heads, n_depth=ar.depth,
-                           attn_order=ar.attn_order, blocks=ar.blocks, m_attn=ar.m_attn, m_mlp=ar.m_mlp)
-    rng = np.random.default_rng(0)
-    x = rng.standard_normal((n_batch, 1, ar.width)).astype(np.float32)
+    tr = TorchDecodeStack(sd, "", n_in=ar.width, n_ctx=ar.input_dims, n_head=ar.heads, n_depth=ar.depth,
+                          attn_order=ar.attn_order, blocks=ar.blocks, m_attn=ar.m_attn, n_batch=n_batch)
+    x = np.random.default_rng(0).standard_normal((n_batch, 1, ar.width)).astype(np.float32)
+    before = torch.get_num_threads()
     tr.forward(x)                                    # warm-up step (t = 0)
     best, threads = None, 1
-    for nt in (8, 16, 32, 64, 128):
+    for nt in (8, 16, 32, 64, 128, 256):
         if nt > (os.cpu_count() or 1):
             break
-        with threadpool_limits(limits=nt):
-            t0 = time.perf_counter()
-            tr.forward(x)
-            dt1 = time.perf_counter() - t0
+        torch.set_num_threads(nt)
+        tr.forward(x)
+        t0 = time.perf_counter()
+        tr.forward(x)
+        dt1 = time.perf_counter() - t0
         if best is None or dt1 < best:
             best, threads = dt1, nt
-    with threadpool_limits(limits=threads):
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            tr.forward(x)
-        sec_per_step = (time.perf_counter() - t0) / steps
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.forward(x)
+    sec_per_step = (time.perf_counter() - t0) / steps
+    torch.set_num_threads(before)
     value = audio_seconds / (sec_per_step * total_decode_steps)
     return dict(value=value, unit="audio_s/s", cores=int(threads), kind="port",
                 sample=f"{steps} consecutive decode steps of the level-0 upsampler transformer (early positions) at batch "
-                       f"{n_batch}, numpy fp32 oracle: {sec_per_step * 1e3:.1f} ms/step, extrapolated over the "
-                       f"{total_decode_steps} decode steps of the workload (prefill, conditioner and VQ-VAE conv stacks "
-                       "are not charged to the CPU)")
+                       f"{n_batch}, torch-CPU fp32 port of the oracle (oracle/torch_port.py): {sec_per_step * 1e3:.1f} ms/step, "
+                       f"extrapolated over the {total_decode_steps} decode steps of the workload (prefill, conditioner and "
+                       "VQ-VAE conv stacks are not charged to the CPU)")
 
 
 def projection_roofline(eng, t0, n_steps):
@@ -165,7 +169,7 @@ def main():
     ap.add_argument("--model", default="1b_lyrics")
     ap.add_argument("--seconds", type=float, default=20.0)
     ap.add_argument("--samples-per-gpu", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--cpu-steps", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the levels strictly one after the other (the reference's order) instead of pipelining them")

@@ -233,3 +233,33 @@ def test_separated_encoder_decoder_prior(tiny_hps):
     assert np.array_equal(z, g["z_raw"])
     assert np.array_equal(sep.sample(3, z=np.zeros((3, 0), np.int64), y=g["y0"], top_k=1), g["z_ancestral"])
     assert np.array_equal(sep.sample(3, z=g["z_ancestral"][:, :20], y=g["y0"], top_k=1, chunk_size=6), g["z_primed"])
+
+
+def test_torch_port_matches_numpy_oracle():
+    """oracle/torch_port.py (what bench.py times as the CPU baseline) against the golden-pinned numpy oracle: the same
+    hidden states step by step, for the block / transpose / prev and the prime patterns."""
+    from oracle.torch_port import TorchDecodeStack
+    from oracle.transformer import Transformer
+    rng = np.random.default_rng(0)
+    for cfg in (dict(n_in=32, n_ctx=48, n_head=2, n_depth=6, attn_order=2, blocks=8),
+                dict(n_in=32, n_ctx=64, n_head=2, n_depth=8, attn_order=12, blocks=8, prime_len=12),
+                dict(n_in=24, n_ctx=20, n_head=3, n_depth=2, attn_order=0, blocks=None)):
+        W, D = cfg["n_in"], cfg["n_depth"]
+        S = W // 4
+        sd = {}
+        for d in range(D):
+            p = f"_attn_mods.{d}."
+            for nm, shp in (("attn.c_attn.w", (W, 3 * S)), ("attn.c_proj.w", (S, W)), ("mlp.c_fc.w", (W, W)),
+                            ("mlp.c_proj.w", (W, W))):
+                sd[p + nm] = (0.2 * rng.standard_normal(shp)).astype(np.float32)
+                sd[p + nm[:-1] + "b"] = (0.1 * rng.standard_normal(shp[1])).astype(np.float32)
+            for ln in ("ln_0", "ln_1"):
+                sd[p + ln + ".weight"] = (1 + 0.1 * rng.standard_normal(W)).astype(np.float32)
+                sd[p + ln + ".bias"] = (0.1 * rng.standard_normal(W)).astype(np.float32)
+        ref = Transformer(sd, "", **cfg)
+        port = TorchDecodeStack(sd, "", n_batch=3, **cfg)
+        for t in range(cfg["n_ctx"]):
+            x = rng.standard_normal((3, 1, W)).astype(np.float32)
+            want = ref.forward(x)
+            got = port.forward(x).numpy()
+            assert np.abs(got - want).max() < 2e-4 * max(1.0, np.abs(want).max()), (cfg["attn_order"], t)
