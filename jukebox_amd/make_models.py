@@ -6,7 +6,7 @@ import os
 import numpy as np
 import torch as t
 
-from .hparams import REMOTE_PREFIX, Hyperparams, setup_hparams
+from .hparams import REMOTE_PREFIX, setup_hparams
 from .utils import dist_adapter as dist
 from .utils.dist_utils import print_all
 from .utils.torch_utils import freeze_model

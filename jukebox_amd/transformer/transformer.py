@@ -2,7 +2,6 @@
 released checkpoints load with strict=True; forward(sample=True) runs on the HIP kernels.  The fused
 decode loop lives in jukebox_amd.engine.PriorEngine; this module-level forward serves chunked calls
 (the reference's check_sample/check_chunks style use) through the same kernels."""
-import torch as t
 import torch.nn as nn
 
 from .. import _lib as L

@@ -7,7 +7,7 @@ from conftest import load_golden, sub_state
 from oracle import ops
 from oracle.autoregressive import ConditionalAutoregressive2D, split_chunks
 from oracle.prior import SimplePrior
-from oracle.sample import get_starts, sample_level
+from oracle.sample import get_starts
 from oracle.transformer import Transformer, allowed_keys, decode_key_index
 from oracle.vqvae import VQVAE
 

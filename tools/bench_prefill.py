@@ -4,7 +4,6 @@ import torch
 sys.path.insert(0, ".")
 from tools.bench_engine import CFGS, random_state
 from jukebox_amd.engine import PriorEngine
-from jukebox_amd.hparams import setup_hparams
 from jukebox_amd.prior.conditioners import Conditioner
 
 dev = torch.device("cuda:0")
