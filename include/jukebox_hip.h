@@ -160,6 +160,9 @@ void jb_tune_attn_decode_parts(int enable);
  * q, out: [n][n_q][S]. */
 int jb_attn_prefill(int dtype, int attn_func, const void* q, const void* kcache, const void* vcache, int cache_cap,
                     void* out, int n_batch, int n_head, int d_head, int block_ctx, int t0, int n_q, void* stream);
+/* EXPERIMENTAL: 1 = fp16 prefill attention with 4-wave workgroups sharing vector-staged K/V tiles (every pattern except
+ * transpose); default 0. */
+void jb_tune_attn_prefill_v2(int enable);
 
 /* Attention probabilities of one head for queries t0..t0+n_q-1 (softmax over each query's pattern key set), fp32 rows
  * out[n][out_row0 + i][key position < n_keys_out]; zeros where a key is not attended.  Serves the lyric alignment

@@ -659,6 +659,170 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(int func, const T* __r
         }
 }
 
+// EXPERIMENTAL (off by default, jb_tune_attn_prefill_v2): the prefill attention above with the staging fixed.
+// attn_prefill_kernel runs one wave per 16-query tile and copies every K / V tile into its private LDS with 2-byte
+// loads; at the upsamplers' sizes that is 4 TFLOP/s.  Here a workgroup of 4 waves owns 4 consecutive query tiles of one
+// (sample, head) -- which share almost all of their keys under the dense / block / prev / prime / cross patterns -- and
+// stages each 32-key K and V tile ONCE, with 16-byte loads by all 256 threads; every wave then runs the same
+// MFMA / online-softmax body as above on its own tile.  fp16, d_head and n_state multiples of 8; the transpose pattern
+// (whose query tiles are residue classes) stays on the kernel above.
+template <int ND16>
+__global__ __launch_bounds__(256) void attn_prefill_v2_kernel(int func, const f16* __restrict__ q, const f16* __restrict__ kc,
+                                                              const f16* __restrict__ vc, int cap, f16* __restrict__ out,
+                                                              int n_head, int d, int bc, int t0, int nq) {
+    using V = f16x8;
+    constexpr int E = 8, KT = 32, QW = 4;
+    constexpr int DP = ND16 * 16;
+    constexpr int LDR = DP + E;
+    constexpr int NG = KT / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f16* sQ = reinterpret_cast<f16*>(smem_raw);      // [QW][16][LDR]
+    f16* sK = sQ + QW * 16 * LDR;                    // [KT][LDR]
+    f16* sV = sK + KT * LDR;                         // [KT][LDR]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int S = n_head * d;
+    const int dv = d / E;                            // 16-byte vectors per row
+
+    // ---- queries of this workgroup (64 consecutive positions) and of this wave (16 of them) ----
+    const int wg_q0 = t0 + blockIdx.x * (QW * 16);
+    const int wg_qlast = min(wg_q0 + QW * 16, t0 + nq) - 1;        // >= wg_q0: the grid has no empty workgroups
+    const int qpos0 = wg_q0 + wave * 16;
+    const int nvalid = max(0, min(16, t0 + nq - qpos0));
+    const int my_q = qpos0 + c;
+    const bool q_ok = c < nvalid;
+    int kstart, nkeys;                               // candidate keys kstart .. kstart + nkeys - 1 cover all 64 queries
+    if (func == JB_ATTN_DENSE) { kstart = 0; nkeys = wg_qlast + 1; }
+    else if (func == JB_ATTN_BLOCK) { kstart = (wg_q0 / bc) * bc; nkeys = wg_qlast - kstart + 1; }
+    else if (func == JB_ATTN_PREV_BLOCK) { kstart = max(wg_q0 / bc - 1, 0) * bc; nkeys = (wg_qlast / bc) * bc - kstart; }
+    else if (func == JB_ATTN_PRIME) { kstart = 0; nkeys = min(wg_qlast + 1, cap); }
+    else { kstart = 0; nkeys = cap; }
+
+    // ---- stage the 4 query tiles (zero rows / padding channels where there is no query) ----
+    for (int idx = tid; idx < QW * 16 * (LDR / E); idx += 256) {
+        const int r = idx / (LDR / E), i = idx - r * (LDR / E);
+        const int pos = wg_q0 + r;
+        V v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (pos < t0 + nq && i < dv) v = *reinterpret_cast<const V*>(q + ((int64_t)n * nq + (pos - t0)) * S + h * d + i * E);
+        *reinterpret_cast<V*>(sQ + r * LDR + i * E) = v;
+    }
+
+    f32x4 oacc[ND16];
+#pragma unroll
+    for (int i = 0; i < ND16; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float scale = 1.0f / sqrtf(sqrtf((float)d));
+    const float scale2 = scale * scale;
+    const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
+    const f16* vbase = vc + ((int64_t)n * cap) * S + h * d;
+    const f16* sQw = sQ + wave * 16 * LDR;
+
+    for (int u0 = 0; u0 < nkeys; u0 += KT) {
+        __syncthreads();                              // every wave is done with the previous K / V tile (and sQ is written)
+        for (int idx = tid; idx < KT * (LDR / E); idx += 256) {
+            const int r = idx / (LDR / E), i = idx - r * (LDR / E);
+            const int u = u0 + r;
+            V kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (u < nkeys && i < dv) {
+                const int64_t off = (int64_t)(kstart + u) * S + i * E;
+                kv = *reinterpret_cast<const V*>(kbase + off);
+                vv = *reinterpret_cast<const V*>(vbase + off);
+            }
+            *reinterpret_cast<V*>(sK + r * LDR + i * E) = kv;
+            *reinterpret_cast<V*>(sV + r * LDR + i * E) = vv;
+        }
+        __syncthreads();
+        if (nvalid <= 0) continue;                    // wave-uniform: this wave has no queries (tail of the chunk)
+
+        f32x4 sc[NG];
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) sc[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dk = 0; dk < DP; dk += KT) {
+            if (dk >= d) break;
+            V qfrag, kfrag[NG];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int ch = dk + g * E + e;
+                qfrag[e] = ch < DP ? sQw[c * LDR + ch] : (f16)0;
+            }
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int ch = dk + g * E + e;
+                    kfrag[gi][e] = ch < DP ? sK[(gi * 16 + c) * LDR + ch] : (f16)0;
+                }
+                sc[gi] = jb_mfma(kfrag[gi], qfrag, sc[gi]);
+            }
+        }
+        float pv[NG][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = u0 + gi * 16 + g * 4 + r;
+                const int j = kstart + u;
+                bool ok = q_ok && u < nkeys;
+                if (ok) {
+                    switch (func) {
+                        case JB_ATTN_DENSE: case JB_ATTN_PRIME: ok = j <= my_q; break;
+                        case JB_ATTN_BLOCK: ok = j <= my_q && (j / bc) == (my_q / bc); break;
+                        case JB_ATTN_PREV_BLOCK: ok = (j / bc) == (my_q / bc) - 1; break;
+                        default: break;
+                    }
+                }
+                const float sv = jb_round<f16>(jb_round<f16>(sc[gi][r]) * scale2);
+                pv[gi][r] = ok ? sv : -INFINITY;
+                mx = fmaxf(mx, pv[gi][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_new == -INFINITY) ? 1.0f : expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pe = (pv[gi][r] == -INFINITY) ? 0.f : expf(pv[gi][r] - m_new);
+                pv[gi][r] = pe;
+                psum += pe;
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        V pfrag;
+#pragma unroll
+        for (int e = 0; e < E; ++e) pfrag[e] = (f16)pv[e >> 2][e & 3];
+#pragma unroll
+        for (int i = 0; i < ND16; ++i) {
+            oacc[i] *= alpha;
+            V vfrag;
+#pragma unroll
+            for (int e = 0; e < E; ++e) vfrag[e] = sV[(g * 4 + (e & 3) + 16 * (e >> 2)) * LDR + i * 16 + c];
+            oacc[i] = jb_mfma(vfrag, pfrag, oacc[i]);
+        }
+    }
+
+    if (!q_ok) return;
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    f16* orow = out + ((int64_t)n * nq + (my_q - t0)) * S + h * d;
+#pragma unroll
+    for (int i = 0; i < ND16; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = i * 16 + g * 4 + r;
+            if (ch < d) orow[ch] = (f16)(oacc[i][r] * inv);
+        }
+}
+
+static int g_prefill_v2 = 0;
+extern "C" void jb_tune_attn_prefill_v2(int enable) { g_prefill_v2 = enable != 0; }
+
 extern "C" int jb_attn_prefill(int dtype, int attn_func, const void* q, const void* kcache, const void* vcache,
                                int cache_cap, void* out, int n_batch, int n_head, int d_head, int block_ctx, int t0,
                                int n_q, void* stream) {
@@ -678,6 +842,29 @@ extern "C" int jb_attn_prefill(int dtype, int attn_func, const void* q, const vo
     const int esz = dtype == JB_F16 ? 2 : 4, E = dtype == JB_F16 ? 8 : 4, KT = dtype == JB_F16 ? 32 : 16;
     dim3 grid(tiles, n_head, n_batch);
     hipStream_t s = (hipStream_t)stream;
+    if (g_prefill_v2 && dtype == JB_F16 && attn_func != JB_ATTN_TRANSPOSE_BLOCK && d_head % 8 == 0 && (n_head * d_head) % 8 == 0) {
+        dim3 g2((n_q + 63) / 64, n_head, n_batch);
+#define JB_LAUNCH_PF2(ND)                                                                                            \
+    do {                                                                                                            \
+        size_t lds2 = (size_t)(4 * 16 + 2 * 32) * (ND * 16 + 8) * 2;                                                \
+        if (lds2 > 64 * 1024)                                                                                       \
+            JB_HIP(hipFuncSetAttribute((const void*)attn_prefill_v2_kernel<ND>,                                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                    \
+        attn_prefill_v2_kernel<ND><<<g2, 256, lds2, s>>>(attn_func, (const f16*)q, (const f16*)kcache, (const f16*)vcache, \
+                                                        cache_cap, (f16*)out, n_head, d_head, block_ctx, t0, n_q);  \
+    } while (0)
+        if (nd16 <= 1) JB_LAUNCH_PF2(1);
+        else if (nd16 <= 2) JB_LAUNCH_PF2(2);
+        else if (nd16 <= 4) JB_LAUNCH_PF2(4);
+        else if (nd16 <= 8) JB_LAUNCH_PF2(8);
+        else if (nd16 <= 10) JB_LAUNCH_PF2(10);
+        else if (nd16 <= 16) JB_LAUNCH_PF2(16);
+        else if (nd16 <= 30) JB_LAUNCH_PF2(30);
+        else JB_UNSUPPORTED("d_head > 480");
+#undef JB_LAUNCH_PF2
+        JB_CHECK_LAUNCH();
+        return JB_OK;
+    }
 #define JB_LAUNCH_PF(T, ND)                                                                                         \
     do {                                                                                                            \
         size_t lds = (size_t)(16 + 2 * KT) * (ND * 16 + E) * esz;                                                   \

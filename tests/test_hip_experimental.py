@@ -95,3 +95,32 @@ def test_engine_fused_pairs_fp16():
     n_ok = int(np.argmax(diverged)) if diverged.any() else 96
     assert n_ok >= 8 and np.abs(p0[:, :n_ok] - p1[:, :n_ok]).max() < 3e-2 * max(1.0, np.abs(p0).max())
     assert (z0 == z1).mean() > 0.8
+
+
+@pytest.mark.parametrize("func", [0, 1, 3, 7])
+@pytest.mark.parametrize("H_,d,bc", [(1, 480, 128), (2, 64, 8), (1, 120, 8)])
+def test_attn_prefill_v2(func, H_, d, bc):
+    """jb_tune_attn_prefill_v2(1): 4-wave workgroups sharing vector-staged K/V tiles, against fp32 math on the half
+    operands (same bar as tests/test_hip_kernels.py::test_attn_prefill)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from jukebox_amd import _lib as L, hip_ops as H
+    from test_hip_kernels import _np_attention
+    rng = np.random.default_rng(func * 10 + d + 1)
+    N, prime_r = 2, 24
+    T = 520 if bc == 128 else 120
+    S = H_ * d
+    cap = prime_r if func == 7 else T
+    K = h16(rng.standard_normal((N, cap, S)).astype(np.float32))
+    V = h16(rng.standard_normal((N, cap, S)).astype(np.float32))
+    kc, vc = dev(K, torch.float16), dev(V, torch.float16)
+    spans = ((0, 40), (0, 1), (5, 7), (13, 50), (64, 56), (37, 83)) if bc == 8 else ((0, 512), (100, 300), (384, 136), (7, 65))
+    L.lib().jb_tune_attn_prefill_v2(1)
+    try:
+        for t0, nq in spans:
+            q = h16(rng.standard_normal((N, nq, S)).astype(np.float32))
+            got = H.attn_prefill(func, dev(q, torch.float16), kc, vc, H_, bc, t0).float().cpu().numpy()
+            want = _np_attention(func, q, K, V, H_, bc, prime_r, list(range(t0, t0 + nq)), False)
+            assert np.abs(got - want).max() < 6e-3 * max(1.0, np.abs(want).max()), (func, t0, nq)
+    finally:
+        L.lib().jb_tune_attn_prefill_v2(0)
