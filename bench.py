@@ -197,12 +197,15 @@ def main():
     sk = S.default_sampling_kwargs(a.model if not tiny else "1b_lyrics")
     audio_seconds_per_step = n_samples * sample_length / sr
 
-    level_t = {}
+    level_t, level_t0 = {}, {}
 
     def mark(level):
-        torch.cuda.synchronize()
+        torch.cuda.current_stream(device).synchronize()     # the level's own stream is already drained by the sampler
         level_t.setdefault(level, []).append(time.perf_counter())
-    S._sample.level_done = mark
+
+    def mark_start(level):
+        level_t0.setdefault(level, []).append(time.perf_counter())
+    S._sample.level_done, S._sample.level_start = mark, mark_start
 
     def one_step():
         return S.ancestral_sample(labels, sk, priors, hps, save=False, device=device)
@@ -215,6 +218,7 @@ def main():
     for _ in range(a.warmup):
         S.ancestral_sample(labels, sk, priors, warm_hps, save=False, device=device)
     level_t.clear()
+    level_t0.clear()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -239,6 +243,9 @@ def main():
     if a.steps == 1:
         for l in (2, 1, 0):          # seconds from the start of the step until level l had produced all its codes
             breakdown[f"level{l}_codes_done_at_s"] = round(level_t[l][-1] - t0, 3)
+            if l in level_t0:        # tokens per second of the level while it was running (levels overlap when pipelined)
+                busy = max(level_t[l][-1] - level_t0[l][-1], 1e-9)
+                breakdown[f"level{l}_tokens_per_s"] = round(n_samples // world * (sample_length // priors[l].raw_to_tokens) / busy, 1)
 
     # dominant kernel, timed in situ with HIP events on the launch stream: the LayerNorm-fused weight-streaming
     # projections of the level-0 upsampler's decode step

@@ -144,6 +144,9 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 kw = dict(sampling_kwargs[level])
                 kw["sample_base"] = lo
                 lab = _shard_labels(labels[level], lo, hi)
+                started = getattr(_sample, "level_start", None)
+                if callable(started):
+                    started(level)
                 for start, sample_tokens in _level_plan(prior, zs_local[level].shape[1], total_length, hop_length):
                     if prior.x_cond and (level + 1) in sample_levels:
                         need = (start + prior.n_ctx) // prior.cond_downsample
@@ -245,6 +248,8 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
         kw = dict(sampling_kwargs[level])
         kw["sample_base"] = lo
         if local_hps.n_samples > 0 and not pipelined:
+            if callable(getattr(_sample, "level_start", None)):
+                _sample.level_start(level)
             zs_local = sample_level(zs_local, _shard_labels(labels[level], lo, hi), kw, level, prior, total_length,
                                     hop_length, local_hps)
         if not hps.get("keep_priors_resident", False):
