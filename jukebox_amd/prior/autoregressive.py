@@ -2,6 +2,8 @@
 (jukebox/prior/autoregressive.py:48-359).  `sample` / `primed_sample` run the whole token loop inside
 the HIP decode engine (jukebox_amd.engine.PriorEngine): one hipGraph replay per token, chunked MFMA
 prefill for the primed part; nothing is computed in torch."""
+import math
+
 import numpy as np
 import torch as t
 import torch.nn as nn
@@ -109,21 +111,41 @@ class ConditionalAutoregressive2D(nn.Module):
         from ..engine import attn_funcs
         return attn_funcs(self.attn_order, self.depth)
 
-    def forward(self, x, x_cond=None, y_cond=None, encoder_kv=None, fp16=False, **kw):
-        """Teacher-forced pass over a full sequence.  Only the `only_encode` use of the reference's forward is on the
-        sampling path (the lyric encoder of separated enc-dec priors, prior.py:285-292, autoregressive.py:114-157):
-        returns the final activations (N, T, width) fp32.  The training loss path is out of scope."""
-        assert self.only_encode, "the training forward (losses) is out of scope; use sample / primed_sample"
-        assert not self.x_cond and not self.y_cond and x_cond is None and y_cond is None and encoder_kv is None
+    def forward(self, x, x_cond=None, y_cond=None, encoder_kv=None, fp16=False, loss_full=False, encode=False,
+                get_preds=False, get_acts=False, get_sep_loss=False):
+        """autoregressive.py:114-175, inference only: the teacher-forced pass over a full sequence as ONE engine prefill
+        (position t sees tokens < t).  `only_encode` models return the final activations (N, T, width) fp32 (the lyric
+        encoder of separated enc-dec priors, prior.py:285-292); the others return (loss, preds | None) with the loss
+        in bits per token -- with get_sep_loss the (prime, generated) parts separately, prime first."""
+        assert not get_acts, "get_acts is not supported (activations are only exposed by only_encode models)"
         with t.no_grad():
             x = self.preprocess(x)
             N, D = x.shape
             assert D == self.input_dims and (0 <= x).all() and (x < self.bins).all()
-            eng = self.engine(N, fp16)
-            eng.set_cond(None, None)
+            if self.only_encode:
+                assert not self.x_cond and not self.y_cond and x_cond is None and y_cond is None and encoder_kv is None
+                eng = self.engine(N, fp16)
+                eng.set_cond(None, None)
+                eng.tokens[:, :D] = x
+                eng.prefill(0, D)
+                return eng.hidden[:, :D].clone()
+            has_cross = 6 in self._funcs()
+            assert (encoder_kv is not None) == has_cross, "encoder_kv is required exactly for cross-attention models"
+            self._check_cond(N, x_cond, y_cond)
+            eng = self.engine(N, fp16, want_preds=True)
+            eng.set_cond(x_cond, y_cond)
+            if has_cross:
+                eng.set_encoder_kv(encoder_kv)
             eng.tokens[:, :D] = x
             eng.prefill(0, D)
-            return eng.hidden[:, :D].clone()
+            preds = eng.preds[:, :D].clone()                               # (N, D, bins) fp32 logits
+            ce = lambda lg, tg: nn.functional.cross_entropy(lg.reshape(-1, self.bins), tg.reshape(-1)) / math.log(2.0)
+            if get_sep_loss:
+                assert self.prime_len is not None
+                loss = (ce(preds[:, :self.prime_len], x[:, :self.prime_len]), ce(preds[:, self.prime_len:], x[:, self.prime_len:]))
+            else:
+                loss = ce(preds, x)
+            return (loss, preds) if get_preds else (loss, None)
 
     def _check_cond(self, N, x_cond, y_cond):
         D = self.input_dims

@@ -23,6 +23,7 @@ class ConditionalAutoregressive2D:
         self.bins, self.width = bins, width
         self.x_cond, self.y_cond = x_cond, y_cond
         self.only_encode = only_encode
+        self.prime_len = prime_len
         g = lambda n: np.asarray(sd[prefix + n], dtype=F32)
         self.x_emb = g("x_emb.weight")
         self.pos_emb = g("pos_emb.pos_emb")
@@ -163,3 +164,23 @@ class ConditionalAutoregressive2D:
         if self.only_encode:
             return h
         return np.matmul(h, self.x_out.T).astype(F32)
+
+    def forward(self, x, x_cond=None, y_cond=None, encoder_kv=None, fp16=False, get_preds=False, get_sep_loss=False):
+        """autoregressive.py:114-175 -- teacher-forced loss in bits per token (cross entropy / ln 2); with get_sep_loss the
+        (prime, generated) parts separately, split at prime_len."""
+        x = np.asarray(x).reshape(np.asarray(x).shape[0], -1).astype(np.int64)
+        logits = self.forward_logits(x, x_cond, y_cond, encoder_kv, fp16)
+        if self.only_encode:
+            return logits
+
+        def ce(lg, tg):
+            lg = lg.reshape(-1, lg.shape[-1]).astype(np.float64)
+            m = lg.max(-1, keepdims=True)
+            lse = (m[:, 0] + np.log(np.exp(lg - m).sum(-1)))
+            return F32((lse - lg[np.arange(lg.shape[0]), tg.reshape(-1)]).mean() / np.log(2.0))
+        if get_sep_loss:
+            pl = self.prime_len
+            loss = (ce(logits[:, :pl], x[:, :pl]), ce(logits[:, pl:], x[:, pl:]))
+        else:
+            loss = ce(logits, x)
+        return (loss, logits) if get_preds else (loss, None)

@@ -167,3 +167,34 @@ class SimplePrior:
         ekv = layer_norm(conv1d(acts, sd["prime_state_proj.w"], sd["prime_state_proj.b"]),
                          sd["prime_state_ln.weight"], sd["prime_state_ln.bias"]).astype(F32)
         return r16(ekv, fp16)
+
+    def z_forward(self, z, z_conds=(), y=None, fp16=False, get_preds=False):
+        """prior.py:312-347 -- (loss, metrics) of a given code sequence: bits per token of the generated part (bpd), of
+        the lyric part (prime_loss) and their weighted sum."""
+        x_cond, y_cond, prime = self.get_cond(list(z_conds), y)
+        hp = self.hps
+        if self.single_enc_dec:
+            zz = np.concatenate([np.asarray(prime) + self.prior_bins_shift[0], np.asarray(z) + self.prior_bins_shift[1]], axis=1)
+            xc = np.concatenate([np.zeros((zz.shape[0], self.n_tokens, hp["prior_width"]), F32), x_cond], axis=1)
+            (prime_loss, gen_loss), preds = self.prior.forward(zz, xc, y_cond, fp16=fp16, get_sep_loss=True, get_preds=True)
+            prime_dims, gen_dims = self.prior_dims
+        else:
+            encoder_kv = self.get_encoder_kv(prime, fp16)
+            if getattr(self, "use_tokens", False):
+                from .ops import r16
+                lg = np.matmul(np.asarray(encoder_kv, F32), self.sd["prime_x_out.weight"].T).astype(np.float64)
+                lg = lg.reshape(-1, lg.shape[-1])
+                m = lg.max(-1, keepdims=True)
+                lse = m[:, 0] + np.log(np.exp(lg - m).sum(-1))
+                prime_loss = F32((lse - lg[np.arange(lg.shape[0]), np.asarray(prime).reshape(-1)]).mean() / np.log(2.0))
+                prime_dims = self.n_tokens
+            else:
+                prime_loss, prime_dims = F32(0.0), 0
+            gen_loss, preds = self.prior.forward(z, x_cond, y_cond, encoder_kv, fp16=fp16, get_preds=True)
+            gen_dims = self.n_ctx
+        total = prime_dims + gen_dims
+        loss = F32(hp["prime_loss_fraction"]) * prime_loss * F32(prime_dims) / F32(total) + gen_loss * F32(gen_dims) / F32(total)
+        metrics = dict(bpd=gen_loss, prime_loss=prime_loss, gen_loss=gen_loss)
+        if get_preds:
+            metrics["preds"] = preds
+        return F32(loss), metrics

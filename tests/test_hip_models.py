@@ -254,3 +254,29 @@ def test_top_prior_fp16_against_reference_fp16(models):
     got, want = zp.cpu().numpy(), g["top.z_primed16"]
     assert got.shape == want.shape and np.array_equal(got[:, :24], want[:, :24])     # primed part is copied through
     assert (got == want).mean() > 0.85, (got == want).mean()
+
+
+@pytest.mark.skipif(__import__("os").environ.get("JB_EXPERIMENTAL") != "1",
+                    reason="written after the round's GPU budget was spent: enable with JB_EXPERIMENTAL=1, then drop the gate")
+def test_teacher_forced_losses(models, tiny_hps):
+    """SimplePrior.z_forward (prior.py:312-347) on the HIP prefill path: loss, bits per token of the lyric and music parts
+    and the logits of a given code sequence against the reference (tests/golden/forward.npz), fp32."""
+    from jukebox_amd.make_models import make_prior
+    vq, (up0, up1, top) = models
+    g, f = load_golden("priors"), load_golden("forward")
+    gs = load_golden("prior_sep")
+    h = Hyperparams(tiny_hps["tiny_sep"])
+    h.y_bins = tuple(h.y_bins)
+    sep = make_prior(h, vq, "cpu")
+    sep.load_state_dict({k: torch.from_numpy(v) for k, v in sub_state(gs, "sd.").items()}, strict=True)
+    sep = sep.cuda()
+    cases = (("top", top, g["top.z_ancestral"], [], g["top.y0"]),
+             ("up0", up0, g["up0.z"], [g["up0.z_cond"]], g["up0.y"]),
+             ("up1", up1, g["up1.z"], [g["up1.z_cond"]], g["up1.y"]),
+             ("sep", sep, gs["z_ancestral"][:1], [], gs["y0"][:1]))
+    for tag, prior, z, z_conds, y in cases:
+        loss, m = prior.z_forward(cu(z), [cu(c) for c in z_conds], cu(y), fp16=False, get_preds=True)
+        assert np.abs(m["preds"].cpu().numpy() - f[f"{tag}.preds"]).max() < 3e-4, tag
+        for k in ("bpd", "prime_loss", "gen_loss"):
+            assert abs(float(m[k]) - float(f[f"{tag}.{k}"])) < 1e-4, (tag, k)
+        assert abs(float(loss) - float(f[f"{tag}.loss"])) < 1e-4, tag

@@ -263,3 +263,22 @@ def test_torch_port_matches_numpy_oracle():
             want = ref.forward(x)
             got = port.forward(x).numpy()
             assert np.abs(got - want).max() < 2e-4 * max(1.0, np.abs(want).max()), (cfg["attn_order"], t)
+
+
+def test_teacher_forced_losses(tiny_hps):
+    """SimplePrior.z_forward / ConditionalAutoregressive2D.forward (prior.py:312-347, autoregressive.py:114-175): the
+    evaluation pass over a given code sequence -- loss, bits per token of the lyric and music parts, logits -- against
+    the reference on the merged (1b_lyrics-like) top prior, both upsamplers and the separated enc-dec prior."""
+    f = load_golden("forward")
+    g, (up0, up1, top) = _priors(tiny_hps)
+    gs, sep = _sep_prior(tiny_hps)
+    cases = (("top", top, g["top.z_ancestral"], [], g["top.y0"]),
+             ("up0", up0, g["up0.z"], [g["up0.z_cond"]], g["up0.y"]),
+             ("up1", up1, g["up1.z"], [g["up1.z_cond"]], g["up1.y"]),
+             ("sep", sep, gs["z_ancestral"][:1], [], gs["y0"][:1]))
+    for tag, prior, z, z_conds, y in cases:
+        loss, m = prior.z_forward(z, z_conds, y, get_preds=True)
+        assert np.abs(m["preds"] - f[f"{tag}.preds"]).max() < 1e-4, tag
+        for k in ("bpd", "prime_loss", "gen_loss"):
+            assert abs(float(m[k]) - float(f[f"{tag}.{k}"])) < 2e-5, (tag, k, m[k], f[f"{tag}.{k}"])
+        assert abs(float(loss) - float(f[f"{tag}.loss"])) < 2e-5, (tag, loss, f[f"{tag}.loss"])
