@@ -32,6 +32,19 @@ def get_relevant_lyric_tokens(full_tokens, n_tokens, total_length, offset, durat
     return tokens, indices
 
 
+_PUNCT = {"\u2014": "--", "\u2013": "-", "\u2018": "'", "\u2019": "'", "\u201c": '"', "\u201d": '"', "\u2026": "...",
+          "\u00df": "ss", "\u00e6": "ae", "\u00c6": "AE", "\u00f8": "o", "\u00d8": "O", "\u0153": "oe", "\u0152": "OE"}
+
+
+def to_ascii(text):
+    """Stand-in for `unidecode` (data/text_processor.py:12, not installed here): compatibility-decompose and drop the
+    combining marks (e-acute -> e), plus the handful of punctuation marks / ligatures lyric sheets actually contain.
+    Identical to unidecode on ASCII and on accented Latin letters; other scripts are dropped instead of romanised."""
+    import unicodedata
+    text = "".join(_PUNCT.get(c, c) for c in text)
+    return unicodedata.normalize("NFKD", text).encode("ascii", "ignore").decode()
+
+
 class EmptyLabeller:
     def get_label(self, artist=None, genre=None, lyrics=None, total_length=None, offset=None):
         return dict(y=np.array([], dtype=np.int64), info=dict(artist="n/a", genre="n/a", lyrics=[], full_tokens=[]))
@@ -55,7 +68,7 @@ class TextProcessor:
         self.tokens[0] = ""
 
     def clean(self, text):
-        text = text.encode("ascii", "ignore").decode()      # the reference uses unidecode (not installed here)
+        text = to_ascii(text)
         text = text.replace("\\", "\n")
         return self.not_vocab.sub("", text)
 

@@ -45,7 +45,10 @@ def install():
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
     sys.modules["fire"].Fire = lambda f: None
-    sys.modules["unidecode"].unidecode = lambda s: s.encode("ascii", "ignore").decode()
+    # unidecode is not installed: the same ASCII stand-in the product uses (accented Latin letters -> base letters)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from jukebox_amd.data.labels import to_ascii
+    sys.modules["unidecode"].unidecode = to_ascii
     if not hasattr(sys.modules["mpi4py"], "MPI"):
         sys.modules["mpi4py"].MPI = types.SimpleNamespace()
 

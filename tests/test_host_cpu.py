@@ -179,3 +179,25 @@ def test_no_cpu_fallback_and_reference_error_messages(tiny_hps, monkeypatch):
     monkeypatch.setattr(L, "LIB_PATH", os.path.join(ROOT, "jukebox_amd", "csrc", "does_not_exist.so"))
     with pytest.raises(L.JukeboxHipError, match="no CPU fallback"):
         L.lib()
+
+
+def test_labeller_names_match_reference(monkeypatch):
+    """Labeller.get_label (data/labels.py:22-87): artist / genre name lookup (v2: normalised bag of words, v3: lower-cased
+    names), lyric cleaning and tokenising, and the lyric window -- against label vectors produced by the reference's
+    Labeller (tests/golden/labels.npz).  Needs the reference's id tables (data files that are not redistributed here)."""
+    ids = os.environ.get("JUKEBOX_IDS_DIR") or "/root/reference/jukebox/data/ids"
+    if not os.path.isdir(ids):
+        pytest.skip("artist / genre id tables not available (set JUKEBOX_IDS_DIR)")
+    monkeypatch.setenv("JUKEBOX_IDS_DIR", ids)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_labels_golden_metas", os.path.join(ROOT, "tests", "golden", "gen_labels_golden.py"))
+    src = open(spec.origin).read()
+    metas = eval(src[src.index("METAS = [") + len("METAS = "):src.index("]\n\n\ndef main")] + "]")      # the list literal only
+    from jukebox_amd.data.labels import Labeller
+    g = load_golden("labels")
+    for tag, v3, words, n_tok in (("v2", False, 5, 512), ("v3", True, 1, 384)):
+        lab = Labeller(words, n_tok, 1048576, v3=v3)
+        for i, m in enumerate(metas):
+            r = lab.get_label(total_length=180 * 44100, offset=(i % 3) * 1048576, **m)
+            assert list(r["info"]["full_tokens"]) == list(g[f"{tag}.full_tokens{i}"]), (tag, i)
+            assert np.array_equal(np.asarray(r["y"]), g[f"{tag}.y{i}"]), (tag, i)
