@@ -201,3 +201,34 @@ def test_labeller_names_match_reference(monkeypatch):
             r = lab.get_label(total_length=180 * 44100, offset=(i % 3) * 1048576, **m)
             assert list(r["info"]["full_tokens"]) == list(g[f"{tag}.full_tokens{i}"]), (tag, i)
             assert np.array_equal(np.asarray(r["y"]), g[f"{tag}.y{i}"]), (tag, i)
+
+
+def test_restore_model_reads_reference_checkpoints(tiny_hps, tmp_path, monkeypatch):
+    """make_models.py:24-62: a checkpoint file in the reference's format ({'hps', 'model', 'opt', 'step'}, keys possibly
+    prefixed with 'module.' by DDP) restores through hps.restore_prior with strict loading; released (remote) paths
+    resolve to ~/.cache and are never downloaded."""
+    from jukebox_amd.hparams import REMOTE_PREFIX
+    from jukebox_amd.make_models import make_prior
+    vq, priors = _tiny_models(tiny_hps)
+    gp = load_golden("priors")
+    sd = {("module." + k if i % 2 else k): torch.from_numpy(v) for i, (k, v) in enumerate(sub_state(gp, "p2.").items())
+          if not k.startswith(("labels_y", "full_tokens"))}
+    path = tmp_path / "prior_level_2.pth.tar"
+    torch.save(dict(hps=dict(tiny_hps["tiny_top"]), model=sd, opt=None, step=4321), path)
+    h = Hyperparams(tiny_hps["tiny_top"])
+    h.y_bins = tuple(h.y_bins)
+    h.restore_prior = str(path)
+    top = make_prior(h, vq, "cpu")
+    assert top.step == 4321
+    want = {k[7:] if k.startswith("module.") else k: v for k, v in sd.items()}
+    for k, v in top.state_dict().items():
+        assert torch.equal(v, want[k]), k
+    # released checkpoints: looked up in ~/.cache, no download
+    monkeypatch.setenv("HOME", str(tmp_path))
+    h.restore_prior = REMOTE_PREFIX + "5b/prior_level_2.pth.tar"
+    with pytest.raises(FileNotFoundError, match="downloads are not performed"):
+        make_prior(h, vq, "cpu")
+    cache = tmp_path / ".cache" / "5b"
+    cache.mkdir(parents=True)
+    torch.save(dict(model=want, step=7), cache / "prior_level_2.pth.tar")
+    assert make_prior(h, vq, "cpu").step == 7
