@@ -126,6 +126,15 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)          # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
+        # tuning knobs from the environment (tools/, bench.py and experiments share them): kernel-selection switches
+        # that default to the measured-best variant
+        env = os.environ.get
+        if env("JB_ATTN_PARTS") is not None:
+            l.jb_tune_attn_decode_parts(int(env("JB_ATTN_PARTS")))
+        if env("JB_PREFILL_V2") is not None:
+            l.jb_tune_attn_prefill_v2(int(env("JB_PREFILL_V2")))
+        if env("JB_GEMM_LDS_MIN_ROWS") is not None:
+            l.jb_tune_gemm_lds(int(env("JB_GEMM_LDS_MIN_ROWS")))
         _lib = l
     return _lib
 

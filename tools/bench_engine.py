@@ -7,10 +7,6 @@ import time
 import torch
 
 from jukebox_amd.engine import PriorEngine, attn_funcs
-from jukebox_amd import _lib as _L
-import os
-if os.environ.get("JB_ATTN_PARTS") == "0":
-    _L.lib().jb_tune_attn_decode_parts(0)
 
 CFGS = {
     "1b": dict(seq_len=6528, bins=2127, width=2048, depth=72, heads=2, attn_order=12, blocks=64, prime_len=384, y_cond=True),
