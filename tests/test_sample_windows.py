@@ -275,3 +275,16 @@ def test_save_samples_modes(mode, tmp_path, monkeypatch):
         assert priors[2].calls == []
     with pytest.raises(ValueError, match="Unknown sample mode"):
         S.save_samples("1b_lyrics", "cpu", hps, Hyperparams(mode="nope"))
+
+
+def test_command_line_arguments_parse_like_fire():
+    """`python -m jukebox_amd.sample --model=... --hop_fraction=0.5,0.5,0.125` (the reference's fire.Fire(run) command line)."""
+    kw = S._argv_kwargs(["--model=5b_lyrics", "--name=sample_5b", "--levels=3", "--sample_length_in_seconds=20",
+                         "--total_sample_length_in_seconds", "180", "--sr=44100", "--n_samples=6",
+                         "--hop_fraction=0.5,0.5,0.125", "--mode=primed", "--audio_file=a.wav,b.wav",
+                         "--prompt_length_in_seconds=12.5"])
+    assert kw == dict(model="5b_lyrics", name="sample_5b", levels=3, sample_length_in_seconds=20,
+                      total_sample_length_in_seconds=180, sr=44100, n_samples=6, hop_fraction=(0.5, 0.5, 0.125),
+                      mode="primed", audio_file="a.wav,b.wav", prompt_length_in_seconds=12.5)
+    with pytest.raises(AssertionError):
+        S._argv_kwargs(["model=1b_lyrics"])
