@@ -3,29 +3,83 @@
 of `1b_lyrics` (top prior + 2 upsamplers + VQ-VAE decode), 20 s of audio, 16 samples per GPU, synthetic labels and
 seeded random-init weights of the released architecture (no checkpoints are reachable offline).
 
-    python bench.py --gpus 1 --steps 1 --warmup 0
+    python bench.py --gpus N --steps K --warmup W          # N > 1: re-launches itself as N ranks under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one full pass of the hot path over one batch: all three levels for 16 samples per GPU (n_samples is sharded
-over the ranks, weak scaling).  Rank 0 prints ONE JSON line.
+over the ranks, weak scaling) -- minutes of GPU time.  The run therefore works against a WALL BUDGET (JB_BENCH_BUDGET_S,
+default 1400 s from process start, model build included): at most one short untimed warm-up pass, then full-length timed
+steps while another one still fits, at least one and at most --steps.  The JSON line reports the steps actually timed
+(`steps`, `ms_per_step`) next to the requested counts, so a driver command such as `--steps 20 --warmup 5` always
+yields a line.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
+T_PROC = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--model", default="1b_lyrics")
+    ap.add_argument("--seconds", type=float, default=20.0)
+    ap.add_argument("--samples-per-gpu", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=32, help="decode steps of the fallback CPU port (kind 'port')")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the levels strictly one after the other (the reference's order) instead of pipelining them")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="build only the level-0 upsampler, run a short decode burst and print the roofline block "
+                         "(the command profiled under profiles/)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: every step is a short sleep.  Exercises the launcher, the rank bootstrap (gloo on a "
+                         "CPU-only host), the budgeted step loop and the JSON contract (tests/test_bench_contract.py)")
+    return ap.parse_args(argv)
+
+
+def _respawn_as_ranks(a, argv):
+    """`python bench.py --gpus N` without an outer torchrun: become the launcher of N ranks (one per GPU)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, JB_BENCH_T0=repr(T_PROC))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+if __name__ == "__main__":
+    _a = _parse_args()
+    if _a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(_respawn_as_ranks(_a, sys.argv[1:]))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from jukebox_amd import sample as S  # noqa: E402
 from jukebox_amd.hparams import Hyperparams, setup_hparams  # noqa: E402
 from jukebox_amd.make_models import MODELS, make_prior, make_vqvae  # noqa: E402
 from jukebox_amd.utils import dist_adapter as dist  # noqa: E402
 from jukebox_amd.utils.dist_utils import setup_dist_from_env  # noqa: E402
+
+BUDGET_S = float(os.environ.get("JB_BENCH_BUDGET_S", "1400"))
+T_ORIGIN = float(os.environ.get("JB_BENCH_T0", repr(T_PROC)))
+
+
+def budget_left():
+    return BUDGET_S - (time.time() - T_ORIGIN)
+
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md)
 try:
@@ -77,13 +131,35 @@ def synthetic_labels(priors, n_samples, total_length, device):
     return labels
 
 
-def cpu_baseline(prior, n_batch, steps, total_decode_steps, audio_seconds):
-    """CPU port of the decode step (oracle/torch_port.py: the oracle's algorithm on the torch CPU kernels the reference
-    itself would run on; pinned to the numpy oracle by tests/test_oracle_golden.py) timed on this box's host cores on a
-    bounded sample: `steps` decode steps of the level-0 upsampler's transformer at batch n_batch, fp32.  The thread count
-    is chosen by a short sweep (16-row matmuls do not scale to hundreds of threads).  Calibration against the unmodified
-    reference in the build container (8 cores, tests/golden/time_reference_cpu.py): reference 182 ms, this port 131 ms,
-    numpy oracle 469 ms per step -- the port is the faster (conservative) stand-in."""
+def cpu_baseline_reference(seconds, n_batch, budget_s):
+    """The UNMODIFIED reference on this box's host cores: oracle/time_reference.py in a subprocess (its import shim
+    monkey-patches torch, so it cannot share a process with the GPU path) against the snapshot oracle/_ref made by
+    oracle/make_ref.py.  Bounded: about 25 s of timed CPU work + the construction of the reference model.  Returns the
+    cpu_baseline object (kind "reference") or None when the snapshot is absent or the leg fails."""
+    script = os.path.join(ROOT, "oracle", "time_reference.py")
+    if not os.path.isdir(os.path.join(ROOT, "oracle", "_ref", "jukebox")) or not os.path.exists(script):
+        return None
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, script, "--budget-s", str(budget_s), "--batch", str(n_batch), "--seconds", str(seconds)],
+                           env=env, capture_output=True, text=True, timeout=max(60.0, 3.5 * budget_s))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        sys.stderr.write(f"cpu_baseline (reference) produced no JSON, rc={r.returncode}: {r.stderr[-400:]}\n")
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        sys.stderr.write(f"cpu_baseline (reference) failed: {e}\n")
+    return None
+
+
+def cpu_baseline_port(prior, n_batch, steps, total_decode_steps, audio_seconds):
+    """Fallback when oracle/_ref is absent: CPU port of the decode step (oracle/torch_port.py: the oracle's algorithm on
+    the torch CPU kernels, with preallocated k/v caches; pinned to the numpy oracle by tests/test_oracle_golden.py) timed
+    on this box's host cores: `steps` decode steps of the level-0 upsampler's transformer at batch n_batch, fp32, early
+    positions.  It is FASTER than the unmodified reference (no per-step cache re-copy: the reference's step grows from
+    0.2 s at t=0 to 1.5 s at t=6144 on 8 cores, this port stays at ~0.13 s), so it flatters the CPU."""
     from oracle.torch_port import TorchDecodeStack
     ar = prior.prior
     sd = {k: v.detach().float().cpu().numpy() for k, v in ar.transformer.state_dict().items()}
@@ -114,7 +190,7 @@ def cpu_baseline(prior, n_batch, steps, total_decode_steps, audio_seconds):
                 sample=f"{steps} consecutive decode steps of the level-0 upsampler transformer (early positions) at batch "
                        f"{n_batch}, torch-CPU fp32 port of the oracle (oracle/torch_port.py): {sec_per_step * 1e3:.1f} ms/step, "
                        f"extrapolated over the {total_decode_steps} decode steps of the workload (prefill, conditioner and "
-                       "VQ-VAE conv stacks are not charged to the CPU)")
+                       "VQ-VAE conv stacks are not charged to the CPU; faster than the unmodified reference, see docstring)")
 
 
 def projection_roofline(eng, t0, n_steps):
@@ -124,16 +200,22 @@ def projection_roofline(eng, t0, n_steps):
     achieved = abytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
     # their own rocprofv3 runs on the same kernel/shapes (profiles/r01_pmc_dominant_kernel.json); null otherwise
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")))
-        if int(pmc["algorithmic_bytes_per_launch"]) == int(abytes):
-            traffic = int(pmc["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, source = None, None
+    for name in ("r02_pmc_dominant_kernel.json", "r01_pmc_dominant_kernel.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if int(pmc["algorithmic_bytes_per_launch"]) == int(abytes):
+                traffic = int(pmc["traffic_bytes_per_launch"])
+                source = f"profiles/{name} (separate rocprofv3 --pmc passes on the same kernel and shapes; NOT measured in this run)"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     return dict(bound="hbm", kernel="gemv_lnf_kernel<f16> (LayerNorm-folded attn.c_attn / mlp.c_fc of the decode step)",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=traffic, avg_launch_us=round(us, 3), launches_timed=launches, bytes_per_launch=int(abytes))
+                traffic=traffic, traffic_source=source, avg_launch_us=round(us, 3), launches_timed=launches,
+                bytes_per_launch=int(abytes),
+                timing="HIP events on the launch stream around a back-to-back burst of exactly these launches over all "
+                       "layers (cold weights per launch, as in the real step)")
 
 
 def roofline_only(a, device):
@@ -161,26 +243,72 @@ def roofline_only(a, device):
     print(json.dumps(out))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--model", default="1b_lyrics")
-    ap.add_argument("--seconds", type=float, default=20.0)
-    ap.add_argument("--samples-per-gpu", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=128)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="run the levels strictly one after the other (the reference's order) instead of pipelining them")
-    ap.add_argument("--roofline-only", action="store_true",
-                    help="build only the level-0 upsampler, run a short decode burst and print the roofline block "
-                         "(the command profiled under profiles/)")
-    a = ap.parse_args()
+def timed_steps(step_fn, requested, world, device, tail_reserve_s, sync):
+    """Time full steps: barrier + device sync on both sides, MAX over ranks.  Every rank takes the same decision to go on
+    (all-reduced), so the barrier count matches.  Returns (steps_timed, seconds, per_step_seconds, last_result)."""
+    on_gpu = device.type == "cuda"
 
+    def agree(flag):
+        if world == 1:
+            return flag
+        tdev = device if torch.distributed.get_backend() != "gloo" else "cpu"
+        f = torch.tensor([1 if flag else 0], dtype=torch.int32, device=tdev)
+        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MIN)
+        return bool(int(f.item()))
+
+    if world > 1:
+        torch.distributed.barrier()
+    sync()
+    t0 = time.perf_counter()
+    done, per_step, out = 0, [], None
+    while True:
+        ts = time.perf_counter()
+        out = step_fn()
+        sync()
+        per_step.append(time.perf_counter() - ts)
+        done += 1
+        more = done < requested and budget_left() > 1.08 * max(per_step) + tail_reserve_s
+        if not agree(more):
+            break
+    sync()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdev = device if (on_gpu and torch.distributed.get_backend() != "gloo") else "cpu"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return done, dt, per_step, out
+
+
+def dist_info(world):
+    return dict(world_size=world, backend=(torch.distributed.get_backend() if world > 1 else "none"),
+                launcher="torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "single process")
+
+
+def dry_run(a, rank, world, device):
+    """No GPU work (see --dry-run): same launcher, bootstrap, budgeted loop and JSON layout, every step a sleep."""
+    n_samples = a.samples_per_gpu * world
+    audio = n_samples * a.seconds
+    done, dt, per_step, _ = timed_steps(lambda: time.sleep(0.02 * (1 + rank)), max(a.steps, 1), world, device, 0.0, lambda: None)
+    if rank != 0:
+        return
+    print(json.dumps(dict(metric=BASELINE_METRIC, value=round(audio * done / dt, 4), unit="audio_s/s", n_gpus=world, steps=done,
+                          warmup=0, steps_requested=a.steps, warmup_requested=a.warmup, ms_per_step=round(dt / done * 1e3, 1),
+                          higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f16",
+                          data="dry-run (no GPU work; launcher / rank bootstrap / step loop only)",
+                          config=dict(workload="dry-run", samples_per_gpu=a.samples_per_gpu, parallelism=f"sample-sharded x{world}"),
+                          dist=dist_info(world), roofline=None, cpu_baseline=None)))
+
+
+def main():
+    a = _parse_args()
     rank, local_rank, device = setup_dist_from_env()
     world = dist.get_world_size()
-    assert world == a.gpus or world == 1, f"launched with {world} ranks but --gpus {a.gpus}"
+    assert world == a.gpus, f"running as {world} rank(s) but --gpus {a.gpus} (launch with torch.distributed.run or let bench.py spawn the ranks)"
+    if a.dry_run:
+        return dry_run(a, rank, world, device)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
 
     if a.roofline_only:
@@ -192,7 +320,7 @@ def main():
     vq, priors = build_models(a.model, sample_length, device)
     n_samples = a.samples_per_gpu * world
     hps = Hyperparams(n_samples=n_samples, sample_length=sample_length, hop_fraction=[0.5, 0.5, 0.125], sr=sr, name="bench",
-                      keep_priors_resident=True, pipeline_levels=not a.no_pipeline)
+                      keep_priors_resident=True, pipeline_levels=not a.no_pipeline, seed=0)
     labels = synthetic_labels(priors, n_samples, 180 * sr if not tiny else 3 * 4608, device)
     sk = S.default_sampling_kwargs(a.model if not tiny else "1b_lyrics")
     audio_seconds_per_step = n_samples * sample_length / sr
@@ -207,71 +335,79 @@ def main():
         level_t0.setdefault(level, []).append(time.perf_counter())
     S._sample.level_done, S._sample.level_start = mark, mark_start
 
+    step_t0 = []
+
     def one_step():
+        step_t0.append(time.perf_counter())
         return S.ancestral_sample(labels, sk, priors, hps, save=False, device=device)
 
-    # Warm-up passes are untimed: they run the same three-level job on 6 s of audio (every kernel, graph capture and
-    # allocation of the timed step, 1/3 of its length) so that `--warmup W` does not cost W x 5 minutes.
+    # Warm-up (untimed): at most ONE pass of the same three-level job on 6 s of audio per sample -- every kernel, graph
+    # capture and allocation of the timed step without its length (a full-length pass costs minutes).
     warm_len = min(sample_length, int(6.0 * sr) // hop * hop) if not tiny else sample_length
     warm_hps = Hyperparams(hps)
     warm_hps.sample_length = warm_len
-    for _ in range(a.warmup):
+    n_warm = 0
+    if a.warmup > 0 and budget_left() > 600:
         S.ancestral_sample(labels, sk, priors, warm_hps, save=False, device=device)
+        n_warm = 1
     level_t.clear()
     level_t0.clear()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        zs = one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else device)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+    cpu_leg_s = 0.0 if (world > 1 or a.no_cpu_baseline) else 120.0
+    steps_done, dt, per_step, zs = timed_steps(one_step, max(a.steps, 1), world, device, 45.0 + cpu_leg_s,
+                                               lambda: torch.cuda.synchronize())
     assert all(int(z.shape[1]) == sample_length // p.raw_to_tokens for z, p in zip(zs, priors))
 
     if rank != 0:
         return
-    value = audio_seconds_per_step * a.steps / dt
-    # per-level wall time of the last step
-    breakdown = {"levels_pipelined": not a.no_pipeline}
-    if a.steps == 1:
-        for l in (2, 1, 0):          # seconds from the start of the step until level l had produced all its codes
-            breakdown[f"level{l}_codes_done_at_s"] = round(level_t[l][-1] - t0, 3)
-            if l in level_t0:        # tokens per second of the level while it was running (levels overlap when pipelined)
-                busy = max(level_t[l][-1] - level_t0[l][-1], 1e-9)
-                breakdown[f"level{l}_tokens_per_s"] = round(n_samples // world * (sample_length // priors[l].raw_to_tokens) / busy, 1)
+    value = audio_seconds_per_step * steps_done / dt
+    # per-level wall time of the LAST timed step
+    t_last = step_t0[-1]
+    breakdown = {"levels_pipelined": not a.no_pipeline, "step_seconds": [round(x, 2) for x in per_step]}
+    for l in (2, 1, 0):          # seconds from the start of the step until level l had produced all its codes
+        if l in level_t:
+            breakdown[f"level{l}_codes_done_at_s"] = round(level_t[l][-1] - t_last, 3)
+        if l in level_t0 and l in level_t:   # tokens per second of the level while it ran (levels overlap when pipelined)
+            busy = max(level_t[l][-1] - level_t0[l][-1], 1e-9)
+            breakdown[f"level{l}_tokens_per_s"] = round(n_samples // world * (sample_length // priors[l].raw_to_tokens) / busy, 1)
 
-    # dominant kernel, timed in situ with HIP events on the launch stream: the LayerNorm-fused weight-streaming
+    # dominant kernel, timed in situ with HIP events on the launch stream: the LayerNorm-folded weight-streaming
     # projections of the level-0 upsampler's decode step
-    eng = next(iter(priors[0].prior._engines.values()))
+    eng = priors[0].prior.bound_engine()
     roofline = projection_roofline(eng, 4096 if not tiny else 64, 16 if not tiny else 8)
-    # one decode step (graph replay) of the same engine
+    # one decode step (graph replay) of the same engine, against the algorithmic bytes of a step
     torch.cuda.synchronize()
     ts = time.perf_counter()
     n_probe = 64 if not tiny else 16
     eng.decode(4096 if not tiny else 64, n_probe)
     torch.cuda.synchronize()
-    breakdown["level0_decode_ms_per_token_step"] = round((time.perf_counter() - ts) / n_probe * 1e3, 4)
+    step_ms = (time.perf_counter() - ts) / n_probe * 1e3
+    breakdown["level0_decode_ms_per_token_step"] = round(step_ms, 4)
     breakdown["launches_per_token_step"] = eng.launches_per_step
+    step_bytes = eng.step_bytes(4096 if not tiny else 64)
+    breakdown["level0_decode_step_algorithmic_gb"] = round(step_bytes / 1e9, 4)
+    breakdown["level0_decode_step_frac_of_hbm_peak"] = round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
     out = dict(metric=BASELINE_METRIC, value=round(value, 4), unit="audio_s/s",
-               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 1),
+               n_gpus=world, steps=steps_done, warmup=n_warm, steps_requested=a.steps, warmup_requested=a.warmup,
+               ms_per_step=round(dt / steps_done * 1e3, 1),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
                config=dict(workload=f"{a.model} full 3-level ancestral sample (top prior + 2 upsamplers + VQ-VAE decode), "
                                     f"{sample_length / sr:.2f} s audio at {sr} Hz, n_samples={n_samples} "
                                     f"({a.samples_per_gpu}/GPU), temp=0.99, fp16 activations and weights, "
                                     "hop_fraction=(0.5,0.5,0.125), random-init weights",
-                           samples_per_gpu=a.samples_per_gpu, parallelism=f"sample-sharded x{world}"),
-               roofline=roofline, breakdown=breakdown)
+                           samples_per_gpu=a.samples_per_gpu, parallelism=f"sample-sharded x{world}",
+                           wall_budget_s=BUDGET_S,
+                           note="a step is the whole 3-level job; the run times as many full steps as fit the wall budget "
+                                "(steps <= steps_requested), after at most one short warm-up pass"),
+               dist=dist_info(world), roofline=roofline, breakdown=breakdown)
     if world == 1 and not a.no_cpu_baseline:
-        total_steps = sum(sample_length // p.raw_to_tokens for p in priors)
-        out["cpu_baseline"] = cpu_baseline(priors[0], a.samples_per_gpu, a.cpu_steps, total_steps, audio_seconds_per_step)
+        cb = None
+        if not tiny and budget_left() > 90:
+            cb = cpu_baseline_reference(sample_length / sr, a.samples_per_gpu, 45.0)
+        if cb is None:
+            total_steps = sum(sample_length // p.raw_to_tokens for p in priors)
+            cb = cpu_baseline_port(priors[0], a.samples_per_gpu, a.cpu_steps if not tiny else 4, total_steps, audio_seconds_per_step)
+        out["cpu_baseline"] = cb
     print(json.dumps(out))
 
 

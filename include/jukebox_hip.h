@@ -101,7 +101,6 @@ typedef struct jb_gemv_args {
     int act;
     int qkv_split, S;
     void* kcache; void* vcache; int cache_cap; const int* t_dev;
-    const void* prefetch; int64_t prefetch_bytes;   /* optional: memory the NEXT launch will stream (touched early, values unused) */
     /* Folded LayerNorm (ln_gamma == ln_beta == NULL, ln_fold_c1 != NULL): LN(x)·W + b is evaluated as
      *     rstd[n] * (x[n]·W' - mean[n] * c1[j]) + b'[j],   W' = diag(gamma)·W,  c1 = column sums of W' as stored,
      *     b' = beta·W + b,
@@ -109,31 +108,20 @@ typedef struct jb_gemv_args {
      * from the same operand fragments while the weight stream is in flight.  The caller passes W = packed W',
      * bias = b', ln_fold_c1 = c1 (J floats).  Only where jb_gemv_ln_fold_supported() says so. */
     const float* ln_fold_c1;
+    /* Optional second output of the plain projection (no LayerNorm): out2[n][j] = float(out[n][j]) + add2[n*add2_n_stride
+     * + t*add2_t_stride + j], t = *t_dev (add2 may be NULL).  The decode step's last mlp.c_proj uses it to hand the
+     * logits head `x.float() + cond` (add_cond_after_transformer, jukebox/prior/autoregressive.py:226-227) without a
+     * separate launch. */
+    float* out2; int64_t ldo2; const float* add2; int64_t add2_n_stride, add2_t_stride;
+    /* Optional operand from the key-split decode attention (x == NULL, fp16, n_rows <= 32): row n of the input is the
+     * log-sum-exp merge of the n_parts partial softmax states written by jb_attn_decode_split,
+     *     x[n][k] = sum_s w_s * x_parts[(n*n_parts + s)*K + k],  w_s from x_ml[((n*n_head + k/d_head)*n_parts + s)*2 + {0,1}]
+     * rounded to half once (the attention output of factored_attention.py:107-108).  attn.c_proj of the decode step. */
+    const void* x_parts; const float* x_ml; int n_parts, n_head, d_head;
 } jb_gemv_args;
 int jb_gemv(const jb_gemv_args* args /* host */, void* stream);
 /* 1 if jb_gemv accepts ln_fold_c1 for this problem (whole k-tiles, the rows' operand fragments fit in registers). */
 int jb_gemv_ln_fold_supported(int dtype, int K, int J, int n_rows);
-
-/* EXPERIMENTAL (decode step with jb_engine_cfg.fused_pairs): two dependent projections in one launch, fp16, n_rows <= 16.
- *   part A (J_a/16 workgroups):  out_a = res + in1 . Wa + bias_a                   -- a residual row, tile by tile; each
- *                                tile publishes its per-row (sum, sum of squares) into `stats`, tagged with *epoch_dev;
- *   part B (J_b/16 workgroups):  out_b = act(rstd * ([in0 | in1] . Wb + k_b - mean * c1_b) + bias_b)
- *                                with mean / rstd of the out_a rows (LayerNorm folded: Wb = [diag(gamma).W ; Wa.diag(gamma).W],
- *                                k_b = bias_a . diag(gamma).W, c1_b = column sums of diag(gamma).W, bias_b = beta.W + b).
- * stats: J_a/16 x 16 x 2 64-bit words, zero-initialised; *epoch_dev must differ between successive launches that
- * share a stats buffer (never 0).  *error_flag is set if a part-B workgroup gave up waiting for statistics. */
-typedef struct jb_gemv_pair_args {
-    int n_rows;
-    const void* in1; int64_t ld1; int K1;
-    const void* Wa; const float* bias_a; const void* res; int64_t ldr; void* out_a; int64_t ldo_a; int J_a;
-    const void* in0; int64_t ld0; int K0;
-    const void* Wb; const float* k_b; const float* c1_b; const float* bias_b; int J_b; int act;
-    void* out_b; int64_t ldo_b;
-    int qkv_split, S; void* kcache; void* vcache; int cache_cap; const int* t_dev;
-    float ln_eps;
-    void* stats; const unsigned* epoch_dev; int* error_flag;
-} jb_gemv_pair_args;
-int jb_gemv_pair(const jb_gemv_pair_args* args /* host */, void* stream);
 
 /* Single-query cached attention for the decode step: one workgroup per (sample, head); the key
  * set is derived on the device from *t_dev and the pattern, softmax in fp32.
@@ -148,10 +136,20 @@ int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const v
  * the generic kernel of jb_attn_decode (defaults 512 / 4; a value <= 0 keeps the current one).  kb < 0 disables the
  * fp16 MFMA fast path (QK^T on MFMA) so that the generic kernel runs for every dtype. */
 void jb_tune_attn_decode(int threads, int kb);
-/* fp16 MFMA fast path: 0 (default) = one workgroup per (sample, head); 1 = channel-split workgroups (several per
- * (sample, head), each owning <= 128 value channels and recomputing the scores) -- slower on MI355X at the released
- * model sizes, kept as a tuning knob. */
-void jb_tune_attn_decode_parts(int enable);
+/* Key-split decode attention (fp16; d_head = 32 x {1,2,4,8,15,16}): n_parts workgroups per (sample, head), each taking
+ * every n_parts-th group of 16-key tiles and writing its own softmax state UNMERGED --
+ *   parts[(n*n_parts + s)*S + h*d_head + c] = sum_k p_k v_k[c] / l_s (f16),   ml[((n*n_head + h)*n_parts + s)*2] = (m_s, l_s)
+ * -- for jb_gemv's x_parts operand (attn.c_proj merges while it loads).  One CU cannot pull a whole 128-key K/V set
+ * faster than the rest of the chip does everything else, so the decode step spreads each (sample, head) over CUs.
+ * max_keys: upper bound of the key-set size of this layer over the whole sequence (block_ctx, blocks, seq_len, ...).
+ * Same reference code as jb_attn_decode. */
+int jb_attn_decode_split(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache, int cache_cap,
+                         void* parts, float* ml, int n_batch, int n_head, int d_head, int block_ctx, const int* t_dev,
+                         int max_keys, int n_parts, void* stream);
+/* Recommended n_parts (1..4) for a layer, 0 when the shape is outside the split kernel's envelope. */
+int jb_attn_decode_split_parts(int dtype, int d_head, int max_keys);
+/* Tuning hook: most splits per (sample, head) (1..4, default 4) and waves per split workgroup for short key sets (default 2). */
+void jb_tune_attn_decode_split(int max_parts, int waves);
 
 /* Chunked-prefill attention (q_l > 1) on MFMA with LDS-staged k/v tiles and online softmax:
  * queries at positions t0 .. t0+n_q-1 against the caches (already holding those positions).
@@ -160,8 +158,9 @@ void jb_tune_attn_decode_parts(int enable);
  * q, out: [n][n_q][S]. */
 int jb_attn_prefill(int dtype, int attn_func, const void* q, const void* kcache, const void* vcache, int cache_cap,
                     void* out, int n_batch, int n_head, int d_head, int block_ctx, int t0, int n_q, void* stream);
-/* EXPERIMENTAL: 1 = fp16 prefill attention with 4-wave workgroups sharing vector-staged K/V tiles (every pattern except
- * transpose); default 0. */
+/* 1 (default) = fp16 prefill attention with 4-wave workgroups sharing vector-staged K/V tiles (every pattern except
+ * transpose, which keeps the one-wave kernel); 0 = the one-wave kernel everywhere.  Measured on MI355X (upsampler,
+ * 4096 x 16 tokens): 586 -> 459 ms per primed window. */
 void jb_tune_attn_prefill_v2(int enable);
 
 /* Attention probabilities of one head for queries t0..t0+n_q-1 (softmax over each query's pattern key set), fp32 rows
@@ -188,12 +187,24 @@ int jb_final_add(int h_dtype, const void* h, float* xf, int64_t xf_n_stride, con
 
 /* Temperature, top-k / nucleus filtering and categorical sampling of one token per row, written to
  * tokens[n][t] (t = *t_dev); optional copy of the raw logits to preds[n][t][bins].
- * autoregressive.py:233-235 + filter_logits (jukebox/transformer/ops.py:113-142).  Randomness is a
- * counter-based stream keyed by (seed, sample_base + n, t); top_k == 1 is argmax (lowest index on ties). */
-typedef struct jb_sample_params { float temp; int top_k; float top_p; int sample_base; uint64_t seed; } jb_sample_params;
+ * autoregressive.py:233-235 + filter_logits (jukebox/transformer/ops.py:113-142).  Randomness is a counter-based
+ * (Philox4x32-10) uniform keyed by (seed, stream_id, sample_base + n, pos_base + t): stream_id separates the levels of
+ * one job, pos_base is the window's start so that the position is ABSOLUTE -- no two windows, levels or samples share a
+ * draw.  top_k == 1 is argmax (lowest index on ties).  bins <= 4096. */
+typedef struct jb_sample_params {
+    float temp; int top_k; float top_p; int sample_base; uint64_t seed; int pos_base; int stream_id;
+} jb_sample_params;
 int jb_sample_logits(const float* logits, int n_batch, int bins, const jb_sample_params* params /* device */,
                      int64_t* tokens, int64_t tok_stride, const int* t_dev, float* preds, int64_t preds_n_stride,
                      void* stream);
+/* The decode step's tail in one launch: jb_sample_logits, then the embedding of the NEXT position
+ * x_next[n] = x_emb[token] + pos_emb[t+1] + x_cond[n][t+1] (jb_embed for position t+1; skipped when t+1 == seq_len),
+ * then *t_dev = t + 1 by the workgroup that finishes last (*ticket: device counter, zero before the first call,
+ * left at zero). */
+int jb_sample_step(const float* logits, int n_batch, int bins, const jb_sample_params* params /* device */, int64_t* tokens,
+                   int64_t tok_stride, int* t_dev, float* preds, int64_t preds_n_stride, int x_dtype, void* x_next,
+                   const float* x_emb, const float* pos_emb, const float* x_cond, int64_t xc_n_stride, int64_t xc_t_stride,
+                   int width, int seq_len, unsigned* ticket, void* stream);
 
 /* Codebook gather (BottleneckBlock.dequantise/decode, jukebox/vqvae/bottleneck.py:121-123,138-147),
  * output channels-last rows [n*T][emb_width] fp32. */
@@ -221,11 +232,6 @@ typedef struct jb_layer {
      * diag(gamma)·W, beta·W + b, column sums.  NULL = the decode step normalises rows in the projection kernel.
      * Prefill always uses w_attn / w_fc with an explicit LayerNorm. */
     const void *w_attn_f, *w_fc_f; const float *b_attn_f, *b_fc_f, *c1_attn, *c1_fc;
-    /* EXPERIMENTAL, jb_engine_cfg.fused_pairs (see jb_gemv_pair): packed [diag(g1).Wfc ; Wproj.diag(g1).Wfc]
-     * (K = width + n_state, J = n_mlp) with k_f = b_proj.diag(g1).Wfc, and -- except in the last layer -- packed
-     * [diag(g0').Wattn' ; Wproj2.diag(g0').Wattn'] of the NEXT layer (K = width + n_mlp, J = 3 n_state) with
-     * k_a = b_proj2.diag(g0').Wattn'; stats_1 / stats_2: (width/16) x 16 x 2 64-bit words each, zeroed. */
-    const void *w_pf, *w_2a; const float *k_f, *k_a; void *stats_1, *stats_2;
 } jb_layer;
 
 typedef struct jb_engine_cfg {
@@ -239,14 +245,13 @@ typedef struct jb_engine_cfg {
     int add_cond_after;
     const void* encoder_kv; int enc_len;                   /* [n][enc_len][width], engine dtype (cross-attention models) */
     float* hidden_out; int64_t hidden_n_stride;            /* optional: final hidden states of prefilled positions, fp32 [n][seq_len][width] */
-    int prefetch_next_weights;                             /* decode step: each projection touches the next one's weights */
-    /* EXPERIMENTAL: decode step with 3 launches per layer (attention | c_proj + c_fc | mlp.c_proj + next c_attn), fp16,
-     * n_batch <= 16, no cross-attention layers; needs the folded images and jb_layer.w_pf / w_2a of every layer.
-     * epoch_dev: device counter, >= 1, advanced by the engine every step; pair_error: device flag (see jb_gemv_pair). */
-    int fused_pairs; unsigned* epoch_dev; int* pair_error;
     /* decode-step work buffers */
     void *x_a, *x_b, *q, *att, *mlp;                        /* engine dtype: [n][W],[n][W],[n][S],[n][S],[n][M] */
     float *xf, *logits;                                    /* [n][W], [n][bins] */
+    /* key-split decode attention (fp16 engines, see jb_attn_decode_split): att_parts [n][4][S] engine dtype,
+     * att_ml [n][n_head][4][2] fp32; NULL = one workgroup per (sample, head) (jb_attn_decode) */
+    void* att_parts; float* att_ml;
+    unsigned* ticket;                                      /* device counter for jb_sample_step, zero-initialised */
     /* prefill work buffers for chunks of <= chunk_cap positions */
     int chunk_cap;
     void *c_xa, *c_xb, *c_h, *c_q, *c_att, *c_mlp;          /* [n*chunk_cap][W|W|W|S|S|M] */
@@ -269,8 +274,9 @@ int jb_engine_destroy(void* handle);
 int jb_engine_set_encoder_kv(void* handle, void* stream);
 /* Prefill positions t0..t0+n_t-1 (tokens already in cfg.tokens): fills the k/v caches, leaves *t_dev = t0+n_t. */
 int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
-/* Run n_steps decode steps starting at position t0 (sets *t_dev = t0 first).  use_graph != 0 captures one step
- * into a hipGraph on first use and replays it. */
+/* Run n_steps decode steps starting at position t0 (sets *t_dev = t0 and embeds position t0 first).  One step =
+ * L x [c_attn | attention | attn.c_proj | mlp.c_fc | mlp.c_proj] | logits | sample + embed(t+1) + counter: 5 L + 2 launches.
+ * use_graph != 0 captures one step into a hipGraph on first use and replays it. */
 int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
 /* Measurement aid: n_steps passes over all layers launching only the LayerNorm-fused projections (attn.c_attn and
  * mlp.c_fc -- the dominant kernel of the decode step) with their real arguments, back to back on `stream`, bracketed
@@ -279,6 +285,9 @@ int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* str
 int jb_engine_probe_projection(void* handle, int t0, int n_steps, void* stream, double* out /* host, 3 doubles */);
 /* Number of kernel launches in one decode step (for launch-overhead accounting). */
 int jb_engine_launches_per_step(void* handle);
+/* Algorithmic HBM bytes of one decode step at position t (weights once per step + k/v rows read
+ * and written + logits head + activation rows). */
+double jb_engine_step_bytes(void* handle, int t);
 
 #ifdef __cplusplus
 }

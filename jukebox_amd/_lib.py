@@ -30,22 +30,15 @@ class GemvArgs(C.Structure):
                 ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
                 ("W", vp), ("bias", vp), ("K", i32), ("J", i32), ("out", vp), ("ldo", i64),
                 ("res", vp), ("ldr", i64), ("act", i32), ("qkv_split", i32), ("S", i32),
-                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp), ("prefetch", vp), ("prefetch_bytes", i64),
-                ("ln_fold_c1", vp)]
-
-
-class GemvPairArgs(C.Structure):
-    _fields_ = [("n_rows", i32), ("in1", vp), ("ld1", i64), ("K1", i32),
-                ("Wa", vp), ("bias_a", vp), ("res", vp), ("ldr", i64), ("out_a", vp), ("ldo_a", i64), ("J_a", i32),
-                ("in0", vp), ("ld0", i64), ("K0", i32),
-                ("Wb", vp), ("k_b", vp), ("c1_b", vp), ("bias_b", vp), ("J_b", i32), ("act", i32),
-                ("out_b", vp), ("ldo_b", i64),
-                ("qkv_split", i32), ("S", i32), ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp),
-                ("ln_eps", f32), ("stats", vp), ("epoch_dev", vp), ("error_flag", vp)]
+                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp),
+                ("ln_fold_c1", vp),
+                ("out2", vp), ("ldo2", i64), ("add2", vp), ("add2_n_stride", i64), ("add2_t_stride", i64),
+                ("x_parts", vp), ("x_ml", vp), ("n_parts", i32), ("n_head", i32), ("d_head", i32)]
 
 
 class SampleParams(C.Structure):
-    _fields_ = [("temp", f32), ("top_k", i32), ("top_p", f32), ("sample_base", i32), ("seed", C.c_uint64)]
+    _fields_ = [("temp", f32), ("top_k", i32), ("top_p", f32), ("sample_base", i32), ("seed", C.c_uint64),
+                ("pos_base", i32), ("stream_id", i32)]
 
 
 class Layer(C.Structure):
@@ -53,8 +46,7 @@ class Layer(C.Structure):
                 ("b_attn", vp), ("b_proj", vp), ("b_fc", vp), ("b_proj2", vp),
                 ("ln0_g", vp), ("ln0_b", vp), ("ln1_g", vp), ("ln1_b", vp),
                 ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("w_enc_k", vp), ("w_enc_v", vp), ("b_enc_kv", vp),
-                ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp),
-                ("w_pf", vp), ("w_2a", vp), ("k_f", vp), ("k_a", vp), ("stats_1", vp), ("stats_2", vp)]
+                ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp)]
 
 
 class EngineCfg(C.Structure):
@@ -62,8 +54,8 @@ class EngineCfg(C.Structure):
                 ("n_layers", i32), ("seq_len", i32), ("block_ctx", i32), ("bins", i32), ("ln_eps", f32),
                 ("x_emb", vp), ("pos_emb", vp), ("x_out_packed", vp), ("start", vp), ("start_stride", i64),
                 ("x_cond", vp), ("xc_n_stride", i64), ("xc_t_stride", i64), ("add_cond_after", i32), ("encoder_kv", vp), ("enc_len", i32), ("hidden_out", vp), ("hidden_n_stride", i64),
-                ("prefetch_next_weights", i32), ("fused_pairs", i32), ("epoch_dev", vp), ("pair_error", vp),
                 ("x_a", vp), ("x_b", vp), ("q", vp), ("att", vp), ("mlp", vp), ("xf", vp), ("logits", vp),
+                ("att_parts", vp), ("att_ml", vp), ("ticket", vp),
                 ("chunk_cap", i32), ("c_xa", vp), ("c_xb", vp), ("c_h", vp), ("c_q", vp), ("c_att", vp),
                 ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
                 ("preds", vp), ("preds_n_stride", i64), ("sample_params", vp),
@@ -82,10 +74,11 @@ _SIGS = {
     "jb_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "jb_gemv": (i32, [C.POINTER(GemvArgs), vp]),
     "jb_gemv_ln_fold_supported": (i32, [i32, i32, i32, i32]),
-    "jb_gemv_pair": (i32, [C.POINTER(GemvPairArgs), vp]),
     "jb_attn_decode": (i32, [i32, i32, vp, i64, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "jb_tune_attn_decode": (None, [i32, i32]),
-    "jb_tune_attn_decode_parts": (None, [i32]),
+    "jb_attn_decode_split": (i32, [i32, vp, i64, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "jb_attn_decode_split_parts": (i32, [i32, i32, i32]),
+    "jb_tune_attn_decode_split": (None, [i32, i32]),
     "jb_tune_gemm_lds": (None, [i32]),
     "jb_tune_attn_prefill_v2": (None, [i32]),
     "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -93,6 +86,7 @@ _SIGS = {
     "jb_embed": (i32, [i32, vp, vp, i64, vp, vp, vp, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
     "jb_final_add": (i32, [i32, vp, vp, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp]),
     "jb_sample_logits": (i32, [vp, i32, i32, vp, vp, i64, vp, vp, i64, vp]),
+    "jb_sample_step": (i32, [vp, i32, i32, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp]),
     "jb_vq_gather": (i32, [vp, vp, vp, i64, i32, i32, vp]),
     "jb_vq_argmin": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
     "jb_engine_create": (i32, [C.POINTER(EngineCfg), C.POINTER(Layer), C.POINTER(vp)]),
@@ -102,6 +96,7 @@ _SIGS = {
     "jb_engine_decode": (i32, [vp, i32, i32, i32, vp]),
     "jb_engine_probe_projection": (i32, [vp, i32, i32, vp, C.POINTER(C.c_double)]),
     "jb_engine_launches_per_step": (i32, [vp]),
+    "jb_engine_step_bytes": (C.c_double, [vp, i32]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -129,8 +124,9 @@ def lib():
         # tuning knobs from the environment (tools/, bench.py and experiments share them): kernel-selection switches
         # that default to the measured-best variant
         env = os.environ.get
-        if env("JB_ATTN_PARTS") is not None:
-            l.jb_tune_attn_decode_parts(int(env("JB_ATTN_PARTS")))
+        if env("JB_ATTN_SPLIT") is not None:          # "max_parts,waves"
+            mp, wv = (int(v) for v in env("JB_ATTN_SPLIT").split(","))
+            l.jb_tune_attn_decode_split(mp, wv)
         if env("JB_PREFILL_V2") is not None:
             l.jb_tune_attn_prefill_v2(int(env("JB_PREFILL_V2")))
         if env("JB_GEMM_LDS_MIN_ROWS") is not None:

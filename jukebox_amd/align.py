@@ -30,11 +30,8 @@ def get_alignment(x, zs, labels, prior, fp16, hps, device="cuda"):
     ar = prior.prior
     prior.to(device)
     empty_cache()
-    eng = PriorEngine({k: v.detach() for k, v in ar.state_dict().items()}, "", n_batch=bs, seq_len=ar.input_dims,
-                      bins=ar.bins, width=ar.width, depth=ar.depth, heads=ar.heads, attn_order=ar.attn_order,
-                      blocks=ar.blocks, m_attn=ar.m_attn, m_mlp=ar.m_mlp, prime_len=ar.prime_len, y_cond=ar.y_cond,
-                      add_cond_after=ar.add_cond_after_transformer, fp16=fp16, chunk_cap=512,
-                      record=(alignment_layer, alignment_head, n_tokens), device=device)
+    # the prior's packed weights are shared with its sampling engines; only caches / work buffers / the recording are new
+    eng = PriorEngine(packed=ar.packed(fp16), n_batch=bs, chunk_cap=512, record=(alignment_layer, alignment_head, n_tokens))
     alignment_hops, indices_hops = {}, {}
     with t.no_grad():
         for start in get_starts(total_length, n_ctx, hop_length):

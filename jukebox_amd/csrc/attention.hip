@@ -269,34 +269,38 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     }
 }
 
-// Channel-split variant of the kernel above: grid.z workgroups per (sample, head), each owning `pc` value channels.
-// One CU can pull ~130 GB/s, so a single workgroup reading a whole 128-key K and V set (245 KB at d = 480) spends
-// longer on its own L1 fill than the rest of the chip would need for everything; here every part recomputes the (cheap,
-// MFMA) scores from the full keys but reads and accumulates only its slice of V.  The PV lanes are laid out as
-// (key group g, channel chunk c): lane (g, c) multiplies ITS four keys g*4 + r -- whose probabilities the score MFMA
-// left in its own registers -- into 8 channels, so no probability ever goes through LDS, and the four key groups are
-// summed once per wave after the last tile.  Softmax statistics are identical in all parts (same arithmetic on the
-// same inputs), so the parts never talk to each other.
+// Key-split variant of the kernel above (the decode step's default in fp16): grid (sample, head, split).  One CU pulls
+// ~100 GB/s, so a single workgroup reading a whole 128-key K and V set (245 KB at d = 480) spends 2-3 us on its own L1
+// fill -- longer than the rest of the chip needs for everything.  Here split s of n_parts takes the 16-key tiles
+// tt = s*nw + w + i*n_parts*nw (w = wave), keeps its own online-softmax state and writes it out UNMERGED:
+//     parts[n][s][h*d + ch] = sum_k p_k v_k[ch] / l_s   (f16; zeros when the split saw no key)
+//     ml[n][h][s]           = (m_s, l_s)                (running max and sum of exp(score - m_s); (-inf, 0) when empty)
+// The log-sum-exp merge over the splits happens in the operand load of attn.c_proj (gemv_merge_kernel, gemm.hip), so
+// the splits never wait for each other and there is no extra launch.
 template <int ND32>
-__global__ __launch_bounds__(512) void attn_decode_mfma_parts_kernel(int func, const f16* __restrict__ q, int64_t ldq,
-                                                                     const f16* __restrict__ kc, const f16* __restrict__ vc,
-                                                                     int cap, f16* __restrict__ out, int64_t ldo, int n_head,
-                                                                     int bc, const int* __restrict__ t_dev, int pc) {
+__global__ __launch_bounds__(512) void attn_decode_split_kernel(int func, const f16* __restrict__ q, int64_t ldq,
+                                                                const f16* __restrict__ kc, const f16* __restrict__ vc, int cap,
+                                                                f16* __restrict__ parts, float* __restrict__ ml, int n_head,
+                                                                int bc, const int* __restrict__ t_dev, int n_parts) {
     constexpr int d = ND32 * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* s_ml = smem;                      // [nw][2]
-    float* s_o = smem + 2 * nw;              // [nw][pc]
+    float* s_pw = smem + 2 * nw;             // [nw][16] probabilities of the wave's current tile
+    float* s_o = s_pw + 16 * nw;             // [nw][d]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int n = blockIdx.x, h = blockIdx.y, part = blockIdx.z;
+    const int n = blockIdx.x, h = blockIdx.y, split = blockIdx.z;
     const int S = n_head * d;
     const int t = *t_dev;
     const KeySet ks = decode_key_set(func, t, bc, cap);
-    f16* o = out + (int64_t)n * ldo + h * d + part * pc;
-    if (ks.count == 0) {
-        for (int i = threadIdx.x; i < pc; i += blockDim.x) o[i] = (f16)0;
+    f16* o = parts + ((int64_t)n * n_parts + split) * S + h * d;
+    float* oml = ml + (((int64_t)n * n_head + h) * n_parts + split) * 2;
+    const int ntiles = (ks.count + 15) >> 4;
+    if (split * nw >= ntiles) {              // nothing for this split (early positions, prev_block in block 0)
+        for (int i = threadIdx.x; i < d; i += blockDim.x) o[i] = (f16)0;
+        if (threadIdx.x == 0) { oml[0] = -INFINITY; oml[1] = 0.f; }
         return;
     }
     const float scale = 1.0f / sqrtf(sqrtf((float)d));
@@ -306,27 +310,27 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_parts_kernel(int func, c
 #pragma unroll
     for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
     const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
-    const int nchunk = pc >> 3;
-    const f16* vbase = vc + ((int64_t)n * cap) * S + h * d + part * pc + min(c, nchunk - 1) * 8;
+    const f16* vbase = vc + ((int64_t)n * cap) * S + h * d;
+    const int c0 = min(lane * 8, d - 8);     // this lane's value channels (lanes past d/8 compute unused duplicates)
 
     float m_w = -INFINITY, l_w = 0.f;
     float of[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) of[e] = 0.f;
+    float* pw = s_pw + 16 * wave;
 
-    const int ntiles = (ks.count + 15) >> 4;
-    for (int tt = wave; tt < ntiles; tt += nw) {
+    for (int tt = split * nw + wave; tt < ntiles; tt += n_parts * nw) {
         const int kbase_i = tt * 16;
         const int ki = min(kbase_i + c, ks.count - 1);
         const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * S + g * 8;
         f16x8 kf[ND32];
 #pragma unroll
         for (int dt = 0; dt < ND32; ++dt) kf[dt] = ld_frag<f16>(kr + dt * 32);
-        f16x8 vv[4];
+        f16x8 vv[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int vi = min(kbase_i + g * 4 + r, ks.count - 1);
-            vv[r] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * S);
+        for (int k = 0; k < 16; ++k) {
+            const int vi = min(kbase_i + k, ks.count - 1);
+            vv[k] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0);
         }
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -335,12 +339,13 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_parts_kernel(int func, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool ok = kbase_i + g * 4 + r < ks.count;
+            // reference: w = matmul(q, k) (half result), w.mul_(scale*scale) (half), then .float()
             pv[r] = ok ? jb_round<f16>(jb_round<f16>(sc[r]) * scale2) : -INFINITY;
             mx = fmaxf(mx, pv[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_w, mx);
+        const float m_new = fmaxf(m_w, mx);                 // finite: every tile has at least one valid key
         const float alpha = expf(m_w - m_new);
         float ps = 0.f;
 #pragma unroll
@@ -352,36 +357,36 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_parts_kernel(int func, c
         ps += __shfl_xor(ps, 32, 64);
         l_w = l_w * alpha + ps;
         m_w = m_new;
+        if (c == 0) *reinterpret_cast<f32x4*>(pw + g * 4) = f32x4{pv[0], pv[1], pv[2], pv[3]};
+        f32x4 p4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p4[i] = *reinterpret_cast<const f32x4*>(pw + i * 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) of[e] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float pr = jb_round<f16>(pv[r]);
+        for (int k = 0; k < 16; ++k) {
+            const float pr = jb_round<f16>(p4[k >> 2][k & 3]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) of[e] += pr * (float)vv[r][e];
+            for (int e = 0; e < 8; ++e) of[e] += pr * (float)vv[k][e];
         }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        of[e] += __shfl_xor(of[e], 16, 64);
-        of[e] += __shfl_xor(of[e], 32, 64);
-    }
     if (lane == 0) { s_ml[2 * wave] = m_w; s_ml[2 * wave + 1] = l_w; }
-    if (g == 0 && c < nchunk) {
+    if (lane * 8 < d) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_o[wave * pc + c * 8 + e] = of[e];
+        for (int e = 0; e < 8; ++e) s_o[wave * d + lane * 8 + e] = of[e];
     }
     __syncthreads();
     float m = -INFINITY;
-    for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);
+    for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);          // finite: wave 0 of this split had a tile
     float lsum = 0.f;
-    for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] * expf(s_ml[2 * w] - m);
+    for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] > 0.f ? s_ml[2 * w + 1] * expf(s_ml[2 * w] - m) : 0.f;
     const float inv = 1.0f / lsum;
-    for (int i = threadIdx.x; i < pc; i += blockDim.x) {
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
         float a = 0.f;
-        for (int w = 0; w < nw; ++w) a += s_o[w * pc + i] * expf(s_ml[2 * w] - m);
+        for (int w = 0; w < nw; ++w) a += s_ml[2 * w + 1] > 0.f ? s_o[w * d + i] * expf(s_ml[2 * w] - m) : 0.f;
         o[i] = (f16)(a * inv);
     }
+    if (threadIdx.x == 0) { oml[0] = m; oml[1] = lsum; }
 }
 
 // launch shape of the decode attention: threads per (sample, head) workgroup and key/value row pairs in flight per wave
@@ -391,8 +396,54 @@ extern "C" void jb_tune_attn_decode(int threads, int kb) {
     if (kb > 0) g_dec_kb = kb;
     g_dec_mfma = kb >= 0;          // kb < 0 selects the generic (vector-ALU QK^T) kernel for every dtype
 }
-static int g_dec_parts = 0;   // measured on MI355X (upsampler, N = 16): 2.35 ms/step with the split vs 2.14 without -- the 4x key re-reads cost more than the narrower V slices save
-extern "C" void jb_tune_attn_decode_parts(int enable) { g_dec_parts = enable != 0; }
+// key-split decode attention: most splits per (sample, head) and waves per split workgroup for short key sets
+static int g_split_max = 4, g_split_waves = 2;
+extern "C" void jb_tune_attn_decode_split(int max_parts, int waves) {
+    if (max_parts >= 1 && max_parts <= 4) g_split_max = max_parts;
+    if (waves >= 1 && waves <= 8) g_split_waves = waves;
+}
+static inline bool split_d_ok(int d_head) {
+    const int nd = d_head / 32;
+    return d_head % 32 == 0 && (nd == 1 || nd == 2 || nd == 4 || nd == 8 || nd == 15 || nd == 16);
+}
+// Splits per (sample, head) for a layer whose key set never exceeds max_keys; 0 = shape not supported (use jb_attn_decode).
+extern "C" int jb_attn_decode_split_parts(int dtype, int d_head, int max_keys) {
+    if (dtype != JB_F16 || !split_d_ok(d_head) || max_keys < 1) return 0;
+    const int tiles = (max_keys + 15) / 16;
+    int parts = (tiles + g_split_waves - 1) / g_split_waves;
+    return parts < 1 ? 1 : (parts > g_split_max ? g_split_max : parts);
+}
+
+extern "C" int jb_attn_decode_split(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache,
+                                    int cache_cap, void* parts, float* ml, int n_batch, int n_head, int d_head,
+                                    int block_ctx, const int* t_dev, int max_keys, int n_parts, void* stream) {
+    JB_REQUIRE(q && kcache && vcache && parts && ml && t_dev, "null pointer");
+    JB_REQUIRE(n_batch > 0 && n_head > 0 && max_keys > 0 && n_parts >= 1 && n_parts <= 4, "bad dims");
+    JB_REQUIRE(split_d_ok(d_head) && ldq % 8 == 0, "d_head must be 32 x {1,2,4,8,15,16} and q rows 16-byte aligned");
+    JB_REQUIRE(attn_func == 0 || attn_func == 7 || attn_func == 6 || block_ctx > 0, "block_ctx required");
+    const int tiles = (max_keys + 15) / 16;
+    int nw = (tiles + n_parts - 1) / n_parts;              // waves per split so that one pass covers the longest key set
+    nw = nw < 1 ? 1 : (nw > 8 ? 8 : nw);
+    if (nw < g_split_waves && tiles >= g_split_waves) nw = g_split_waves;
+    dim3 grid(n_batch, n_head, n_parts);
+    const size_t lds = (size_t)(2 * nw + 16 * nw + nw * d_head) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define JB_LAUNCH_DECS(ND)                                                                                          \
+    attn_decode_split_kernel<ND><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,        \
+                                                          (const f16*)vcache, cache_cap, (f16*)parts, ml, n_head,    \
+                                                          block_ctx, t_dev, n_parts)
+    switch (d_head / 32) {
+        case 1: JB_LAUNCH_DECS(1); break;
+        case 2: JB_LAUNCH_DECS(2); break;
+        case 4: JB_LAUNCH_DECS(4); break;
+        case 8: JB_LAUNCH_DECS(8); break;
+        case 15: JB_LAUNCH_DECS(15); break;
+        default: JB_LAUNCH_DECS(16); break;
+    }
+#undef JB_LAUNCH_DECS
+    JB_CHECK_LAUNCH();
+    return JB_OK;
+}
 
 extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache,
                               const void* vcache, int cache_cap, void* out, int64_t ldo, int n_batch, int n_head,
@@ -413,29 +464,6 @@ extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t l
     hipStream_t s = (hipStream_t)stream;
     if (dtype == JB_F16 && g_dec_mfma && d_head % 32 == 0 && d_head <= 512 && ldq % 8 == 0 && (n_head * d_head) % 8 == 0) {
         const int nwm = 8;
-        int parts = 1;
-        while (d_head / parts > 128) parts *= 2;
-        if (g_dec_parts && d_head % parts == 0 && (d_head / parts) % 8 == 0) {
-            const int pc = d_head / parts;
-            dim3 pgrid(n_batch, n_head, parts);
-            size_t ldsp = (size_t)(2 * nwm + nwm * pc) * sizeof(float);
-#define JB_LAUNCH_DECP(ND)                                                                                             \
-    attn_decode_mfma_parts_kernel<ND><<<pgrid, nwm * 64, ldsp, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,    \
-                                                                  (const f16*)vcache, cache_cap, (f16*)out, ldo, n_head, \
-                                                                  block_ctx, t_dev, pc)
-            switch (d_head / 32) {
-                case 1: JB_LAUNCH_DECP(1); break;
-                case 2: JB_LAUNCH_DECP(2); break;
-                case 4: JB_LAUNCH_DECP(4); break;
-                case 8: JB_LAUNCH_DECP(8); break;
-                case 15: JB_LAUNCH_DECP(15); break;
-                case 16: JB_LAUNCH_DECP(16); break;
-                default: goto generic;
-            }
-#undef JB_LAUNCH_DECP
-            JB_CHECK_LAUNCH();
-            return JB_OK;
-        }
         size_t ldsm = (size_t)(2 * nwm + 16 * nwm + nwm * d_head) * sizeof(float);
 #define JB_LAUNCH_DECM(ND)                                                                                      \
     attn_decode_mfma_kernel<ND><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,    \
@@ -659,7 +687,7 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(int func, const T* __r
         }
 }
 
-// EXPERIMENTAL (off by default, jb_tune_attn_prefill_v2): the prefill attention above with the staging fixed.
+// Default for fp16 (jb_tune_attn_prefill_v2(0) restores the kernel above): the prefill attention with the staging fixed.
 // attn_prefill_kernel runs one wave per 16-query tile and copies every K / V tile into its private LDS with 2-byte
 // loads; at the upsamplers' sizes that is 4 TFLOP/s.  Here a workgroup of 4 waves owns 4 consecutive query tiles of one
 // (sample, head) -- which share almost all of their keys under the dense / block / prev / prime / cross patterns -- and
@@ -820,7 +848,7 @@ __global__ __launch_bounds__(256) void attn_prefill_v2_kernel(int func, const f1
         }
 }
 
-static int g_prefill_v2 = 0;
+static int g_prefill_v2 = 1;   // measured on MI355X (upsampler, 4096 x 16 tokens per window): 586 ms (one-wave kernel) -> 459 ms
 extern "C" void jb_tune_attn_prefill_v2(int enable) { g_prefill_v2 = enable != 0; }
 
 extern "C" int jb_attn_prefill(int dtype, int attn_func, const void* q, const void* kcache, const void* vcache,

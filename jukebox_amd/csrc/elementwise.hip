@@ -4,6 +4,10 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
+// One wave per row.  Rows whose width is a multiple of 8 are read once with 16-byte (f16) / 32-byte (f32) loads into
+// registers (up to 8 vectors of 8 per lane: W <= 4096) and normalised from there -- two-pass statistics, one HBM read;
+// other widths take the scalar loop.
+template <typename T> struct Vec8 { T v[8]; };
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, TO* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -12,6 +16,50 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const TI* xr = x + row * W;
+    TO* yr = y + row * W;
+    if ((W & 7) == 0 && W <= 4096 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+        ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0) {
+        typedef Vec8<TI> __attribute__((aligned(sizeof(TI) * 8))) VI;
+        typedef Vec8<TO> __attribute__((aligned(sizeof(TO) * 8))) VO;
+        const int nvec = W >> 3;
+        VI xv[8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+                xv[i] = *reinterpret_cast<const VI*>(xr + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)xv[i].v[e];
+            }
+        }
+        const float mean = jb_wave_sum(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (lane + 64 * i < nvec) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)xv[i].v[e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(jb_wave_sum(q) / (float)W + eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = lane + 64 * i;
+            if (v < nvec) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8), b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
+                VO o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o.v[e] = (TO)(((float)xv[i].v[e] - mean) * rstd * g0[e] + b0[e]);
+                    o.v[e + 4] = (TO)(((float)xv[i].v[e + 4] - mean) * rstd * g1[e] + b1[e]);
+                }
+                *reinterpret_cast<VO*>(yr + v * 8) = o;
+            }
+        }
+        return;
+    }
     float s = 0.f;
     for (int k = lane; k < W; k += 64) s += (float)xr[k];
     const float mean = jb_wave_sum(s) / (float)W;
@@ -21,7 +69,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
         q += d * d;
     }
     const float rstd = 1.0f / sqrtf(jb_wave_sum(q) / (float)W + eps);
-    TO* yr = y + row * W;
     for (int k = lane; k < W; k += 64) yr[k] = (TO)(((float)xr[k] - mean) * rstd * gamma[k] + beta[k]);
 }
 
@@ -123,10 +170,12 @@ extern "C" int jb_final_add(int h_dtype, const void* h, float* xf, int64_t xf_n_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Philox4x32-10 counter-based generator: one independent stream per (seed, sample, position).
+// Philox4x32-10 counter-based generator: one independent uniform per (seed, stream, sample, absolute position).
+// `stream` separates the levels of one job, `pos` is the ABSOLUTE token position (window start + position in the
+// window), so successive windows and different levels never reuse a draw.
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-__device__ inline float philox_uniform(uint64_t seed, uint32_t sample, uint32_t pos) {
-    uint32_t c0 = sample, c1 = pos, c2 = 0x4a756b65u, c3 = 0x626f7821u;
+__device__ inline float philox_uniform(uint64_t seed, uint32_t stream, uint32_t sample, uint32_t pos) {
+    uint32_t c0 = sample, c1 = pos, c2 = 0x4a756b65u ^ stream, c3 = 0x626f7821u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -155,121 +204,205 @@ __device__ inline void bitonic_sort_desc(float* a, int n2) {
         }
 }
 
-// One workgroup per sample row.
+// 256-thread block primitives on wave shuffles: a wave-level step (6 cross-lane ops) plus one 4-entry LDS exchange.
+// `scratch` holds 8 floats; every call ends with the block synchronised and scratch reusable.
+__device__ __forceinline__ float wave_scan_incl(float v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+// inclusive prefix sum of v over the block in thread order; *total = sum over all threads
+__device__ __forceinline__ float block_scan_incl(float v, float* scratch, float* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inc = wave_scan_incl(v);
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    float base = 0.f, tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float sw = scratch[w];
+        base += w < wave ? sw : 0.f;
+        tot += sw;
+    }
+    __syncthreads();
+    *total = tot;
+    return inc + base;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = jb_wave_max(v);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    __syncthreads();
+    return m;
+}
+__device__ __forceinline__ int block_sum_int(int v, int* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int r = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+    return r;
+}
+
+// What the decode step does after a token has been drawn (all null / zero for the stand-alone operator): the embedding
+// of the NEXT position for this sample -- x_emb[token] + pos_emb[t+1] + x_cond[n][t+1] (get_emb, autoregressive.py:177-197)
+// -- written by the workgroup that drew the token, and the position counter, advanced by the workgroup that finishes
+// last (every workgroup has read *t_dev before it takes its ticket).  Two launches less per token step.
+struct SampleTail {
+    void* x_next; int x_dtype;
+    const float* x_emb; const float* pos_emb; const float* x_cond; int64_t xc_n, xc_t;
+    int W, seq_len;
+    int* t_dev_w; unsigned* ticket;
+};
+
+// One workgroup (4 waves) per sample row: temperature, top-k / nucleus filter, categorical draw.
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int bins, int n2,
                                                      const jb_sample_params* __restrict__ params,
                                                      int64_t* __restrict__ tokens, int64_t tok_stride,
                                                      const int* __restrict__ t_dev, float* __restrict__ preds,
-                                                     int64_t preds_n_stride) {
+                                                     int64_t preds_n_stride, SampleTail tail) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_x = sm;              // [bins] filtered, temperature-scaled logits
     float* s_sort = sm + n2;      // [n2] sort scratch (top-k / nucleus only)
-    __shared__ float s_red[256];
-    __shared__ int s_idx[256];
-    __shared__ float s_thr;
+    __shared__ float s_f[8];
+    __shared__ int s_i[8];
+    __shared__ int s_pick, s_owner;
     const int n = blockIdx.x, tid = threadIdx.x;
     const int t = *t_dev;
     const jb_sample_params P = *params;
     const float* row = logits + (int64_t)n * bins;
-    if (preds) {
-        float* pr = preds + (int64_t)n * preds_n_stride + (int64_t)t * bins;
-        for (int i = tid; i < bins; i += 256) pr[i] = row[i];
+    float* pr = preds ? preds + (int64_t)n * preds_n_stride + (int64_t)t * bins : nullptr;
+    for (int i = tid; i < bins; i += 256) {
+        const float v = row[i];
+        if (pr) pr[i] = v;
+        s_x[i] = v / P.temp;
     }
-    for (int i = tid; i < bins; i += 256) s_x[i] = row[i] / P.temp;
+    if (tid == 0) { s_pick = 0x7fffffff; s_owner = 0x7fffffff; }
     __syncthreads();
+    const int chunk = (bins + 255) / 256;
+    const int lo = min(tid * chunk, bins), hi = min(lo + chunk, bins);     // this thread's contiguous index range
 
     const int top_k = min(P.top_k, bins);
     if (top_k == 1) {
         // greedy: the filtered set is {max}; lowest index wins a tie
         float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int i = tid; i < bins; i += 256) {
-            float v = s_x[i];
-            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+        for (int i = lo; i < hi; ++i) {
+            const float v = s_x[i];
+            if (v > bv) { bv = v; bi = i; }
         }
-        s_red[tid] = bv; s_idx[tid] = bi;
+        const float m = block_max(bv, s_f);
+        if (bv == m && bi != 0x7fffffff) atomicMin(&s_pick, bi);
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) {
-                float v = s_red[tid + o]; int ix = s_idx[tid + o];
-                if (v > s_red[tid] || (v == s_red[tid] && ix < s_idx[tid])) { s_red[tid] = v; s_idx[tid] = ix; }
+    } else {
+        if (top_k > 1 || P.top_p > 0.f) {
+            for (int i = tid; i < n2; i += 256) s_sort[i] = i < bins ? s_x[i] : -INFINITY;
+            __syncthreads();
+            bitonic_sort_desc(s_sort, n2);
+            int keep = top_k;                                  // keep everything >= the k-th largest
+            if (top_k <= 1) {
+                // nucleus (ops.py:129-141): sorted entry i >= 1 is dropped iff the cumulative probability of entries
+                // 0..i-1 exceeds top_p, i.e. keep = 1 + #{j <= bins-2 : cumprob_j <= top_p}
+                const float mx = s_sort[0];
+                float e[16], loc = 0.f;
+                const int c2 = (n2 + 255) / 256, l2 = tid * c2;
+                for (int u = 0; u < c2 && u < 16; ++u) { e[u] = l2 + u < bins ? expf(s_sort[l2 + u] - mx) : 0.f; loc += e[u]; }
+                float tot;
+                float cum = block_scan_incl(loc, s_f, &tot) - loc;
+                int cnt = 0;
+                for (int u = 0; u < c2 && u < 16; ++u) {
+                    cum += e[u];
+                    if (l2 + u <= bins - 2 && cum / tot <= P.top_p) ++cnt;
+                }
+                keep = 1 + block_sum_int(cnt, s_i);
             }
+            const float thr = s_sort[keep - 1];
+            __syncthreads();
+            for (int i = tid; i < bins; i += 256)
+                if (s_x[i] < thr) s_x[i] = -INFINITY;
             __syncthreads();
         }
-        if (tid == 0) tokens[(int64_t)n * tok_stride + t] = s_idx[0];
-        return;
-    }
-    if (top_k > 1 || P.top_p > 0.f) {
-        for (int i = tid; i < n2; i += 256) s_sort[i] = i < bins ? s_x[i] : -INFINITY;
-        __syncthreads();
-        bitonic_sort_desc(s_sort, n2);
-        if (tid == 0) {
-            float thr;
-            if (top_k > 1) {
-                thr = s_sort[top_k - 1];                      // keep everything >= the k-th largest
-            } else {
-                // nucleus: sorted entry s is dropped iff the cumulative probability of entries < s exceeds top_p
-                float mx = s_sort[0], tot = 0.f;
-                for (int i = 0; i < bins; ++i) tot += expf(s_sort[i] - mx);
-                float cum = 0.f; int keep = 1;
-                for (int i = 0; i < bins - 1; ++i) {
-                    cum += expf(s_sort[i] - mx) / tot;
-                    if (cum > P.top_p) break;
-                    keep = i + 2;
-                }
-                thr = s_sort[keep - 1];
-            }
-            s_thr = thr;
+        // Categorical(logits).sample(): inverse CDF in index order.  Thread i owns the contiguous indices [lo, hi); the
+        // block prefix sum of the per-thread masses locates the owner of the target, which walks its own chunk.
+        float mloc = -INFINITY;
+        for (int i = lo; i < hi; ++i) mloc = fmaxf(mloc, s_x[i]);
+        const float m = block_max(mloc, s_f);
+        float part = 0.f;
+        int last_adm = -1;
+        for (int i = lo; i < hi; ++i) {
+            part += expf(s_x[i] - m);
+            if (s_x[i] > -INFINITY) last_adm = i;
         }
-        __syncthreads();
-        const float thr = s_thr;
-        for (int i = tid; i < bins; i += 256)
-            if (s_x[i] < thr) s_x[i] = -INFINITY;
-        __syncthreads();
-    }
-
-    // Categorical(logits).sample(): inverse CDF over contiguous per-thread chunks (index order)
-    float m = -INFINITY;
-    for (int i = tid; i < bins; i += 256) m = fmaxf(m, s_x[i]);
-    s_red[tid] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) s_red[tid] = fmaxf(s_red[tid], s_red[tid + o]);
-        __syncthreads();
-    }
-    m = s_red[0];
-    __syncthreads();
-    const int chunk = (bins + 255) / 256;
-    const int lo = tid * chunk, hi = min(lo + chunk, bins);
-    float part = 0.f;
-    for (int i = lo; i < hi; ++i) part += expf(s_x[i] - m);
-    s_red[tid] = part;
-    __syncthreads();
-    if (tid == 0) {
-        float total = 0.f;
-        for (int i = 0; i < 256; ++i) total += s_red[i];
-        const float u = philox_uniform(P.seed, (uint32_t)(P.sample_base + n), (uint32_t)t);
+        float total;
+        const float inc = block_scan_incl(part, s_f, &total);
+        const float u = philox_uniform(P.seed, (uint32_t)P.stream_id, (uint32_t)(P.sample_base + n), (uint32_t)(P.pos_base + t));
         const float target = u * total;
-        float cum = 0.f;
-        int c = 0;
-        for (; c < 255; ++c) {
-            if (cum + s_red[c] > target) break;
-            cum += s_red[c];
+        // owner = first thread whose inclusive mass exceeds the target (the prefix sums are monotone in thread order)
+        if (inc > target) atomicMin(&s_owner, tid);
+        __syncthreads();
+        if (tid == s_owner) {
+            float cum = inc - part;
+            int pick = last_adm;                               // rounding inside the chunk: its last admissible index
+            for (int i = lo; i < hi; ++i) {
+                cum += expf(s_x[i] - m);
+                if (cum > target && s_x[i] > -INFINITY) { pick = i; break; }
+            }
+            if (pick >= 0) s_pick = pick;
         }
-        int pick = -1, last_pos = 0;
-        for (int i = c * chunk; i < min((c + 1) * chunk, bins); ++i) {
-            float e = expf(s_x[i] - m);
-            if (e > 0.f) last_pos = i;
-            cum += e;
-            if (cum > target) { pick = i; break; }
+        __syncthreads();
+        if (s_pick == 0x7fffffff) {
+            // rounding pushed the target past the end: take the last admissible index of the row
+            int la = last_adm;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) la = max(la, __shfl_xor(la, o, 64));
+            if ((tid & 63) == 0) s_i[tid >> 6] = la;
+            __syncthreads();
+            if (tid == 0) s_pick = max(max(s_i[0], s_i[1]), max(s_i[2], s_i[3]));
+            __syncthreads();
         }
-        if (pick < 0) {
-            // rounding pushed the target past the end: take the last admissible index
-            pick = last_pos;
-            for (int i = bins - 1; i >= 0; --i)
-                if (s_x[i] > -INFINITY) { pick = i; break; }
-        }
-        tokens[(int64_t)n * tok_stride + t] = pick;
     }
+    const int tok = s_pick;
+    if (tid == 0) tokens[(int64_t)n * tok_stride + t] = tok;
+    if (tail.x_next && t + 1 < tail.seq_len) {
+        const int W = tail.W;
+        const float* src = tail.x_emb + (int64_t)tok * W;
+        const float* pe = tail.pos_emb + (int64_t)(t + 1) * W;
+        const float* cd = tail.x_cond ? tail.x_cond + (int64_t)n * tail.xc_n + (int64_t)(t + 1) * tail.xc_t : nullptr;
+        for (int i = tid * 4; i < W; i += 256 * 4) {          // W % 4 == 0 is checked on the host
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + i) + *reinterpret_cast<const f32x4*>(pe + i);
+            if (cd) v += *reinterpret_cast<const f32x4*>(cd + i);
+            if (tail.x_dtype == JB_F16) {
+                const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *reinterpret_cast<f16x4*>((f16*)tail.x_next + (int64_t)n * W + i) = o;
+            } else {
+                *reinterpret_cast<f32x4*>((float*)tail.x_next + (int64_t)n * W + i) = v;
+            }
+        }
+    }
+    if (tail.ticket && tid == 0) {
+        const unsigned prev = atomicAdd(tail.ticket, 1u);
+        if (prev == gridDim.x - 1) {                           // last workgroup: everyone has read *t_dev
+            *tail.ticket = 0u;
+            *tail.t_dev_w = t + 1;
+        }
+    }
+}
+
+static int launch_sample(const float* logits, int n_batch, int bins, const jb_sample_params* params, int64_t* tokens,
+                         int64_t tok_stride, const int* t_dev, float* preds, int64_t preds_n_stride, const SampleTail& tail,
+                         hipStream_t stream) {
+    int n2 = 1;
+    while (n2 < bins) n2 <<= 1;
+    if (n2 > 4096) JB_UNSUPPORTED("vocabulary too large for the LDS sampler (bins <= 4096)");
+    const size_t lds = (size_t)2 * n2 * sizeof(float);
+    sample_kernel<<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds, preds_n_stride, tail);
+    JB_CHECK_LAUNCH();
+    return JB_OK;
 }
 
 extern "C" int jb_sample_logits(const float* logits, int n_batch, int bins, const jb_sample_params* params,
@@ -277,16 +410,22 @@ extern "C" int jb_sample_logits(const float* logits, int n_batch, int bins, cons
                                 int64_t preds_n_stride, void* stream) {
     JB_REQUIRE(logits && params && tokens && t_dev, "null pointer");
     JB_REQUIRE(n_batch > 0 && bins > 0, "bad dims");
-    int n2 = 1;
-    while (n2 < bins) n2 <<= 1;
-    size_t lds = (size_t)2 * n2 * sizeof(float);
-    if (lds > 128 * 1024) JB_UNSUPPORTED("vocabulary too large for the LDS sampler");
-    if (lds > 64 * 1024)
-        JB_HIP(hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    sample_kernel<<<n_batch, 256, lds, (hipStream_t)stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev,
-                                                              preds, preds_n_stride);
-    JB_CHECK_LAUNCH();
-    return JB_OK;
+    SampleTail tail = {};
+    return launch_sample(logits, n_batch, bins, params, tokens, tok_stride, t_dev, preds, preds_n_stride, tail, (hipStream_t)stream);
+}
+
+extern "C" int jb_sample_step(const float* logits, int n_batch, int bins, const jb_sample_params* params, int64_t* tokens,
+                              int64_t tok_stride, int* t_dev, float* preds, int64_t preds_n_stride, int x_dtype, void* x_next,
+                              const float* x_emb, const float* pos_emb, const float* x_cond, int64_t xc_n_stride,
+                              int64_t xc_t_stride, int width, int seq_len, unsigned* ticket, void* stream) {
+    JB_REQUIRE(logits && params && tokens && t_dev && x_next && x_emb && pos_emb && ticket, "null pointer");
+    JB_REQUIRE(n_batch > 0 && bins > 0 && width > 0 && width % 4 == 0 && seq_len > 0, "bad dims (width must be a multiple of 4)");
+    JB_REQUIRE(x_dtype == JB_F16 || x_dtype == JB_F32, "bad dtype");
+    SampleTail tail = {};
+    tail.x_next = x_next; tail.x_dtype = x_dtype; tail.x_emb = x_emb; tail.pos_emb = pos_emb; tail.x_cond = x_cond;
+    tail.xc_n = xc_n_stride; tail.xc_t = xc_t_stride; tail.W = width; tail.seq_len = seq_len;
+    tail.t_dev_w = t_dev; tail.ticket = ticket;
+    return launch_sample(logits, n_batch, bins, params, tokens, tok_stride, t_dev, preds, preds_n_stride, tail, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2,8 +2,9 @@
 //
 // Drives Transformer.forward(sample=True) (jukebox/transformer/transformer.py:169-192) and the token loops of
 // ConditionalAutoregressive2D.sample / primed_sample (jukebox/prior/autoregressive.py:222-236,289-347):
-//   decode step  = embed -> L x [LN0+c_attn(+k/v append) | attention | c_proj+res | LN1+c_fc+gelu | c_proj+res]
-//                  -> (+cond) -> logits -> sample -> t += 1          (5 L + 5 launches, one hipGraph)
+//   decode step  = L x [LN0+c_attn(+k/v append) | attention (key-split) | c_proj(+merge)+res | LN1+c_fc+gelu | c_proj+res]
+//                  -> logits -> sample + embed(t+1) + (t += 1)            (5 L + 2 launches, one hipGraph);
+//                  the last c_proj also writes `x.float() + cond` for the logits head, the sampler embeds the next position
 //   prefill      = the same per layer on a chunk of positions with the tiled GEMM and the MFMA attention.
 // The position t lives in device memory (*t_dev) so that the captured graph is replayable for every step.
 #include <vector>
@@ -20,7 +21,6 @@ struct JbEngine {
 
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 __global__ void inc_int_kernel(int* p) { *p += 1; }
-__global__ void inc_step_kernel(int* t, unsigned* epoch) { *t += 1; *epoch += 1; }
 
 extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers, void** handle) {
     JB_REQUIRE(cfg && layers && handle, "null pointer");
@@ -52,18 +52,9 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
                         jb_gemv_ln_fold_supported(cfg->dtype, cfg->width, cfg->n_mlp, cfg->n_batch)),
                    "folded LayerNorm image of mlp.c_fc is incomplete or unsupported for this shape");
     }
-    if (cfg->fused_pairs) {
-        JB_REQUIRE(cfg->dtype == JB_F16 && cfg->n_batch <= 16 && cfg->epoch_dev && cfg->pair_error,
-                   "fused_pairs needs an fp16 engine with n_batch <= 16, epoch_dev and pair_error");
-        JB_REQUIRE(cfg->width % 32 == 0 && cfg->n_state % 32 == 0 && cfg->n_mlp % 32 == 0 && cfg->width <= 2048 &&
-                       cfg->n_mlp <= 2048 && cfg->width + cfg->n_mlp <= 4096, "fused_pairs: unsupported dims");
-        for (int l = 0; l < cfg->n_layers; ++l) {
-            const jb_layer& L = layers[l];
-            JB_REQUIRE(L.attn_func != 6, "fused_pairs: cross-attention layers are not supported");
-            JB_REQUIRE(L.w_attn_f && L.w_fc_f && L.w_pf && L.k_f && L.stats_1 && L.stats_2 &&
-                           (l + 1 == cfg->n_layers || (L.w_2a && L.k_a)), "fused_pairs: incomplete layer images");
-        }
-    }
+    JB_REQUIRE((cfg->att_parts == nullptr) == (cfg->att_ml == nullptr), "att_parts and att_ml come together");
+    JB_REQUIRE(cfg->bins <= 0 || !cfg->x_out_packed || cfg->ticket, "ticket counter missing");
+    JB_REQUIRE(cfg->width % 4 == 0, "width must be a multiple of 4");
     JB_REQUIRE(!cfg->rec_out || (cfg->rec_layer >= 0 && cfg->rec_layer < cfg->n_layers && cfg->rec_keys > 0 &&
                                  cfg->rec_head >= 0 && cfg->rec_head < cfg->n_head), "bad attention recording request");
     JbEngine* e = new JbEngine();
@@ -86,7 +77,7 @@ extern "C" int jb_engine_destroy(void* handle) {
 extern "C" int jb_engine_launches_per_step(void* handle) {
     if (!handle) return 0;
     const jb_engine_cfg& c = ((JbEngine*)handle)->cfg;
-    return c.fused_pairs ? 3 * c.n_layers + 6 : 5 * c.n_layers + 5;
+    return 5 * c.n_layers + 2;
 }
 
 #define JB_TRY(call)                \
@@ -108,76 +99,35 @@ static void fill_ln_proj(jb_gemv_args& g, const jb_engine_cfg& c, const jb_layer
     }
 }
 
-// EXPERIMENTAL decode step with 3 launches per layer (cfg.fused_pairs; see jb_gemv_pair):
-//   embed | c_attn(0) | L x [attention | c_proj + c_fc | mlp.c_proj + c_attn(next)] | (+cond) | logits | sample | t, epoch += 1
-static int enqueue_step_pairs(JbEngine* e, hipStream_t s) {
-    const jb_engine_cfg& c = e->cfg;
-    const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
-    JB_TRY(jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
-                    c.xc_n_stride, c.xc_t_stride, N, W, 0, c.t_dev, 1, s));
-    {
-        const jb_layer& L = e->layers[0];
-        jb_gemv_args g = {};
-        fill_ln_proj(g, c, L, 0);
-        g.x = c.x_a; g.out = c.q; g.ldo = S; g.J = 3 * S;
-        g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
-        JB_TRY(jb_gemv(&g, s));
+// Largest key set a layer's query can see over the whole sequence (decides the key split of its decode attention).
+static int layer_max_keys(const jb_engine_cfg& c, const jb_layer& L) {
+    switch (L.attn_func) {
+        case JB_ATTN_BLOCK: case JB_ATTN_PREV_BLOCK: return c.block_ctx;
+        case JB_ATTN_TRANSPOSE_BLOCK: return (c.seq_len + c.block_ctx - 1) / c.block_ctx;
+        case JB_ATTN_PRIME: case JB_ATTN_CROSS: return L.cache_cap;
+        default: return c.seq_len;
     }
-    for (int l = 0; l < c.n_layers; ++l) {
-        const jb_layer& L = e->layers[l];
-        JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
-                              c.block_ctx, c.t_dev, c.seq_len, s));
-        jb_gemv_pair_args a = {};
-        a.n_rows = N; a.ln_eps = c.ln_eps; a.epoch_dev = c.epoch_dev; a.error_flag = c.pair_error; a.t_dev = c.t_dev;
-        // x_b = x_a + att.Wproj + b  |  mlp = gelu(LN1(x_b).Wfc + b) from (x_a, att)
-        a.in1 = c.att; a.ld1 = S; a.K1 = S;
-        a.Wa = L.w_proj; a.bias_a = L.b_proj; a.res = c.x_a; a.ldr = W; a.out_a = c.x_b; a.ldo_a = W; a.J_a = W;
-        a.in0 = c.x_a; a.ld0 = W; a.K0 = W;
-        a.Wb = L.w_pf; a.k_b = L.k_f; a.c1_b = L.c1_fc; a.bias_b = L.b_fc_f; a.J_b = M; a.act = JB_ACT_QUICK_GELU;
-        a.out_b = c.mlp; a.ldo_b = M; a.stats = L.stats_1;
-        JB_TRY(jb_gemv_pair(&a, s));
-        // x_a = x_b + mlp.Wproj2 + b  |  q, k, v of the next layer = LN0'(x_a).Wattn' + b from (x_b, mlp)
-        a = {};
-        a.n_rows = N; a.ln_eps = c.ln_eps; a.epoch_dev = c.epoch_dev; a.error_flag = c.pair_error; a.t_dev = c.t_dev;
-        a.in1 = c.mlp; a.ld1 = M; a.K1 = M;
-        a.Wa = L.w_proj2; a.bias_a = L.b_proj2; a.res = c.x_b; a.ldr = W; a.out_a = c.x_a; a.ldo_a = W; a.J_a = W;
-        a.stats = L.stats_2;
-        if (l + 1 < c.n_layers) {
-            const jb_layer& Ln = e->layers[l + 1];
-            a.in0 = c.x_b; a.ld0 = W; a.K0 = W;
-            a.Wb = L.w_2a; a.k_b = L.k_a; a.c1_b = Ln.c1_attn; a.bias_b = Ln.b_attn_f; a.J_b = 3 * S; a.act = JB_ACT_NONE;
-            a.out_b = c.q; a.ldo_b = S;
-            a.qkv_split = 1; a.S = S; a.kcache = Ln.kcache; a.vcache = Ln.vcache; a.cache_cap = Ln.cache_cap;
-        }
-        JB_TRY(jb_gemv_pair(&a, s));
-    }
-    JB_TRY(jb_final_add(c.dtype, c.x_a, c.xf, 0, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride, c.xc_t_stride, N, W,
-                        0, c.t_dev, 1, s));
-    jb_gemv_args g = {};
-    g.dtype = JB_F32; g.x = c.xf; g.ldx = W; g.n_rows = N; g.W = c.x_out_packed; g.K = W; g.J = c.bins;
-    g.out = c.logits; g.ldo = c.bins;
-    JB_TRY(jb_gemv(&g, s));
-    JB_TRY(jb_sample_logits(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds,
-                            c.preds_n_stride, s));
-    inc_step_kernel<<<1, 1, 0, s>>>(c.t_dev, c.epoch_dev);
-    JB_CHECK_LAUNCH();
-    return JB_OK;
+}
+// Splits per (sample, head) of a layer's decode attention; 0 = one workgroup per (sample, head) (jb_attn_decode).
+static int layer_split_parts(const jb_engine_cfg& c, const jb_layer& L) {
+    if (!c.att_parts || c.n_batch > 32) return 0;
+    return jb_attn_decode_split_parts(c.dtype, c.n_state / c.n_head, layer_max_keys(c, L));
 }
 
-// One decode step at position *t_dev; everything position-dependent is read on the device.
+static int enqueue_embed(JbEngine* e, int t0, hipStream_t s) {
+    const jb_engine_cfg& c = e->cfg;
+    return jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
+                    c.xc_n_stride, c.xc_t_stride, c.n_batch, c.width, t0, nullptr, 1, s);
+}
+
+// One decode step at position *t_dev (x_a already holds that position's embedding); everything position-dependent is
+// read on the device.  Leaves the next position's embedding in x_a and *t_dev advanced.
 static int enqueue_step(JbEngine* e, hipStream_t s) {
-    if (e->cfg.fused_pairs) return enqueue_step_pairs(e, s);
     const jb_engine_cfg& c = e->cfg;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
-    JB_TRY(jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
-                    c.xc_n_stride, c.xc_t_stride, N, W, 0, c.t_dev, 1, s));
-    const bool pf = c.prefetch_next_weights != 0;
-    const int64_t by_attn = jb_packed_weight_bytes(W, 3 * S, c.dtype), by_proj = jb_packed_weight_bytes(S, W, c.dtype);
-    const int64_t by_fc = jb_packed_weight_bytes(W, M, c.dtype), by_proj2 = jb_packed_weight_bytes(M, W, c.dtype);
     for (int l = 0; l < c.n_layers; ++l) {
         const jb_layer& L = e->layers[l];
         jb_gemv_args g = {};
-        if (pf) { g.prefetch = L.w_proj; g.prefetch_bytes = by_proj; }
         // a7/a8/a9: ln_0 + c_attn, k/v appended at *t_dev
         fill_ln_proj(g, c, L, 0);
         g.x = c.x_a; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
@@ -188,40 +138,43 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
             g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
         }
         JB_TRY(jb_gemv(&g, s));
-        JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
-                              c.block_ctx, c.t_dev, c.seq_len, s));
-        // attn.c_proj + residual: x_b = x_a + a
+        // attention, then attn.c_proj + residual: x_b = x_a + a
+        const int parts = layer_split_parts(c, L);
         g = {};
-        g.dtype = c.dtype; g.x = c.att; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
+        g.dtype = c.dtype; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
         g.out = c.x_b; g.ldo = W; g.res = c.x_a; g.ldr = W;
-        if (pf) { g.prefetch = L.w_fc; g.prefetch_bytes = by_fc; }
+        if (parts > 0) {
+            JB_TRY(jb_attn_decode_split(L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att_parts, c.att_ml, N, H, d,
+                                        c.block_ctx, c.t_dev, layer_max_keys(c, L), parts, s));
+            g.x_parts = c.att_parts; g.x_ml = c.att_ml; g.n_parts = parts; g.n_head = H; g.d_head = d;
+        } else {
+            JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
+                                  c.block_ctx, c.t_dev, c.seq_len, s));
+            g.x = c.att;
+        }
         JB_TRY(jb_gemv(&g, s));
         // ln_1 + mlp.c_fc + quick_gelu
         g = {};
         fill_ln_proj(g, c, L, 1);
         g.x = c.x_b; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
-        if (pf) { g.prefetch = L.w_proj2; g.prefetch_bytes = by_proj2; }
         JB_TRY(jb_gemv(&g, s));
-        // mlp.c_proj + residual: x_a = x_b + m   (h = x + a + m, transformer.py:82-83)
+        // mlp.c_proj + residual: x_a = x_b + m   (h = x + a + m, transformer.py:82-83); the last layer also hands the
+        // logits head xf = float(x_a) (+ cond[t], autoregressive.py:226-227)
         g = {};
         g.dtype = c.dtype; g.x = c.mlp; g.ldx = M; g.n_rows = N; g.W = L.w_proj2; g.bias = L.b_proj2; g.K = M; g.J = W;
         g.out = c.x_a; g.ldo = W; g.res = c.x_b; g.ldr = W;
-        if (pf) {
-            if (l + 1 < c.n_layers) { g.prefetch = e->layers[l + 1].w_attn; g.prefetch_bytes = by_attn; }
-            else { g.prefetch = c.x_out_packed; g.prefetch_bytes = jb_packed_weight_bytes(W, c.bins, JB_F32); }
+        if (l + 1 == c.n_layers) {
+            g.out2 = c.xf; g.ldo2 = W; g.t_dev = c.t_dev;
+            if (c.add_cond_after && c.x_cond) { g.add2 = c.x_cond; g.add2_n_stride = c.xc_n_stride; g.add2_t_stride = c.xc_t_stride; }
         }
         JB_TRY(jb_gemv(&g, s));
     }
-    JB_TRY(jb_final_add(c.dtype, c.x_a, c.xf, 0, c.add_cond_after ? c.x_cond : nullptr, c.xc_n_stride, c.xc_t_stride, N, W,
-                        0, c.t_dev, 1, s));
     jb_gemv_args g = {};
     g.dtype = JB_F32; g.x = c.xf; g.ldx = W; g.n_rows = N; g.W = c.x_out_packed; g.K = W; g.J = c.bins;
     g.out = c.logits; g.ldo = c.bins;
     JB_TRY(jb_gemv(&g, s));
-    JB_TRY(jb_sample_logits(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds,
-                            c.preds_n_stride, s));
-    inc_int_kernel<<<1, 1, 0, s>>>(c.t_dev);
-    JB_CHECK_LAUNCH();
+    JB_TRY(jb_sample_step(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds, c.preds_n_stride,
+                          c.dtype, c.x_a, c.x_emb, c.pos_emb, c.x_cond, c.xc_n_stride, c.xc_t_stride, W, c.seq_len, c.ticket, s));
     return JB_OK;
 }
 
@@ -234,6 +187,7 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
     set_int_kernel<<<1, 1, 0, s>>>(e->cfg.t_dev, t0);
     JB_CHECK_LAUNCH();
     if (n_steps == 0) return JB_OK;
+    JB_TRY(enqueue_embed(e, t0, s));         // later positions are embedded by the sampler of the step before
     if (!use_graph) {
         for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
         return JB_OK;
@@ -241,11 +195,12 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
     if (!e->graph_exec) {
         // One eager step first, so that every kernel's dynamic-LDS attribute is configured outside of capture;
         // it computes position t0, which the first replay recomputes identically (the sampler's random stream is
-        // keyed by position), so the counter is simply restored.  Then one step is recorded on a private stream
-        // -- recording executes nothing -- and replayed on the caller's stream.
+        // keyed by position), so the counter and the embedding of t0 are simply restored.  Then one step is recorded
+        // on a private stream -- recording executes nothing -- and replayed on the caller's stream.
         JB_TRY(enqueue_step(e, s));
         set_int_kernel<<<1, 1, 0, s>>>(e->cfg.t_dev, t0);
         JB_CHECK_LAUNCH();
+        JB_TRY(enqueue_embed(e, t0, s));
         if (!e->capture_stream) JB_HIP(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
         hipStream_t cs = e->capture_stream;
         JB_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
@@ -403,4 +358,34 @@ extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, voi
     out[1] = launches;
     out[2] = 0.5 * (b_attn + b_fc);
     return JB_OK;
+}
+
+// Algorithmic HBM bytes of one decode step at position t: every weight matrix once, the k/v rows
+// each layer's pattern reads plus the row it appends, the fp32 logits head, and the activation rows between kernels.
+extern "C" double jb_engine_step_bytes(void* handle, int t) {
+    if (!handle) return 0.0;
+    const JbEngine* e = (const JbEngine*)handle;
+    const jb_engine_cfg& c = e->cfg;
+    const double esz = c.dtype == JB_F16 ? 2.0 : 4.0;
+    const double N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp;
+    double bytes = 0.0;
+    for (int l = 0; l < c.n_layers; ++l) {
+        const jb_layer& L = e->layers[l];
+        const int bc = c.block_ctx;
+        double keys = 0;
+        switch (L.attn_func) {
+            case JB_ATTN_DENSE: keys = t + 1; break;
+            case JB_ATTN_BLOCK: keys = t % bc + 1; break;
+            case JB_ATTN_TRANSPOSE_BLOCK: keys = t / bc + 1; break;
+            case JB_ATTN_PREV_BLOCK: keys = t >= bc ? bc : 0; break;
+            case JB_ATTN_PRIME: keys = t + 1 < L.cache_cap ? t + 1 : L.cache_cap; break;
+            case JB_ATTN_CROSS: keys = L.cache_cap; break;
+        }
+        const double w_attn = L.attn_func == JB_ATTN_CROSS ? W * S : 3.0 * W * S;
+        bytes += (w_attn + S * W + W * M + M * W) * esz;                 // weights, once per step
+        bytes += keys * S * 2.0 * esz * N;                               // k/v rows read
+        if (L.attn_func != JB_ATTN_CROSS) bytes += S * 2.0 * esz * N;    // k/v row appended
+    }
+    bytes += (double)c.bins * W * 4.0;                                   // logits head (fp32)
+    return bytes;
 }

@@ -68,6 +68,10 @@ struct EpiParams {
     int qkv_split, S;
     void* kcache; void* vcache; int cache_cap;
     int vec_out;        // 4 consecutive columns may be stored as one vector
+    // decode step, last layer: a second fp32 copy out2[row][j] = value + add2[row*add2_n + t*add2_t + j] (t = *t_dev) --
+    // `x.float() + cond` before the logits head (autoregressive.py:226-227), fused into mlp.c_proj's epilogue
+    float* out2; int64_t ldo2;
+    const float* add2; int64_t add2_n, add2_t;
 };
 
 // vals[r] is the accumulator of column jb + r of output row `orow`; cache_row < 0 disables the k/v write.
@@ -127,11 +131,12 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& p, f32x4 acc, in
 // One output element (decode GEMV epilogue, spread over all threads of the workgroup).
 template <typename T>
 __device__ __forceinline__ void epilogue_store1(const EpiParams& p, float x, int64_t orow, int j, int64_t cache_row,
-                                                float bias_v, float res_v) {
+                                                float bias_v, float res_v, float add2_v = 0.f) {
     if (p.bias) x += jb_round<T>(bias_v);
     x = jb_round<T>(x);
     x = jb_apply_act<T>(x, p.act);
     if (p.res) x = (p.res_scale == 1.0f) ? jb_round<T>(res_v + x) : jb_round<T>(res_v + jb_round<T>(p.res_scale * x));
+    if (p.out2) p.out2[orow * p.ldo2 + j] = x + add2_v;
     if (!p.qkv_split) {
         ((T*)p.out)[orow * p.ldo + j] = (T)x;
     } else {
@@ -375,6 +380,7 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
     p.epi.cache_cap = a->cache_cap;
     p.epi.vec_out = !a->qkv_split && (a->ldo % 4 == 0) && aligned_to(a->out, 4 * esz);
+    p.epi.out2 = nullptr; p.epi.ldo2 = 0; p.epi.add2 = nullptr; p.epi.add2_n = p.epi.add2_t = 0;
     dim3 grid((unsigned)((p.m_total + 255) / 256), (unsigned)((p.njt + 3) / 4));
     const int KT = a->dtype == JB_F16 ? 32 : 16;
     const bool fast = p.vec_a && (a->K % KT == 0);
@@ -405,9 +411,10 @@ struct GemvParams {
     const float* ln_c1;                         // folded LayerNorm: column sums of the stored (gamma-scaled) weights
     const void* W; int K, nkt;
     int vec_x, lds_pitch, fast;
-    const void* pf_ptr; long long pf_bytes;     // next kernel's weights: touched early so they are in the memory-side cache
     long long* dbg;
     const int* t_dev;
+    // key-split attention output as the operand (gemv_merge_kernel): x[n][k] = sum_s w_s(n, head(k)) * parts[n][s][k]
+    const void* x_parts; const float* x_ml; int n_parts, n_head, d_head;
     EpiParams epi;
 };
 
@@ -469,8 +476,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     // are ready.
     constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);      // elements per thread
     int t = 0;
-    if (p.epi.qkv_split) t = *p.t_dev;
-    float e_bias[EPT], e_res[EPT];
+    if (p.epi.qkv_split || p.epi.add2) t = *p.t_dev;
+    float e_bias[EPT], e_res[EPT], e_add2[EPT];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
         const int i = threadIdx.x + u * NW * 64;
@@ -478,17 +485,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
         const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
         e_bias[u] = p.epi.bias ? p.epi.bias[jc] : 0.f;
         e_res[u] = p.epi.res ? (float)((const T*)p.epi.res)[(int64_t)rc * p.epi.ldr + jc] : 0.f;
-    }
-
-    // Cross-kernel prefetch: one dword per 128-byte line of the NEXT projection's weight image.  HBM is ~7 % busy in
-    // this latency-bound chain, so pulling the next kernel's weights into the Infinity Cache while this kernel runs
-    // costs nothing and turns the next kernel's cold HBM stream into cache hits.  The values are summed and consumed
-    // by an empty asm at the end, so the compiler tracks (and never reuses) their registers.
-    int pf_sum = 0;
-    if (p.pf_ptr) {
-        const long long stride = (long long)gridDim.x * (NW * 64) * 128;
-        for (long long off = ((long long)blockIdx.x * (NW * 64) + threadIdx.x) * 128; off < p.pf_bytes; off += stride)
-            pf_sum += *reinterpret_cast<const int*>(reinterpret_cast<const char*>(p.pf_ptr) + off);
+        e_add2[u] = p.epi.add2 ? p.epi.add2[(int64_t)rc * p.epi.add2_n + (int64_t)t * p.epi.add2_t + jc] : 0.f;
     }
 
     if constexpr (LNS && FAST && NV > 0) {
@@ -696,7 +693,6 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     for (int mt = 0; mt < MT; ++mt) s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
     __syncthreads();
     JB_STAMP(6);
-    asm volatile("" ::"v"(pf_sum));
     {
         const float* sa = reinterpret_cast<const float*>(s_acc);
 #pragma unroll
@@ -709,7 +705,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += sa[((w * MT + mt) * 64 + l) * 4 + r];
             const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
-            epilogue_store1<T>(p.epi, v, row, j, cache_row, e_bias[u], e_res[u]);
+            epilogue_store1<T>(p.epi, v, row, j, cache_row, e_bias[u], e_res[u], e_add2[u]);
         }
     }
     JB_STAMP(7);
@@ -814,6 +810,121 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     }
 }
 
+// attn.c_proj of the decode step fed by the KEY-SPLIT decode attention (jb_attn_decode_split): the B operand rows are
+// formed on the fly from the n_parts (<= 4) partial softmax states of each (sample, head) --
+//     x[n][k] = sum_s w_s * parts[n][s][k],   w_s = l_s * exp(m_s - m) / sum_s' l_s' * exp(m_s' - m),  m = max_s m_s
+// (parts are normalised by their own sum l_s, f16; (m_s, l_s) fp32 in x_ml[n][head][s]) -- and rounded to half once, the
+// point where the reference materialises the attention output (factored_attention.py:107-108).  A head owns whole
+// k-tiles (d_head % 32 == 0), so a lane's weights depend on (row, k-tile) only.  Everything is requested up front;
+// the log-sum-exp merge costs n_parts fused multiply-adds per operand element while the weight stream is in flight.
+// This removes the merge from the attention kernel, which can then spread one (sample, head) over several CUs.
+template <int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_merge_kernel(GemvParams p) {
+    using V = f16x8;
+    constexpr int E = 8, KT = 32, WB = 4, PMAX = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    f32x4* s_acc = reinterpret_cast<f32x4*>(s_dyn);                 // [NW][MT][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int jt = blockIdx.x;
+    const f16* parts = (const f16*)p.x_parts;
+    const int P = p.n_parts, H = p.n_head;
+    const int kt0 = (wave * p.nkt) / NW, kt1 = ((wave + 1) * p.nkt) / NW;
+    const f16* wbase = (const f16*)p.W + ((int64_t)jt * p.nkt) * (64 * E) + (int64_t)lane * E;
+
+    constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);
+    float e_bias[EPT], e_res[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = threadIdx.x + u * NW * 64;
+        const int row = (i >> 8) * 16 + (i & 15), j = jt * 16 + ((i & 63) >> 4) * 4 + ((i >> 6) & 3);
+        const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
+        e_bias[u] = p.epi.bias ? p.epi.bias[jc] : 0.f;
+        e_res[u] = p.epi.res ? (float)((const f16*)p.epi.res)[(int64_t)rc * p.epi.ldr + jc] : 0.f;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = kt0; kb < kt1; kb += WB) {
+        V wf[WB], ph[WB][MT][PMAX];
+        float mm[WB][MT][PMAX], ll[WB][MT][PMAX];
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+            const int kt = min(kb + i, p.nkt - 1);
+            wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)kt * (64 * E)));
+            const int k0 = kt * KT + g * E;
+            const int h = (kt * KT) / p.d_head;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = min(mt * 16 + c, p.n_rows - 1);
+#pragma unroll
+                for (int s = 0; s < PMAX; ++s) {
+                    const int sc = min(s, P - 1);                       // clamped: parts past P are loaded again, weight 0
+                    ph[i][mt][s] = ld_frag<f16>(parts + ((int64_t)row * P + sc) * p.K + k0);
+                    const float2 v = *reinterpret_cast<const float2*>(p.x_ml + (((int64_t)row * H + h) * P + sc) * 2);
+                    mm[i][mt][s] = v.x;
+                    ll[i][mt][s] = s < P ? v.y : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+            const V w = keep_frag<f16>(kb + i < kt1, wf[i]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float m = mm[i][mt][0];
+#pragma unroll
+                for (int s = 1; s < PMAX; ++s) m = fmaxf(m, mm[i][mt][s]);
+                float ws[PMAX], tot = 0.f;
+#pragma unroll
+                for (int s = 0; s < PMAX; ++s) {
+                    ws[s] = ll[i][mt][s] > 0.f ? ll[i][mt][s] * expf(mm[i][mt][s] - m) : 0.f;
+                    tot += ws[s];
+                }
+                const float inv = tot > 0.f ? 1.0f / tot : 0.f;        // no key at all (prev_block in block 0): a = 0
+                V xv;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int s = 0; s < PMAX; ++s) a += ws[s] > 0.f ? ws[s] * (float)ph[i][mt][s][e] : 0.f;
+                    xv[e] = (f16)(a * inv);
+                }
+                acc[mt] = jb_mfma(w, xv, acc[mt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    const float* sa = reinterpret_cast<const float*>(s_acc);
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int i = threadIdx.x + u * NW * 64;
+        const int mt = i >> 8, r = (i >> 6) & 3, l = i & 63;
+        const int row = mt * 16 + (l & 15), j = jt * 16 + (l >> 4) * 4 + r;
+        if (i >= MT * 256 || row >= p.n_rows || j >= p.epi.J) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += sa[((w * MT + mt) * 64 + l) * 4 + r];
+        epilogue_store1<f16>(p.epi, v, row, j, -1, e_bias[u], e_res[u]);
+    }
+}
+
+template <int NW>
+static int launch_gemv_merge(const GemvParams& p, int njt, hipStream_t s) {
+    const int mt = (p.n_rows + 15) / 16;
+    const size_t lds = (size_t)NW * mt * 64 * sizeof(f32x4);
+    switch (mt) {
+        case 1: gemv_merge_kernel<1, NW><<<njt, NW * 64, lds, s>>>(p); break;
+        case 2: gemv_merge_kernel<2, NW><<<njt, NW * 64, lds, s>>>(p); break;
+        default: jb_set_error("jb_gemv: the split-attention operand supports n_rows <= 32"); return JB_ERR_UNSUPPORTED;
+    }
+    return JB_OK;
+}
+
 // k-tiles a wave must hold for the folded-LayerNorm kernel, or 0 when the problem is outside its envelope.
 static int lnf_shape(int dtype, int K, int J, int n_rows, int* nw_out) {
     const int KT = dtype == JB_F16 ? 32 : 16, E = dtype == JB_F16 ? 8 : 4;
@@ -907,208 +1018,26 @@ static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
     return nw == 8 ? launch_gemv_nw<T, 8, false>(p, njt, lds, s) : launch_gemv_nw<T, 4, false>(p, njt, lds, s);
 }
 
-// ------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (off by default, jb_engine_cfg.fused_pairs): two dependent projections of the decode step in ONE launch.
-//
-// With LayerNorm folded, the projection after a residual add can be formed from the operands of the add:
-//     x_b = x + a.Wp + bp            (part A: residual-row tiles)
-//     LN(x_b).Wf + bf = rstd * (x.W' + a.(Wp.W') + bp.W' - mean * c1) + b'      (part B: projection tiles)
-// Part B needs x_b only through its row statistics.  Workgroups [0, nA) each produce one 16-column tile of the residual
-// row and publish the tile's per-row (sum, sum of squares) as two self-tagged 64-bit words (value | step tag, written
-// with agent-scope sc1 stores: visible across the 8 XCD L2s, verified by tools/grid_sync_probe.hip).  Workgroups
-// [nA, nA+nB) stream their larger weight slice -- [W' ; Wp.W'] packed as one K0+K1 matrix -- over the concatenated
-// input [x | a] meanwhile, then collect the nA partials (an optimistic fetch is issued with the first loads and
-// re-polled only where the tag is stale), normalise in the epilogue and apply bias / quick_gelu / the q-k-v split.
-// Workgroups are dispatched in block order, so a resident part-B workgroup never waits for a part-A workgroup that
-// cannot be scheduled; the poll is bounded and reports through *error_flag instead of hanging.
-struct PairParams {
-    int n_rows, nA, nB;
-    const f16* in1; int64_t ld1; int nkt1;
-    const f16* Wa; const float* bias_a; const f16* res; int64_t ldr; f16* out_a; int64_t ldo_a; int J_a;
-    const f16* in0; int64_t ld0; int nkt0;
-    const f16* Wb; const float* k_b; const float* c1_b;
-    float ln_eps;
-    unsigned long long* stats; const unsigned* epoch_dev; int* error_flag;
-    const int* t_dev;
-    EpiParams epi;       // part B output
-};
-
-__device__ __forceinline__ unsigned long long jb_tagged(float v, unsigned tag) {
-    return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
-}
-
-__global__ __launch_bounds__(512) void gemv_pair_kernel(PairParams p) {
-    using V = f16x8;
-    constexpr int E = 8, KT = 32, NW = 8;
-    __shared__ __attribute__((aligned(16))) f32x4 s_acc[NW * 64];
-    __shared__ float s_red[16 * 32];
-    __shared__ float s_tot[32];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, c = lane & 15;
-    const int rowc = min(c, p.n_rows - 1);
-    const unsigned epoch = *p.epoch_dev;
-    // this thread's output element (threads < 256): row = lane & 15, column = tile*16 + (lane >> 4)*4 + wave
-    const int erow = c, ecol = g * 4 + (wave & 3);
-
-    if (blockIdx.x < p.nA) {
-        // ---------------- part A: out_a tile = res + in1 . Wa + bias_a, statistics of the stored tile ----------------
-        const int jt = blockIdx.x;
-        const int kt0 = (wave * p.nkt1) / NW, kt1 = ((wave + 1) * p.nkt1) / NW;
-        V xf[8], wf[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int kt = min(kt0 + i, p.nkt1 - 1);
-            xf[i] = ld_frag<f16>(p.in1 + (int64_t)rowc * p.ld1 + kt * KT + g * E);
-            wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(p.Wa + (((int64_t)jt * p.nkt1 + kt) * 64 + lane) * E));
-        }
-        const int j = jt * 16 + ecol;
-        const float e_bias = p.bias_a ? p.bias_a[j] : 0.f;
-        const float e_res = (float)p.res[(int64_t)rowc * p.ldr + j];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc = jb_mfma(wf[i], keep_frag<f16>(kt0 + i < kt1, xf[i]), acc);
-        s_acc[wave * 64 + lane] = acc;
-        __syncthreads();
-        float s1 = 0.f, s2 = 0.f;
-        if (tid < 256) {
-            const float* sa = reinterpret_cast<const float*>(s_acc);
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) v += sa[(w * 64 + lane) * 4 + (wave & 3)];
-            if (p.bias_a) v += jb_round<f16>(e_bias);
-            v = jb_round<f16>(v);
-            v = jb_round<f16>(e_res + v);
-            if (erow < p.n_rows) {
-                p.out_a[(int64_t)erow * p.ldo_a + j] = (f16)v;
-                s1 = v; s2 = v * v;
-            }
-            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (g == 0) { s_red[(wave * 16 + c) * 2] = s1; s_red[(wave * 16 + c) * 2 + 1] = s2; }
-        }
-        __syncthreads();
-        if (tid < 32) {                      // tid = row*2 + which
-            const int row = tid >> 1, which = tid & 1;
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) tot += s_red[(w * 16 + row) * 2 + which];
-            __hip_atomic_store(p.stats + ((int64_t)jt * 16 + row) * 2 + which, jb_tagged(tot, epoch), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
-
-    // ---------------- part B: out_b tile = act(rstd * (in0.Wb[:K0] + in1.Wb[K0:] + k - mean*c1) + bias) ----------------
-    const int jt = blockIdx.x - p.nA;
-    const int nkt = p.nkt0 + p.nkt1;
-    const int kt0 = (wave * nkt) / NW, kt1 = ((wave + 1) * nkt) / NW;
-    V xf[16], wf[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int kt = min(kt0 + i, nkt - 1);
-        const f16* src = kt < p.nkt0 ? p.in0 + (int64_t)rowc * p.ld0 + kt * KT : p.in1 + (int64_t)rowc * p.ld1 + (kt - p.nkt0) * KT;
-        xf[i] = ld_frag<f16>(src + g * E);
-        wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(p.Wb + (((int64_t)jt * nkt + kt) * 64 + lane) * E));
-    }
-    const int j = jt * 16 + ecol, jc = min(j, p.epi.J - 1);
-    const float e_bias = p.epi.bias ? p.epi.bias[jc] : 0.f;
-    const float e_c1 = p.c1_b[jc];
-    const float e_k = p.k_b ? p.k_b[jc] : 0.f;
-    int t = 0;
-    if (p.epi.qkv_split) t = *p.t_dev;
-    // optimistic fetch of the statistics slots this thread sums: (row, which) = tid & 31, tiles (tid >> 5) + 16 u
-    const int rw = tid & 31, tile0 = tid >> 5;
-    unsigned long long sv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int tile = min(tile0 + 16 * u, p.nA - 1);
-        sv[u] = __hip_atomic_load(p.stats + (int64_t)tile * 32 + rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc = jb_mfma(wf[i], keep_frag<f16>(kt0 + i < kt1, xf[i]), acc);
-    s_acc[wave * 64 + lane] = acc;
-    float part = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int tile = tile0 + 16 * u;
-        if (tile < p.nA) {
-            unsigned spins = 0;
-            while ((unsigned)(sv[u] >> 32) != epoch) {
-                if (++spins > (1u << 20)) { *p.error_flag = 1; break; }
-                __builtin_amdgcn_s_sleep(2);
-                sv[u] = __hip_atomic_load(p.stats + (int64_t)tile * 32 + rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            part += __uint_as_float((unsigned)sv[u]);
-        }
-    }
-    s_red[tile0 * 32 + rw] = part;
-    __syncthreads();
-    if (tid < 32) {
-        float tot = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tot += s_red[k * 32 + tid];
-        s_tot[tid] = tot;
-    }
-    __syncthreads();
-    if (tid < 256 && erow < p.n_rows && j < p.epi.J) {
-        const float* sa = reinterpret_cast<const float*>(s_acc);
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) v += sa[(w * 64 + lane) * 4 + (wave & 3)];
-        const float inv_k = 1.0f / (float)p.J_a;
-        const float mean = s_tot[erow * 2] * inv_k;
-        const float var = fmaxf(s_tot[erow * 2 + 1] * inv_k - mean * mean, 0.f);
-        v = (v + e_k - mean * e_c1) / sqrtf(var + p.ln_eps);
-        const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)erow * p.epi.cache_cap + t : -1;
-        epilogue_store1<f16>(p.epi, v, erow, j, cache_row, e_bias, 0.f);
-    }
-}
-
-extern "C" int jb_gemv_pair(const jb_gemv_pair_args* a, void* stream) {
-    JB_REQUIRE(a && a->in1 && a->Wa && a->res && a->out_a && a->stats && a->epoch_dev && a->error_flag, "null pointer");
-    JB_REQUIRE(a->n_rows >= 1 && a->n_rows <= 16, "n_rows must be 1..16");
-    JB_REQUIRE(a->K1 > 0 && a->K1 % 32 == 0 && a->K1 <= 2048, "K1 must be a multiple of 32, <= 2048");
-    JB_REQUIRE(a->J_a > 0 && a->J_a % 16 == 0 && a->J_a / 16 <= 128, "J_a must be a multiple of 16, <= 2048");
-    JB_REQUIRE(a->ld1 % 8 == 0 && a->ldr % 1 == 0 && aligned_to(a->in1, 16), "in1 rows must be 16-byte aligned");
-    PairParams p = {};
-    p.n_rows = a->n_rows; p.nA = a->J_a / 16;
-    p.in1 = (const f16*)a->in1; p.ld1 = a->ld1; p.nkt1 = a->K1 / 32;
-    p.Wa = (const f16*)a->Wa; p.bias_a = a->bias_a; p.res = (const f16*)a->res; p.ldr = a->ldr;
-    p.out_a = (f16*)a->out_a; p.ldo_a = a->ldo_a; p.J_a = a->J_a;
-    p.stats = (unsigned long long*)a->stats; p.epoch_dev = a->epoch_dev; p.error_flag = a->error_flag;
-    p.ln_eps = a->ln_eps; p.t_dev = a->t_dev;
-    p.nB = 0;
-    if (a->J_b > 0) {
-        JB_REQUIRE(a->in0 && a->Wb && a->c1_b && a->out_b, "null pointer (part B)");
-        JB_REQUIRE(a->K0 > 0 && a->K0 % 32 == 0 && a->K0 + a->K1 <= 4096, "K0 must be a multiple of 32, K0 + K1 <= 4096");
-        JB_REQUIRE(a->ld0 % 8 == 0 && aligned_to(a->in0, 16), "in0 rows must be 16-byte aligned");
-        JB_REQUIRE(!a->qkv_split || (a->S > 0 && a->J_b == 3 * a->S && a->kcache && a->vcache && a->t_dev), "bad qkv split");
-        p.nB = (a->J_b + 15) / 16;
-        p.in0 = (const f16*)a->in0; p.ld0 = a->ld0; p.nkt0 = a->K0 / 32;
-        p.Wb = (const f16*)a->Wb; p.k_b = a->k_b; p.c1_b = a->c1_b;
-        p.epi.bias = a->bias_b; p.epi.out = a->out_b; p.epi.ldo = a->ldo_b; p.epi.res = nullptr; p.epi.ldr = 0;
-        p.epi.J = a->J_b; p.epi.act = a->act; p.epi.res_scale = 1.0f;
-        p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
-        p.epi.cache_cap = a->cache_cap; p.epi.vec_out = 0;
-    }
-    gemv_pair_kernel<<<p.nA + p.nB, 512, 0, (hipStream_t)stream>>>(p);
-    JB_CHECK_LAUNCH();
-    return JB_OK;
-}
-
 #ifdef JB_TIMING
 long long* jb_dbg_ptr = nullptr;
 extern "C" void jb_set_dbg(long long* p) { jb_dbg_ptr = p; }
 #endif
 
 extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
-    JB_REQUIRE(a && a->x && a->W && a->out, "null pointer");
+    JB_REQUIRE(a && (a->x || a->x_parts) && a->W && a->out, "null pointer");
     JB_REQUIRE(a->dtype == JB_F32 || a->dtype == JB_F16, "bad dtype");
     JB_REQUIRE(a->n_rows >= 1 && a->n_rows <= 64, "n_rows must be 1..64");
     JB_REQUIRE(a->K > 0 && a->J > 0, "empty problem");
     JB_REQUIRE(!a->qkv_split || (a->S > 0 && a->J == 3 * a->S && a->kcache && a->vcache && a->t_dev), "bad qkv split");
+    JB_REQUIRE(!a->out2 || (a->ldo2 >= a->J && (!a->add2 || a->t_dev)), "bad second output (out2 / add2 need ldo2 >= J and t_dev)");
+    JB_REQUIRE(!a->out2 || (!a->ln_gamma && !a->ln_fold_c1 && !a->x_parts), "out2 is available on the plain projection only");
+    if (a->x_parts) {
+        JB_REQUIRE(!a->x && a->x_ml && a->dtype == JB_F16 && !a->ln_gamma && !a->ln_fold_c1 && !a->qkv_split,
+                   "split-attention operand: fp16, no LayerNorm, no q/k/v split, x must be NULL");
+        JB_REQUIRE(a->n_parts >= 1 && a->n_parts <= 4 && a->n_head >= 1 && a->d_head > 0 && a->d_head % 32 == 0 &&
+                       a->n_head * a->d_head == a->K && a->n_rows <= 32 && aligned_to(a->x_parts, 16),
+                   "split-attention operand: 1..4 parts, d_head a multiple of 32, K = n_head * d_head, n_rows <= 32");
+    }
     const int esz = a->dtype == JB_F16 ? 2 : 4;
     const int E = a->dtype == JB_F16 ? 8 : 4;
     GemvParams p;
@@ -1117,9 +1046,9 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     p.x = a->x; p.ldx = a->ldx; p.n_rows = a->n_rows;
     p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_c1 = a->ln_fold_c1;
     p.W = a->W; p.K = a->K;
-    p.vec_x = (a->ldx % E == 0) && aligned_to(a->x, 16);
+    p.vec_x = a->x && (a->ldx % E == 0) && aligned_to(a->x, 16);
     p.t_dev = a->t_dev;
-    p.pf_ptr = a->prefetch; p.pf_bytes = a->prefetch_bytes;
+    p.x_parts = a->x_parts; p.x_ml = a->x_ml; p.n_parts = a->n_parts; p.n_head = a->n_head; p.d_head = a->d_head;
     p.dbg = nullptr;
 #ifdef JB_TIMING
     p.dbg = jb_dbg_ptr;
@@ -1137,8 +1066,12 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
     p.epi.cache_cap = a->cache_cap;
     p.epi.vec_out = !a->qkv_split && (a->ldo % 4 == 0) && aligned_to(a->out, 4 * esz);
+    p.epi.out2 = a->out2; p.epi.ldo2 = a->ldo2; p.epi.add2 = a->out2 ? a->add2 : nullptr;
+    p.epi.add2_n = a->add2_n_stride; p.epi.add2_t = a->add2_t_stride;
     int rc;
-    if (a->ln_fold_c1) {
+    if (a->x_parts) {
+        rc = p.nkt >= 32 ? launch_gemv_merge<8>(p, njt, (hipStream_t)stream) : launch_gemv_merge<4>(p, njt, (hipStream_t)stream);
+    } else if (a->ln_fold_c1) {
         JB_REQUIRE(!a->ln_gamma && !a->ln_beta, "ln_fold_c1 excludes ln_gamma / ln_beta (gamma and beta are folded into W and bias)");
         int nw = 0;
         const int nf = lnf_shape(a->dtype, a->K, a->J, a->n_rows, &nw);

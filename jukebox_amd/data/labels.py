@@ -80,16 +80,25 @@ class TextProcessor:
 
 
 class ArtistGenreProcessor:
-    """data/artist_genre_processor.py: name -> id tables read from the reference's ids/*.txt."""
+    """data/artist_genre_processor.py:27-100: name -> id tables read from the reference's `ids/v{2,3}_{artist,genre}_ids.txt`
+    (data files of the released checkpoints, not redistributed here): `ids_dir`, else $JUKEBOX_IDS_DIR, else an `ids/`
+    directory next to this file.  Looking a NAME up without tables raises -- the reference cannot run without them
+    either, and silently conditioning every sample on id 0 would be wrong audio without a warning.  With tables, an unknown
+    name maps to id 0 with the reference's message (artist_genre_processor.py:45-47,57-60).  Ids can always be given
+    directly (Labeller.get_batch_labels_from_ids)."""
 
     def __init__(self, v3=False, ids_dir=None):
         self.v3 = v3
-        ids_dir = ids_dir or os.environ.get("JUKEBOX_IDS_DIR")
+        here_ids = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ids")
+        ids_dir = ids_dir or os.environ.get("JUKEBOX_IDS_DIR") or (here_ids if os.path.isdir(here_ids) else None)
+        self.ids_dir = ids_dir
         self.artist_ids, self.genre_ids = {}, {}
+        ver = "v3" if v3 else "v2"
+        self.artist_id_file = os.path.join(ids_dir or "<ids dir>", f"{ver}_artist_ids.txt")
+        self.genre_id_file = os.path.join(ids_dir or "<ids dir>", f"{ver}_genre_ids.txt")
         if ids_dir:
-            ver = "v3" if v3 else "v2"
-            for attr, fn in (("artist_ids", f"{ver}_artist_ids.txt"), ("genre_ids", f"{ver}_genre_ids.txt")):
-                with open(os.path.join(ids_dir, fn), encoding="utf-8") as f:
+            for attr, fn in (("artist_ids", self.artist_id_file), ("genre_ids", self.genre_id_file)):
+                with open(fn, encoding="utf-8") as f:
                     for line in f:
                         name, idx = line.strip().split(";")
                         getattr(self, attr)[name.lower()] = int(idx)
@@ -99,11 +108,27 @@ class ArtistGenreProcessor:
         s = "".join(c if c.isascii() and c.isalnum() else "_" for c in s.lower())
         return re.sub(r"_+", "_", s).strip("_")
 
+    def _require_tables(self, what):
+        if not self.ids_dir:
+            raise RuntimeError(f"cannot map {what} to an id: the artist / genre id tables are not loaded.  Point "
+                               "JUKEBOX_IDS_DIR (or ArtistGenreProcessor(ids_dir=...)) at the reference's jukebox/data/ids "
+                               "directory, or label the batch with ids (Labeller.get_batch_labels_from_ids)")
+
     def get_artist_id(self, artist):
-        return self.artist_ids.get(artist.lower() if self.v3 else self._norm(artist), 0)
+        self._require_tables(f"artist {artist!r}")
+        key = artist.lower() if self.v3 else self._norm(artist)
+        if key not in self.artist_ids:
+            print(f"Input artist {artist} maps to {key}, which is not present in {self.artist_id_file}. "
+                  f"Defaulting to (artist_id, artist) = (0, unknown), if that seems wrong please format artist correctly")
+        return self.artist_ids.get(key, 0)
 
     def get_genre_ids(self, genre):
+        self._require_tables(f"genre {genre!r}")
         genres = [genre.lower()] if self.v3 else self._norm(genre).split("_")
+        for word in genres:
+            if word not in self.genre_ids:
+                print(f"Input genre {genre} maps to the list {genres}. {word} is not present in {self.genre_id_file}. "
+                      f"Defaulting to (word_id, word) = (0, unknown), if that seems wrong please format genre correctly")
         return [self.genre_ids.get(w, 0) for w in genres]
 
 

@@ -31,160 +31,192 @@ def attn_funcs(attn_order, depth):
     return [_ORDERS[attn_order](d) for d in range(depth)]
 
 
-class PriorEngine:
-    """One ConditionalAutoregressive2D bound to device buffers for a fixed batch size.
+class PackedPrior:
+    """The weights of one ConditionalAutoregressive2D, re-laid once for the MFMA kernels (jb_pack_weight) in one engine
+    dtype: per layer the four projections in fragment order, biases / LayerNorm parameters in fp32, the folded-LayerNorm
+    images of c_attn / c_fc (hip_ops.FoldedLN) where the decode kernels can use them, the c_enc_kv halves of
+    cross-attention layers, plus the embedding tables and the fp32 logits head.  Shared by every PriorEngine of the same
+    prior (different batch sizes, with / without logits recording), so a new batch size costs caches and work buffers
+    only -- not another pass over 1-10 GB of weights.
 
     sd: mapping reference-name -> GPU tensor for the keys under `prefix`
-        (x_emb.weight, pos_emb.pos_emb, [start_token], transformer._attn_mods.*, x_out.weight).
-    """
+        (x_emb.weight, pos_emb.pos_emb, [start_token], transformer._attn_mods.*, x_out.weight)."""
 
-    def __init__(self, sd, prefix, *, n_batch, seq_len, bins, width, depth, heads, attn_order, blocks=None,
-                 m_attn=0.25, m_mlp=1.0, prime_len=None, y_cond=False, add_cond_after=True, fp16=True,
-                 chunk_cap=256, want_preds=False, record=None, encoder_dims=0, only_encode=False, fold_ln=None,
-                 fused_pairs=None, device="cuda"):
+    def __init__(self, sd, prefix, *, seq_len, bins, width, depth, heads, attn_order, blocks=None, m_attn=0.25, m_mlp=1.0,
+                 prime_len=None, y_cond=False, add_cond_after=True, fp16=True, encoder_dims=0, only_encode=False,
+                 fold_ln=None, device="cuda"):
         L.lib()
         self.device = torch.device(device)
-        self.N, self.T, self.bins, self.W = n_batch, seq_len, bins, width
+        self.T, self.bins, self.W = seq_len, bins, width
         self.S, self.M, self.H, self.depth = int(m_attn * width), int(m_mlp * width), heads, depth
+        self.fp16 = bool(fp16)
         self.dtype = torch.float16 if fp16 else torch.float32
         self.code = L.F16 if fp16 else L.F32
         self.block_ctx = seq_len // blocks if blocks else 0
         self.prime_cap = (prime_len // blocks + 1) * blocks if prime_len else 0
         self.funcs = attn_funcs(attn_order, depth)
-        self.y_cond, self.add_cond_after = y_cond, add_cond_after
-        self.chunk_cap = min(chunk_cap, seq_len)
+        self.y_cond, self.add_cond_after, self.only_encode = y_cond, add_cond_after, only_encode
+        self.enc_len = int(encoder_dims or 0)
         # Decode step: LayerNorm folded into c_attn / c_fc (hip_ops.FoldedLN).  Default: on for fp16 engines; the fp32
         # engine (the parity mode) normalises rows explicitly, operation for operation as the reference.  JB_FOLD_LN=0/1
         # overrides both.
         if fold_ln is None:
             fold_ln = bool(int(os.environ["JB_FOLD_LN"])) if "JB_FOLD_LN" in os.environ else fp16
         self.fold_ln = bool(fold_ln) and not only_encode
-        # EXPERIMENTAL (JB_FUSED_PAIRS=1): decode step with 3 launches per layer (jb_gemv_pair).  A part-B workgroup
-        # waits in-kernel for part-A workgroups of the same launch, so at most ONE engine per GPU may run in this mode
-        # while other streams keep the chip busy (two such kernels oversubscribing the CUs could wait on each other).
-        if fused_pairs is None:
-            fused_pairs = bool(int(os.environ.get("JB_FUSED_PAIRS", "0")))
-        self.fused_pairs = bool(fused_pairs) and self.fold_ln and fp16 and n_batch <= 16
         dev, dt = self.device, self.dtype
         g = lambda name: sd[prefix + name].to(dev).contiguous()
         f32 = lambda name: g(name).float().contiguous()
-
         self.x_emb = f32("x_emb.weight")
         self.pos_emb = f32("pos_emb.pos_emb")
         self.start_token = None if y_cond else f32("start_token")
-        self.only_encode = only_encode
         self.x_out = None if only_encode else H.pack_linear_w(f32("x_out.weight"), torch.float32)
-        self.enc_len = int(encoder_dims or 0)
-        self._keep = []          # tensors referenced by raw pointer from the engine
-        self.layers_c = (L.Layer * depth)()
-        N, T, S, W, M = self.N, self.T, self.S, self.W, self.M
-        self.kcaches, self.vcaches = [], []
+        W, S, M = self.W, self.S, self.M
+        self.layers = []
         for d in range(depth):
             p = f"transformer._attn_mods.{d}."
             func = self.funcs[d]
             if func not in (0, 1, 2, 3, 6, 7):
                 raise L.JukeboxHipError(f"attn_func {func} is not supported by the engine")
-            ws = [H.pack_conv1d_w(g(p + n), dt) for n in ("attn.c_attn.w", "attn.c_proj.w", "mlp.c_fc.w", "mlp.c_proj.w")]
-            bs = [f32(p + n) for n in ("attn.c_attn.b", "attn.c_proj.b", "mlp.c_fc.b", "mlp.c_proj.b")]
-            lns = [f32(p + n) for n in ("ln_0.weight", "ln_0.bias", "ln_1.weight", "ln_1.bias")]
-            cap = self.prime_cap if func == 7 else (self.enc_len if func == 6 else T)
+            lay = dict(func=func,
+                       ws=[H.pack_conv1d_w(g(p + n), dt) for n in ("attn.c_attn.w", "attn.c_proj.w", "mlp.c_fc.w", "mlp.c_proj.w")],
+                       bs=[f32(p + n) for n in ("attn.c_attn.b", "attn.c_proj.b", "mlp.c_fc.b", "mlp.c_proj.b")],
+                       lns=[f32(p + n) for n in ("ln_0.weight", "ln_0.bias", "ln_1.weight", "ln_1.bias")],
+                       cap=self.prime_cap if func == 7 else (self.enc_len if func == 6 else self.T),
+                       f_attn=None, f_fc=None, enc=None, b_enc=None)
             if func == 6:
                 # c_enc_kv (n_in, 2*n_state): key half and value half as separate packed matrices
                 wkv = g(p + "attn.c_enc_kv.w")
-                enc = [H.PackedWeight(H.pack_weight(wkv, W, S, 2 * S, 1, dt, offset_elems=part * S), W, S, dt) for part in (0, 1)]
-                b_enc = f32(p + "attn.c_enc_kv.b")
-                self._keep += enc + [b_enc]
-            kc = torch.zeros((N, cap, S), dtype=dt, device=dev)
-            vc = torch.zeros((N, cap, S), dtype=dt, device=dev)
-            self.kcaches.append(kc)
-            self.vcaches.append(vc)
-            self._keep += ws + bs + lns
-            lc = self.layers_c[d]
-            lc.attn_func = func
-            lc.w_attn, lc.w_proj, lc.w_fc, lc.w_proj2 = (w.ptr for w in ws)
-            lc.b_attn, lc.b_proj, lc.b_fc, lc.b_proj2 = (b.data_ptr() for b in bs)
-            lc.ln0_g, lc.ln0_b, lc.ln1_g, lc.ln1_b = (t.data_ptr() for t in lns)
-            lc.kcache, lc.vcache, lc.cache_cap = kc.data_ptr(), vc.data_ptr(), cap
-            f_attn = f_fc = None
+                lay["enc"] = [H.PackedWeight(H.pack_weight(wkv, W, S, 2 * S, 1, dt, offset_elems=part * S), W, S, dt) for part in (0, 1)]
+                lay["b_enc"] = f32(p + "attn.c_enc_kv.b")
             if self.fold_ln:
                 j_attn = S if func == 6 else 3 * S
-                if H.ln_fold_supported(dt, W, j_attn, N):
-                    f_attn = f = H.FoldedLN(g(p + "attn.c_attn.w"), bs[0], lns[0], lns[1], dt)
+                if H.ln_fold_supported(dt, W, j_attn, 1):
+                    lay["f_attn"] = H.FoldedLN(g(p + "attn.c_attn.w"), lay["bs"][0], lay["lns"][0], lay["lns"][1], dt)
+                if H.ln_fold_supported(dt, W, M, 1):
+                    lay["f_fc"] = H.FoldedLN(g(p + "mlp.c_fc.w"), lay["bs"][2], lay["lns"][2], lay["lns"][3], dt)
+                for f in (lay["f_attn"], lay["f_fc"]):
+                    if f is not None:
+                        f.wf = None                  # the unpacked image is bind-time only
+            self.layers.append(lay)
+
+    def weight_bytes(self):
+        n = self.x_out.data.numel() * 4 if self.x_out is not None else 0
+        for lay in self.layers:
+            for w in lay["ws"] + (lay["enc"] or []):
+                n += w.data.numel() * w.data.element_size()
+        return n
+
+
+class PriorEngine:
+    """One ConditionalAutoregressive2D bound to device buffers for a fixed batch size: k/v caches, work buffers,
+    conditioning, token buffer, and the native engine handle (jb_engine_*).  The packed weights come from a PackedPrior
+    (`packed=`), or are packed here from `sd` when none is given.
+
+    The conditioning inputs are COPIED into persistent buffers, so the handle and its captured hipGraph survive across
+    windows (set_cond per window is a device copy, not a re-capture)."""
+
+    def __init__(self, sd=None, prefix="", *, n_batch, chunk_cap=256, want_preds=False, record=None, packed=None,
+                 **model):
+        if packed is None:
+            packed = PackedPrior(sd, prefix, **model)
+        self.packed = pk = packed
+        self.device = pk.device
+        self.N, self.T, self.bins, self.W = n_batch, pk.T, pk.bins, pk.W
+        self.S, self.M, self.H, self.depth = pk.S, pk.M, pk.H, pk.depth
+        self.dtype, self.code = pk.dtype, pk.code
+        self.block_ctx, self.prime_cap, self.funcs = pk.block_ctx, pk.prime_cap, pk.funcs
+        self.y_cond, self.add_cond_after, self.only_encode = pk.y_cond, pk.add_cond_after, pk.only_encode
+        self.enc_len, self.fold_ln = pk.enc_len, pk.fold_ln
+        self.chunk_cap = min(chunk_cap, self.T)
+        dev, dt = self.device, self.dtype
+        N, T, S, W, M = self.N, self.T, self.S, self.W, self.M
+        self.layers_c = (L.Layer * self.depth)()
+        self.kcaches, self.vcaches = [], []
+        for d, lay in enumerate(pk.layers):
+            kc = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
+            vc = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
+            self.kcaches.append(kc)
+            self.vcaches.append(vc)
+            lc = self.layers_c[d]
+            lc.attn_func = lay["func"]
+            lc.w_attn, lc.w_proj, lc.w_fc, lc.w_proj2 = (w.ptr for w in lay["ws"])
+            lc.b_attn, lc.b_proj, lc.b_fc, lc.b_proj2 = (b.data_ptr() for b in lay["bs"])
+            lc.ln0_g, lc.ln0_b, lc.ln1_g, lc.ln1_b = (t.data_ptr() for t in lay["lns"])
+            lc.kcache, lc.vcache, lc.cache_cap = kc.data_ptr(), vc.data_ptr(), lay["cap"]
+            if self.fold_ln:
+                j_attn = S if lay["func"] == 6 else 3 * S
+                f = lay["f_attn"]
+                if f is not None and H.ln_fold_supported(dt, W, j_attn, N):
                     lc.w_attn_f, lc.b_attn_f, lc.c1_attn = f.pw.ptr, f.bias.data_ptr(), f.c1.data_ptr()
-                    self._keep.append(f)
-                if H.ln_fold_supported(dt, W, M, N):
-                    f_fc = f = H.FoldedLN(g(p + "mlp.c_fc.w"), bs[2], lns[2], lns[3], dt)
+                f = lay["f_fc"]
+                if f is not None and H.ln_fold_supported(dt, W, M, N):
                     lc.w_fc_f, lc.b_fc_f, lc.c1_fc = f.pw.ptr, f.bias.data_ptr(), f.c1.data_ptr()
-                    self._keep.append(f)
-            if self.fused_pairs:
-                if func == 6 or f_attn is None or f_fc is None:
-                    raise L.JukeboxHipError("fused_pairs needs folded c_attn / c_fc images and no cross-attention layers")
-                pf = H.FusedPair(f_fc, g(p + "attn.c_proj.w"), bs[1], dt)          # c_proj + c_fc
-                stats = torch.zeros((2, W // 16, 16, 2), dtype=torch.int64, device=dev)
-                lc.w_pf, lc.k_f = pf.pw.ptr, pf.k.data_ptr()
-                lc.stats_1, lc.stats_2 = stats[0].data_ptr(), stats[1].data_ptr()
-                self._keep += [pf, stats]
-                if d > 0:                                                           # mlp.c_proj of layer d-1 + this c_attn
-                    pp = f"transformer._attn_mods.{d - 1}."
-                    pa = H.FusedPair(f_attn, g(pp + "mlp.c_proj.w"), f32(pp + "mlp.c_proj.b"), dt)
-                    self.layers_c[d - 1].w_2a, self.layers_c[d - 1].k_a = pa.pw.ptr, pa.k.data_ptr()
-                    self._keep.append(pa)
-            for f in (f_attn, f_fc):
-                if f is not None:
-                    f.wf = None                                                     # the unpacked image is bind-time only
-            if func == 6:
-                lc.w_enc_k, lc.w_enc_v, lc.b_enc_kv = enc[0].ptr, enc[1].ptr, b_enc.data_ptr()
+            if lay["func"] == 6:
+                lc.w_enc_k, lc.w_enc_v, lc.b_enc_kv = lay["enc"][0].ptr, lay["enc"][1].ptr, lay["b_enc"].data_ptr()
 
         e = lambda *shape, dtype=dt: torch.zeros(shape, dtype=dtype, device=dev)
         Cc = self.chunk_cap
         self.buf = dict(x_a=e(N, W), x_b=e(N, W), q=e(N, S), att=e(N, S), mlp=e(N, M),
-                        xf=e(N, W, dtype=torch.float32), logits=e(N, max(bins, 1), dtype=torch.float32),
+                        xf=e(N, W, dtype=torch.float32), logits=e(N, max(self.bins, 1), dtype=torch.float32),
                         c_xa=e(N * Cc, W), c_xb=e(N * Cc, W), c_h=e(N * Cc, W), c_q=e(N * Cc, S), c_att=e(N * Cc, S),
                         c_mlp=e(N * Cc, M))
+        # key-split decode attention (fp16 engines whose head size the split kernel takes): partial softmax states
+        self.att_parts = self.att_ml = None
+        split_env = os.environ.get("JB_ATTN_SPLIT_OFF", "0") == "1"
+        if not self.only_encode and not split_env and N <= 32 and \
+                L.lib().jb_attn_decode_split_parts(self.code, S // self.H, max(self.block_ctx, 16)) > 0:
+            self.att_parts = e(N, 4, S)
+            self.att_ml = e(N, self.H, 4, 2, dtype=torch.float32)
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.epoch = torch.ones(1, dtype=torch.int32, device=dev)        # fused_pairs: tag of the current step (never 0)
-        self.pair_error = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.preds = e(N, T, bins, dtype=torch.float32) if want_preds else None
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.preds = e(N, T, self.bins, dtype=torch.float32) if want_preds else None
         if want_preds:
             self.buf["c_xf"] = e(N * Cc, W, dtype=torch.float32)
         self.sample_params = H.make_sample_params(device=dev)
         # record = (layer, head, n_keys): keep that head's attention probabilities during prefill (alignment)
         self.record = record
         self.rec_out = e(N, T, record[2], dtype=torch.float32) if record else None
-        self.hidden = e(N, T, W, dtype=torch.float32) if only_encode else None
+        self.hidden = e(N, T, W, dtype=torch.float32) if self.only_encode else None
         self.encoder_kv = e(N, self.enc_len, W) if self.enc_len else None
+        # persistent conditioning: start row(s) and x_cond in the shape class last seen ("full" (N, T, W) / "bcast" (N, 1, W) / None)
+        self.start = e(N, W, dtype=torch.float32) if self.y_cond else pk.start_token.reshape(W).contiguous()
+        self.start_stride = W if self.y_cond else 0
         self.x_cond = None
-        self.start = None
+        self._cond_mode = "unset"
         self.handle = None
 
     # -- conditioning / sampler state ------------------------------------------------------------------
     def set_cond(self, x_cond, y_cond):
-        """x_cond: (N, T, W) / (N, 1, W) fp32 or None; y_cond: (N, 1, W) when the model is y-conditioned."""
+        """x_cond: (N, T, W) / (N, 1, W) fp32 or None; y_cond: (N, 1, W) when the model is y-conditioned.  Values are
+        copied into the engine's own buffers (same device addresses every window)."""
+        mode = None
         if x_cond is not None:
-            x_cond = x_cond.to(self.device).float().contiguous()
             assert x_cond.shape[0] == self.N and x_cond.shape[2] == self.W and x_cond.shape[1] in (1, self.T)
-        self.x_cond = x_cond
+            mode = "full" if x_cond.shape[1] == self.T and self.T > 1 else "bcast"
         if self.y_cond:
             assert y_cond is not None and tuple(y_cond.shape) == (self.N, 1, self.W)
-            self.start = y_cond.to(self.device).float().reshape(self.N, self.W).contiguous()
-            self.start_stride = self.W
-        else:
-            self.start = self.start_token.reshape(self.W).contiguous()
-            self.start_stride = 0
-        self._create()
+            self.start.copy_(y_cond.reshape(self.N, self.W))
+        if mode != self._cond_mode:
+            self.x_cond = None if mode is None else torch.empty((self.N, self.T if mode == "full" else 1, self.W),
+                                                                dtype=torch.float32, device=self.device)
+            self._cond_mode = mode
+            self._create()
+        if x_cond is not None:
+            self.x_cond.copy_(x_cond)
 
-    def set_sampling(self, temp=1.0, top_k=0, top_p=0.0, seed=0, sample_base=0):
-        new = H.make_sample_params(temp, top_k, top_p, seed, sample_base, device=self.device)
+    def set_sampling(self, temp=1.0, top_k=0, top_p=0.0, seed=0, sample_base=0, pos_base=0, stream_id=0):
+        new = H.make_sample_params(temp, top_k, top_p, seed, sample_base, pos_base, stream_id, device=self.device)
         self.sample_params.copy_(new)          # same device address: captured graphs stay valid
 
     def _create(self):
         self.close()
+        pk = self.packed
         c = L.EngineCfg()
         c.dtype, c.n_batch, c.width, c.n_state, c.n_head, c.n_mlp = self.code, self.N, self.W, self.S, self.H, self.M
         c.n_layers, c.seq_len, c.block_ctx, c.bins, c.ln_eps = self.depth, self.T, self.block_ctx, self.bins, 1e-5
-        c.x_emb, c.pos_emb = self.x_emb.data_ptr(), self.pos_emb.data_ptr()
-        c.x_out_packed = self.x_out.ptr if self.x_out is not None else None
+        c.x_emb, c.pos_emb = pk.x_emb.data_ptr(), pk.pos_emb.data_ptr()
+        c.x_out_packed = pk.x_out.ptr if pk.x_out is not None else None
         if self.encoder_kv is not None:
             c.encoder_kv, c.enc_len = self.encoder_kv.data_ptr(), self.enc_len
         if self.hidden is not None:
@@ -195,12 +227,12 @@ class PriorEngine:
             c.xc_n_stride = self.x_cond.stride(0)
             c.xc_t_stride = self.x_cond.stride(1) if self.x_cond.shape[1] > 1 else 0
         c.add_cond_after = int(self.add_cond_after)
-        c.prefetch_next_weights = int(os.environ.get("JB_PREFETCH", "0"))
-        c.fused_pairs = int(self.fused_pairs)
-        c.epoch_dev, c.pair_error = self.epoch.data_ptr(), self.pair_error.data_ptr()
         b = self.buf
         for k in ("x_a", "x_b", "q", "att", "mlp", "xf", "logits", "c_xa", "c_xb", "c_h", "c_q", "c_att", "c_mlp"):
             setattr(c, k, b[k].data_ptr())
+        if self.att_parts is not None:
+            c.att_parts, c.att_ml = self.att_parts.data_ptr(), self.att_ml.data_ptr()
+        c.ticket = self.ticket.data_ptr()
         c.chunk_cap = self.chunk_cap
         c.c_xf = b["c_xf"].data_ptr() if "c_xf" in b else None
         c.tokens, c.tok_stride, c.t_dev = self.tokens.data_ptr(), self.tokens.stride(0), self.t_dev.data_ptr()
@@ -250,9 +282,12 @@ class PriorEngine:
     def launches_per_step(self):
         return L.lib().jb_engine_launches_per_step(self.handle)
 
+    def step_bytes(self, t):
+        """Algorithmic HBM bytes of one decode step at position t."""
+        return float(L.lib().jb_engine_step_bytes(self.handle, int(t)))
+
     def cache_bytes(self):
         return sum(k.numel() * k.element_size() * 2 for k in self.kcaches)
 
     def weight_bytes(self):
-        return sum(t.data.numel() * t.data.element_size() if isinstance(t, H.PackedWeight) else 0 for t in self._keep) \
-            + (self.x_out.data.numel() * 4 if self.x_out is not None else 0)
+        return self.packed.weight_bytes()

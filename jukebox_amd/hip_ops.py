@@ -57,50 +57,10 @@ class FoldedLN:
         K, J = w.shape
         w_used = w.to(dtype).double()
         wf = (gamma.double()[:, None] * w_used).to(dtype).contiguous()
-        self.wf = wf                                           # unpacked diag(gamma)·W (kept for FusedPair images)
+        self.wf = wf                                           # unpacked diag(gamma)·W
         self.pw = PackedWeight(pack_weight(wf, K, J, J, 1, dtype), K, J, dtype)
         self.c1 = wf.double().sum(0).float().contiguous()
         self.bias = (beta.double() @ w_used + b.double()).float().contiguous()
-
-
-class FusedPair:
-    """EXPERIMENTAL image for jb_gemv_pair part B: the projection behind a residual add, taken from the operands of
-    the add.  `folded` is the FoldedLN of that projection (W' = diag(gamma)·W); the residual add is
-    out = res + in1·w_prev + b_prev (w_prev: Conv1D.w (K1, K0)).  Packs [W' ; w_prev·W'] as one (K0 + K1) x J matrix
-    and k = b_prev·W'; c1 / bias stay those of `folded`."""
-
-    def __init__(self, folded, w_prev, b_prev, dtype):
-        wf = folded.wf
-        K0, J = wf.shape
-        K1 = w_prev.shape[0]
-        assert w_prev.shape[1] == K0
-        prod = (w_prev.to(dtype).float() @ wf.float()).to(dtype)
-        cat = torch.cat([wf, prod], 0).contiguous()
-        self.pw = PackedWeight(pack_weight(cat, K0 + K1, J, J, 1, dtype), K0 + K1, J, dtype)
-        self.k = (b_prev.float() @ wf.float()).contiguous()
-        self.K0, self.K1, self.J = K0, K1, J
-
-
-def gemv_pair(in1, w_a, bias_a, res, in0, folded, pair, stats, epoch, error, act=L.ACT_NONE, eps=1e-5):
-    """jb_gemv_pair (EXPERIMENTAL): returns (out_a, out_b) = (res + in1·Wa + bias_a, act(LN(out_a)·W + b)) with the
-    second taken from (in0, in1) and the folded / fused images."""
-    _chk_cuda(in1, res, in0, stats, epoch, error)
-    n = in1.shape[0]
-    out_a = torch.empty_like(res)
-    out_b = torch.empty((n, pair.J), dtype=in1.dtype, device=in1.device)
-    a = L.GemvPairArgs()
-    a.n_rows = n
-    a.in1, a.ld1, a.K1 = in1.data_ptr(), in1.stride(0), in1.shape[1]
-    a.Wa, a.bias_a, a.res, a.ldr = w_a.ptr, L.ptr(bias_a), res.data_ptr(), res.stride(0)
-    a.out_a, a.ldo_a, a.J_a = out_a.data_ptr(), out_a.stride(0), res.shape[1]
-    a.in0, a.ld0, a.K0 = in0.data_ptr(), in0.stride(0), in0.shape[1]
-    a.Wb, a.k_b, a.c1_b, a.bias_b, a.J_b, a.act = pair.pw.ptr, pair.k.data_ptr(), folded.c1.data_ptr(), \
-        folded.bias.data_ptr(), pair.J, act
-    a.out_b, a.ldo_b = out_b.data_ptr(), out_b.stride(0)
-    a.ln_eps = eps
-    a.stats, a.epoch_dev, a.error_flag = stats.data_ptr(), epoch.data_ptr(), error.data_ptr()
-    L.check(L.lib().jb_gemv_pair(C.byref(a), L.stream()))
-    return out_a, out_b
 
 
 def ln_fold_supported(dtype, K, J, n_rows):
@@ -203,18 +163,34 @@ def tap_view(pw, taps):
     return v
 
 
-def gemv(x, pw, bias=None, ln=None, res=None, act=L.ACT_NONE, out=None, eps=1e-5, ln_fold=None):
+def gemv(x, pw, bias=None, ln=None, res=None, act=L.ACT_NONE, out=None, eps=1e-5, ln_fold=None, parts=None, out2=None,
+         add2=None, t_dev=None):
     """Decode-step skinny GEMM (see jb_gemv).  x: (n_rows<=64, K).  ln = (gamma, beta): normalise the rows in the
-    kernel; ln_fold = FoldedLN: the folded form (pw / bias are taken from it)."""
+    kernel; ln_fold = FoldedLN: the folded form (pw / bias are taken from it); parts = (x_parts (N, P, K) f16,
+    ml (N, H, P, 2) fp32): the operand is the merge of the key-split attention's partial states (x must be None);
+    out2 (N, J) fp32 [+ add2 (N, T, J) fp32 read at row *t_dev]: the second, fp32 output of the plain projection."""
     if ln_fold is not None:
         assert ln is None and bias is None and pw is None
         pw, bias = ln_fold.pw, ln_fold.bias
-    _chk_cuda(x, bias, res, out)
+    _chk_cuda(x, bias, res, out, out2, add2)
+    src = x if x is not None else parts[0]
     if out is None:
-        out = torch.empty((x.shape[0], pw.J), dtype=x.dtype, device=x.device)
+        out = torch.empty((src.shape[0], pw.J), dtype=src.dtype, device=src.device)
     a = L.GemvArgs()
-    a.dtype = L.dtype_code(x.dtype)
-    a.x, a.ldx, a.n_rows = x.data_ptr(), x.stride(0), x.shape[0]
+    a.dtype = L.dtype_code(src.dtype)
+    a.n_rows = src.shape[0]
+    if x is not None:
+        a.x, a.ldx = x.data_ptr(), x.stride(0)
+    else:
+        xp, ml = parts
+        _chk_cuda(xp, ml)
+        a.x_parts, a.x_ml, a.n_parts, a.n_head = xp.data_ptr(), ml.data_ptr(), xp.shape[1], ml.shape[1]
+        a.d_head, a.ldx = xp.shape[2] // ml.shape[1], xp.shape[2]
+    if out2 is not None:
+        a.out2, a.ldo2 = out2.data_ptr(), out2.stride(0)
+        if add2 is not None:
+            a.add2, a.add2_n_stride, a.add2_t_stride = add2.data_ptr(), add2.stride(0), add2.stride(1)
+        a.t_dev = L.ptr(t_dev)
     if ln is not None:
         a.ln_gamma, a.ln_beta, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), eps
     if ln_fold is not None:
@@ -236,6 +212,18 @@ def attn_decode(func, q, kcache, vcache, n_head, block_ctx, t_dev, max_len):
                                    vcache.data_ptr(), kcache.shape[1], out.data_ptr(), out.stride(0), N, n_head,
                                    S // n_head, block_ctx or 0, t_dev.data_ptr(), max_len, L.stream()))
     return out
+
+
+def attn_decode_split(func, q, kcache, vcache, n_head, block_ctx, t_dev, max_keys, n_parts):
+    """Key-split decode attention (fp16): returns (parts (N, n_parts, S) f16, ml (N, n_head, n_parts, 2) fp32)."""
+    _chk_cuda(q, kcache, vcache, t_dev)
+    N, S = q.shape
+    parts = torch.empty((N, n_parts, S), dtype=q.dtype, device=q.device)
+    ml = torch.empty((N, n_head, n_parts, 2), dtype=torch.float32, device=q.device)
+    L.check(L.lib().jb_attn_decode_split(func, q.data_ptr(), q.stride(0), kcache.data_ptr(), vcache.data_ptr(),
+                                         kcache.shape[1], parts.data_ptr(), ml.data_ptr(), N, n_head, S // n_head,
+                                         block_ctx or 0, t_dev.data_ptr(), max_keys, n_parts, L.stream()))
+    return parts, ml
 
 
 def attn_prefill(func, q, kcache, vcache, n_head, block_ctx, t0):
@@ -273,8 +261,8 @@ def sample_logits(logits, params_dev, tokens, t_dev, preds=None):
                                      preds.stride(0) if preds is not None else 0, L.stream()))
 
 
-def make_sample_params(temp=1.0, top_k=0, top_p=0.0, seed=0, sample_base=0, device="cuda"):
+def make_sample_params(temp=1.0, top_k=0, top_p=0.0, seed=0, sample_base=0, pos_base=0, stream_id=0, device="cuda"):
     """Device copy of jb_sample_params."""
-    p = L.SampleParams(temp, top_k, top_p, sample_base, seed)
+    p = L.SampleParams(temp, top_k, top_p, sample_base, seed & 0xFFFFFFFFFFFFFFFF, pos_base, stream_id)
     raw = bytes(p)
     return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)

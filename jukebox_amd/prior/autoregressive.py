@@ -8,7 +8,7 @@ import numpy as np
 import torch as t
 import torch.nn as nn
 
-from ..engine import PriorEngine
+from ..engine import PackedPrior, PriorEngine
 from ..transformer.transformer import Transformer
 
 
@@ -67,14 +67,14 @@ class ConditionalAutoregressive2D(nn.Module):
             self.x_out = nn.Linear(width, bins, bias=False)
             if self.share_x_emb_x_out:
                 self.x_out.weight = self.x_emb.weight
-        self._engines = {}
+        self._engines, self._packed, self._last_engine = {}, {}, None
 
     def _apply(self, fn, *a, **k):
         before = (self.x_emb.weight.device, self.x_emb.weight.dtype, self.x_emb.weight.data_ptr())
         out = super()._apply(fn, *a, **k)
         after = (self.x_emb.weight.device, self.x_emb.weight.dtype, self.x_emb.weight.data_ptr())
-        if before != after:
-            self._engines = {}          # device copies are dropped when the module really moves (prior.cpu())
+        if before != after:             # device copies are dropped when the module really moves (prior.cpu())
+            self._engines, self._packed, self._last_engine = {}, {}, None
         return out
 
     def preprocess(self, x):
@@ -89,23 +89,37 @@ class ConditionalAutoregressive2D(nn.Module):
 
     # ---- engine binding --------------------------------------------------------------------------------
     def engine(self, n_samples, fp16, want_preds=False, chunk_cap=512):
-        key = (n_samples, bool(fp16), bool(want_preds))
+        """The engine bound to this prior for a batch size.  The packed weights (PackedPrior) are built once per dtype
+        and shared; an engine per (batch size, dtype, logits recording) adds only its k/v caches and work buffers and
+        stays bound, so alternating batch sizes (split_batch tails) or get_preds calls never re-pack weights."""
+        fp16 = bool(fp16)
+        packed = self.packed(fp16)
+        key = (n_samples, fp16, bool(want_preds))
         if key not in self._engines:
-            self._engines = {}          # one bound engine at a time (weights are packed per engine)
+            self._engines[key] = PriorEngine(packed=packed, n_batch=n_samples, chunk_cap=chunk_cap,
+                                             want_preds=want_preds)
+        self._last_engine = self._engines[key]
+        return self._last_engine
+
+    def packed(self, fp16):
+        """This prior's weights in MFMA order for one engine dtype (built on first use, dropped when the module moves)."""
+        if self.x_emb.weight.device.type != "cuda":
+            raise RuntimeError("move the prior to the GPU before sampling (prior.cuda()); there is no CPU path")
+        fp16 = bool(fp16)
+        if fp16 not in self._packed:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            if self.x_emb.weight.device.type != "cuda":
-                raise RuntimeError("move the prior to the GPU before sampling (prior.cuda()); there is no CPU path")
-            self._engines[key] = PriorEngine(sd, "", n_batch=n_samples, seq_len=self.input_dims, bins=self.bins,
+            self._packed[fp16] = PackedPrior(sd, "", seq_len=self.input_dims, bins=self.bins,
                                              encoder_dims=self.encoder_dims if 6 in self._funcs() else 0,
-                                             only_encode=self.only_encode,
-                                             width=self.width, depth=self.depth, heads=self.heads,
-                                             attn_order=self.attn_order, blocks=self.blocks, m_attn=self.m_attn,
-                                             m_mlp=self.m_mlp, prime_len=self.prime_len, y_cond=self.y_cond,
-                                             add_cond_after=self.add_cond_after_transformer, fp16=fp16,
-                                             chunk_cap=chunk_cap, want_preds=want_preds,
-                                             fused_pairs=getattr(self, "fused_pairs", None),
-                                             device=self.x_emb.weight.device)
-        return self._engines[key]
+                                             only_encode=self.only_encode, width=self.width, depth=self.depth,
+                                             heads=self.heads, attn_order=self.attn_order, blocks=self.blocks,
+                                             m_attn=self.m_attn, m_mlp=self.m_mlp, prime_len=self.prime_len,
+                                             y_cond=self.y_cond, add_cond_after=self.add_cond_after_transformer,
+                                             fp16=fp16, device=self.x_emb.weight.device)
+        return self._packed[fp16]
+
+    def bound_engine(self):
+        """The engine used last (bench.py probes it); None before the first sample / forward call."""
+        return self._last_engine
 
     def _funcs(self):
         from ..engine import attn_funcs
@@ -161,7 +175,7 @@ class ConditionalAutoregressive2D(nn.Module):
             assert x_cond is None
 
     def _run(self, n_samples, x_prime, x_cond, y_cond, encoder_kv, fp16, temp, top_k, top_p, get_preds, sample_tokens,
-             seed=0, sample_base=0):
+             seed=0, sample_base=0, pos_base=0, stream_id=0):
         assert self.training is False
         assert top_k == 0 or top_p == 0.0
         has_cross = 6 in self._funcs()
@@ -171,7 +185,8 @@ class ConditionalAutoregressive2D(nn.Module):
         self._check_cond(n_samples, x_cond, y_cond)
         eng = self.engine(n_samples, fp16, want_preds=get_preds)
         eng.set_cond(x_cond, y_cond)
-        eng.set_sampling(temp=temp, top_k=top_k, top_p=top_p, seed=seed, sample_base=sample_base)
+        eng.set_sampling(temp=temp, top_k=top_k, top_p=top_p, seed=seed, sample_base=sample_base, pos_base=pos_base,
+                         stream_id=stream_id)
         if has_cross:
             assert tuple(encoder_kv.shape) == (n_samples, self.encoder_dims, self.width)
             eng.set_encoder_kv(encoder_kv)
@@ -204,16 +219,18 @@ class ConditionalAutoregressive2D(nn.Module):
         return x
 
     def sample(self, n_samples, x_cond=None, y_cond=None, encoder_kv=None, fp16=False, temp=1.0, top_k=0, top_p=0.0,
-               get_preds=False, sample_tokens=None, seed=0, sample_base=0):
-        """autoregressive.py:199-249."""
+               get_preds=False, sample_tokens=None, seed=0, sample_base=0, pos_base=0, stream_id=0):
+        """autoregressive.py:199-249.  Extensions: the draw for sample n at window position t is the counter-based uniform
+        keyed by (seed, stream_id, sample_base + n, pos_base + t) -- see jb_sample_params."""
         with t.no_grad():
             return self._run(n_samples, None, x_cond, y_cond, encoder_kv, fp16, temp, top_k, top_p, get_preds,
-                             sample_tokens, seed, sample_base)
+                             sample_tokens, seed, sample_base, pos_base, stream_id)
 
     def primed_sample(self, n_samples, x, x_cond=None, y_cond=None, encoder_kv=None, fp16=False, temp=1.0, top_k=0,
-                      top_p=0.0, get_preds=False, chunk_size=None, sample_tokens=None, seed=0, sample_base=0):
+                      top_p=0.0, get_preds=False, chunk_size=None, sample_tokens=None, seed=0, sample_base=0, pos_base=0,
+                      stream_id=0):
         """autoregressive.py:251-359.  `chunk_size` is accepted for API compatibility; the engine prefills in its
         own (larger) chunks -- results are chunk-invariant (the reference's check_chunks, factored_attention.py:457-488)."""
         with t.no_grad():
             return self._run(n_samples, x, x_cond, y_cond, encoder_kv, fp16, temp, top_k, top_p, get_preds,
-                             sample_tokens, seed, sample_base)
+                             sample_tokens, seed, sample_base, pos_base, stream_id)

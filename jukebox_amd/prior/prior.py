@@ -180,9 +180,10 @@ class SimplePrior(nn.Module):
         return None
 
     def sample(self, n_samples, z=None, z_conds=None, y=None, fp16=False, temp=1.0, top_k=0, top_p=0.0, chunk_size=None,
-               sample_tokens=None, seed=0, sample_base=0):
-        """prior.py:245-283.  seed / sample_base (extensions): the random stream of global sample index
-        sample_base + n at position t is a pure function of (seed, index, t), so sharded runs reproduce."""
+               sample_tokens=None, seed=0, sample_base=0, pos_base=0):
+        """prior.py:245-283.  seed / sample_base / pos_base (extensions): the draw for global sample index
+        sample_base + n at window position t is a pure function of (seed, level, index, pos_base + t) -- pos_base is the
+        window's start at this level -- so sharded runs reproduce and no two windows or levels share a draw."""
         N = n_samples
         if z is not None:
             assert z.shape[0] == N, f"Expected shape ({N},**), got shape {z.shape}"
@@ -195,7 +196,8 @@ class SimplePrior(nn.Module):
         if dist.get_rank() == 0:
             name = {True: "Ancestral", False: "Primed"}[no_past_context]
             print_once(f"{name} sampling {n_samples} samples with temp={temp}, top_k={top_k}, top_p={top_p}")
-        kw = dict(fp16=fp16, temp=temp, top_k=top_k, top_p=top_p, seed=seed, sample_base=sample_base)
+        kw = dict(fp16=fp16, temp=temp, top_k=top_k, top_p=top_p, seed=seed, sample_base=sample_base, pos_base=pos_base,
+                  stream_id=int(self.level))
         self.prior.decode_tap = self._decode_tap()
         with t.no_grad():
             x_cond, y_cond, prime = self.get_cond(z_conds, y)

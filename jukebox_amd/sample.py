@@ -58,7 +58,7 @@ def sample_single_window(zs, labels, sampling_kwargs, level, prior, start, hps):
     for z_i, z_conds_i, y_i in zip(z_list, z_conds_list, y_list):
         z_conds_i = None if z_conds_i is None else [zc.contiguous() for zc in z_conds_i]
         z_samples.append(prior.sample(n_samples=z_i.shape[0], z=z_i.contiguous(), z_conds=z_conds_i, y=y_i,
-                                      sample_base=sample_base + done, **kwargs))
+                                      sample_base=sample_base + done, pos_base=start, **kwargs))
         done += z_i.shape[0]
     z = t.cat(z_samples, dim=0)
     z_new = z[:, -new_tokens:]
@@ -92,7 +92,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     HIP stream (driven by its own host thread) and starts a window as soon as the upper-level codes that window is
     conditioned on exist (prior.get_z_conds needs zs[level+1][start/cd : end/cd]).  The decode step is latency-bound
     and uses at most half of the CUs, so the three levels overlap almost for free.  Tokens are a pure function of
-    (seed, global sample index, position), so the schedule does not change the result."""
+    (seed, level, global sample index, absolute position), so the schedule does not change the result."""
     import threading
     cond = threading.Condition()
     progress = {l: int(z.shape[1]) for l, z in enumerate(zs_local)}
@@ -114,13 +114,6 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # normal-priority stream ran three decode chains concurrently at 1.3x the single-chain step time.  The two
     # upsampler levels (the long poles) therefore get high priority, the top level normal priority.
     order = sorted(levels)                                 # lowest level first
-    if os.environ.get("JB_FUSED_PAIRS") == "1":
-        # experimental 3-launch decode layer: its kernels wait in-kernel on workgroups of the same launch, so at most one
-        # of the concurrently running engines may use it -- the long pole (lowest level)
-        for level in levels:
-            ar = getattr(priors[level], "prior", None)
-            if ar is not None:
-                ar.fused_pairs = level == order[0]
     prios = [-1, -1, 0, 0]
     stream_of = {level: t.cuda.Stream(device=device, priority=prios[min(i, 3)]) if on_gpu else None
                  for i, level in enumerate(order)}
@@ -225,6 +218,15 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
     (identical on every rank -- see broadcast_conditioning); returns the full zs on every rank."""
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_range(hps.n_samples, rank, world)
+    # One seed per job (hps.seed, `--seed` on the command line); without one rank 0 draws it from the OS, as the reference's
+    # unseeded torch RNG gives different audio on every run.  The draw of (level, sample, absolute position) is a pure
+    # function of it, whatever the sharding, the window schedule or the batch split.
+    seed = hps.get("seed", None)
+    if seed is None:
+        seed = int.from_bytes(os.urandom(7), "little")
+        if world > 1:
+            seed = int(broadcast_tensor(t.tensor([seed], dtype=t.long, device=device), 0)[0].item())
+    sampling_kwargs = [dict(kw, seed=int(kw.get("seed", seed))) for kw in sampling_kwargs]
     local_hps = Hyperparams(hps)
     local_hps.n_samples = hi - lo
     zs_local = [z[lo:hi].contiguous() for z in zs]

@@ -46,19 +46,22 @@ def test_binding_loads_and_validates_arguments(built):
 
 
 def test_struct_layouts_match_header():
-    """ctypes mirrors vs sizes the C compiler computes (guards against silent field drift)."""
-    import subprocess, tempfile, textwrap
+    """ctypes mirrors vs the layout the C compiler computes from include/jukebox_hip.h: the size of every struct and the
+    offset of every field (guards against silent field drift / reordering)."""
+    import subprocess, tempfile
     from jukebox_amd import _lib as L
-    src = textwrap.dedent("""
-        #include <stdio.h>
-        #include "jukebox_hip.h"
-        int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(jb_gemm_args), sizeof(jb_gemv_args),
-                                sizeof(jb_sample_params), sizeof(jb_layer), sizeof(jb_engine_cfg),
-                                sizeof(jb_gemv_pair_args)); return 0; }
-    """)
+    pairs = [("jb_gemm_args", L.GemmArgs), ("jb_gemv_args", L.GemvArgs), ("jb_sample_params", L.SampleParams),
+             ("jb_layer", L.Layer), ("jb_engine_cfg", L.EngineCfg)]
+    lines, expect = [], []
+    for cname, ct in pairs:
+        lines.append(f'printf("%zu\\n", sizeof({cname}));')
+        expect.append(C.sizeof(ct))
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("%zu\\n", offsetof({cname}, {fname}));')
+            expect.append(getattr(ct, fname).offset)
+    src = "#include <stdio.h>\n#include <stddef.h>\n#include \"jukebox_hip.h\"\nint main(void) {\n" + "\n".join(lines) + "\nreturn 0; }\n"
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
-        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
-    assert sizes == [C.sizeof(L.GemmArgs), C.sizeof(L.GemvArgs), C.sizeof(L.SampleParams), C.sizeof(L.Layer),
-                     C.sizeof(L.EngineCfg), C.sizeof(L.GemvPairArgs)]
+        got = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    assert got == expect

@@ -1,0 +1,59 @@
+"""CPU suite: bench.py's driver contract without a GPU (`--dry-run`: every step is a short sleep).
+
+`python bench.py --gpus N` must create its own N ranks when no launcher did (the driver calls it both ways), rank 0
+prints exactly one JSON line with n_gpus = N, and the step loop works against the wall budget: at least one step, at most
+--steps, never past JB_BENCH_BUDGET_S."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "JB_BENCH_T0", "JB_BENCH_BUDGET_S"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_single_process_line_and_budget():
+    out = _run(["--dry-run", "--steps", "3", "--warmup", "5"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["steps_requested"] == 3 and out["warmup_requested"] == 5
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["vs_baseline"] is None
+    # a budget that is already spent: exactly one step is timed, the line still appears
+    out = _run(["--dry-run", "--steps", "20", "--warmup", "5"], env=dict(JB_BENCH_BUDGET_S="0"))
+    assert out["steps"] == 1 and out["steps_requested"] == 20
+
+
+def test_gpus_2_spawns_its_own_ranks():
+    """No outer torchrun: bench.py re-launches itself as 2 ranks (gloo here), both run the same number of steps, rank 0
+    reports n_gpus = 2 and the max-over-ranks time (rank 1 sleeps twice as long per step)."""
+    out = _run(["--gpus", "2", "--dry-run", "--steps", "4"])
+    assert out["n_gpus"] == 2 and out["steps"] == 4
+    assert out["dist"]["world_size"] == 2 and out["dist"]["backend"] == "gloo"
+    assert out["ms_per_step"] >= 38.0            # rank 1: 40 ms per step
+    assert out["config"]["parallelism"] == "sample-sharded x2"
+
+
+def test_outer_launcher_is_respected():
+    """Launched the driver's way (torch.distributed.run outside): no second level of spawning."""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "JB_BENCH_T0", "JB_BENCH_BUDGET_S"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+                        "--steps", "2"], capture_output=True, text=True, env=e, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2

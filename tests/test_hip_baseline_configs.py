@@ -98,3 +98,189 @@ def test_config3_1b_top_prior_geometry():
     torch.cuda.synchronize()
     p16 = eng16.preds.cpu().numpy()[:, n_tok - 1:n_tok + 1]
     assert np.abs(p16 - p_ref[:, n_tok - 1:n_tok + 1]).max() < 5e-2 * max(1.0, np.abs(p_ref).max())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Full-size parity at BASELINE's configs 2 and 3.  The CPU oracle cannot teacher-force 8000 positions x 16 samples in a
+# test (hours), so the checks are split the way the path itself is split:
+#   (a) PREFILL at the real index ranges: the engine's chunked prefill of the whole prefix, all layers, against the numpy
+#       oracle (oracle.transformer.Transformer, pinned to the reference's goldens) for sample 0 -- every layer's k/v rows
+#       at every position (the last layer's rows depend on everything before them);
+#   (b) DECODE at the real index ranges, all N = 16 samples: the torch port of the oracle's decode step
+#       (oracle/torch_port.py, pinned to the numpy oracle) starts from the k/v caches (a) has validated and must produce
+#       the engine's logits and greedy tokens for 64 consecutive positions.
+def _random_prior_state(gen, W, depth, bins, seq, heads, y_cond, scale=0.02):
+    S = W // 4
+    r = lambda *shape, sc=scale: torch.randn(*shape, device="cuda", generator=gen) * sc
+    sd = {"x_emb.weight": r(bins, W, sc=0.05), "pos_emb.pos_emb": r(seq, W, sc=0.01)}
+    sd["x_out.weight"] = sd["x_emb.weight"]
+    if not y_cond:
+        sd["start_token"] = r(1, W, sc=0.01)
+    for d in range(depth):
+        p = f"transformer._attn_mods.{d}."
+        sd[p + "attn.c_attn.w"], sd[p + "attn.c_proj.w"] = r(W, 3 * S), r(S, W)
+        sd[p + "mlp.c_fc.w"], sd[p + "mlp.c_proj.w"] = r(W, W), r(W, W)
+        for nm, n in (("attn.c_attn.b", 3 * S), ("attn.c_proj.b", W), ("mlp.c_fc.b", W), ("mlp.c_proj.b", W)):
+            sd[p + nm] = r(n, sc=0.01)
+        for ln in ("ln_0", "ln_1"):
+            sd[p + ln + ".weight"] = 1 + r(W, sc=0.05)
+            sd[p + ln + ".bias"] = r(W, sc=0.02)
+    return sd
+
+
+def _embed_np(sd_np, tokens, t0, n_t, x_cond, start):
+    """get_emb (autoregressive.py:177-197) for positions t0..t0+n_t-1 of the given samples: (N, n_t, W) float32."""
+    pos = np.arange(t0, t0 + n_t)
+    prev = np.where(pos > 0, pos - 1, 0)
+    x = sd_np["x_emb.weight"][tokens[:, prev]]
+    if t0 == 0:
+        x[:, 0] = start
+    x = x + sd_np["pos_emb.pos_emb"][pos][None]
+    if x_cond is not None:
+        x = x + x_cond[:, pos]
+    return x.astype(np.float32)
+
+
+def _full_size_case(tag, W, depth, heads, attn_order, blocks, seq, bins, prime_len, y_cond, t0, n_steps, N=16, seed=3):
+    from jukebox_amd.engine import PriorEngine
+    from oracle.torch_port import TorchDecodeStack
+    from oracle.transformer import Transformer as OracleTransformer
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    sd = _random_prior_state(gen, W, depth, bins, seq, heads, y_cond)
+    eng = PriorEngine(sd, "", n_batch=N, seq_len=seq, bins=bins, width=W, depth=depth, heads=heads, attn_order=attn_order,
+                      blocks=blocks, prime_len=prime_len, y_cond=y_cond, fp16=False, want_preds=True, chunk_cap=512)
+    x_cond = torch.randn(N, seq, W, device="cuda", generator=gen) * 0.05 if y_cond else None
+    yc = torch.randn(N, 1, W, device="cuda", generator=gen) * 0.05 if y_cond else None
+    eng.set_cond(x_cond, yc)
+    eng.set_sampling(temp=1.0, top_k=1)
+    tokens = torch.randint(0, bins if prime_len is None else 79, (N, t0), device="cuda", generator=gen)
+    eng.tokens[:, :t0] = tokens
+    eng.prefill(0, t0)
+    eng.decode(t0, n_steps)
+    torch.cuda.synchronize()
+    z = eng.tokens.cpu().numpy()[:, :t0 + n_steps]
+    preds = eng.preds[:, t0:t0 + n_steps].cpu().numpy()
+    sd_np = {k: v.cpu().numpy() for k, v in sd.items()}
+    tr_sd = {k[len("transformer."):]: v for k, v in sd_np.items() if k.startswith("transformer.")}
+    xc_np = x_cond[:, :t0 + n_steps].cpu().numpy() if x_cond is not None else None
+    start = yc.cpu().numpy().reshape(N, W) if y_cond else sd_np["start_token"].reshape(1, W)
+
+    # (a) prefill of sample 0 at every position, every layer
+    tr = OracleTransformer(tr_sd, "", W, seq, heads, depth, attn_order=attn_order, blocks=blocks, prime_len=prime_len)
+    for c0 in range(0, t0, 1024):
+        n = min(1024, t0 - c0)
+        tr.forward(_embed_np(sd_np, z[:1], c0, n, None if xc_np is None else xc_np[:1], start[:1]), t0=c0)
+    worst = 0.0
+    for d in range(depth):
+        cap = tr.k[d].shape[1]
+        for cache, ref in ((eng.kcaches[d], tr.k[d]), (eng.vcaches[d], tr.v[d])):
+            got = cache[0, :min(cap, t0)].cpu().numpy()
+            worst = max(worst, float(np.abs(got - ref[0, :got.shape[0]]).max() / max(1.0, np.abs(ref).max())))
+    assert worst < 3e-4, (tag, "prefill k/v", worst)
+    del tr
+
+    # (b) decode of all samples from the validated caches
+    st = TorchDecodeStack(tr_sd, "", W, seq, heads, depth, attn_order=attn_order, blocks=blocks, prime_len=prime_len, n_batch=N)
+    for d in range(depth):
+        n = min(st.K[d].shape[1], t0)
+        st.K[d][:, :n] = eng.kcaches[d][:, :n].cpu()
+        st.V[d][:, :n] = eng.vcaches[d][:, :n].cpu()
+    st.t = t0
+    w_out = sd_np["x_out.weight"]
+    for i in range(n_steps):
+        t = t0 + i
+        x = _embed_np(sd_np, z, t, 1, xc_np, start)              # the engine's own tokens: teacher-forced on its stream
+        h = st.forward(x).numpy().reshape(N, W)
+        if xc_np is not None:
+            h = h + xc_np[:, t]                                    # add_cond_after_transformer
+        logits = h @ w_out.T
+        err = np.abs(preds[:, i] - logits).max() / max(1.0, np.abs(logits).max())
+        assert err < 5e-4, (tag, "logits", t, err)
+        pick = logits.argmax(1)
+        for n in np.nonzero(pick != z[:, t])[0]:
+            srt = np.sort(logits[n])
+            assert srt[-1] - srt[-2] < 2e-3, (tag, "token mismatch outside a near-tie", n, t)
+    eng.close()
+
+
+def test_config2_small_prior_full_size_late_positions():
+    """BASELINE config 2: small_prior (hparams.py:210 -- width 1024, depth 48, 1 head, attn_order 2, blocks 64, n_ctx 8192),
+    N = 16, fp32: teacher-forced prefill of 8064 positions, then 64 greedy decode steps in block row 63 -- the transpose
+    pattern reads 64 keys at stride 128, prev_block reads block 62, block attention the last block."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    h = setup_hparams("small_prior", {})
+    assert (h.prior_width, h.prior_depth, h.heads, h.attn_order, h.blocks, h.n_ctx) == (1024, 48, 1, 2, 64, 8192)
+    _full_size_case("small_prior", W=1024, depth=48, heads=1, attn_order=2, blocks=64, seq=8192, bins=1024, prime_len=None,
+                    y_cond=False, t0=8064, n_steps=64)
+
+
+def test_config3_1b_lyrics_top_prior_full_depth():
+    """BASELINE config 3: prior_1b_lyrics at FULL depth 72, N = 16 (width 2048, 2 heads x 256, attn_order 12: prime layers
+    15 / 31 / 63 with 448 keys, dense layer 47; 384 lyric + 6144 music positions, block_ctx 102): 384-token lyric prefill,
+    then 64 greedy decode steps, fp32."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _full_size_case("1b_lyrics_top", W=2048, depth=72, heads=2, attn_order=12, blocks=64, seq=6528, bins=2127, prime_len=384,
+                    y_cond=True, t0=384, n_steps=64)
+
+
+def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
+    """The timed configuration is fp16 with folded LayerNorm and the key-split attention, whose rounding points differ from
+    the reference-ordered fp16 path.  Gate: on the upsampler geometry (width 1920, depth 72, block_ctx 64), N = 16, with
+    OUTLIER channels in the residual stream and in the LayerNorm gains (what real checkpoints have and what stresses the
+    sum-of-squares form of the folded variance), every engine teacher-forced on the fp32 engine's greedy stream:
+      * the production engine's logits are as close to fp32 as those of the reference-ordered fp16 engine (explicit
+        LayerNorm, one-workgroup attention: the reference's own rounding points) -- max error within 1.5x, mean within 1.25x;
+      * its top-1 agrees with fp32 at least as often as the reference-ordered engine's does (-1 %), and on >= 95 % of the
+        positions outright (random-init logits are Gaussian, so ~3 % of the fp32 decisions are near-ties at fp16 noise;
+        the agreement rate is invariant to the scale of the fp32 logits head)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from jukebox_amd.engine import PriorEngine
+    W, depth, bins, seq, N, t0, n_steps = 1920, 72, 2048, 8192, 16, 4032, 160
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    sd = _random_prior_state(gen, W, depth, bins, seq, 1, True)
+    out_ch = torch.tensor([7, 300, 911, 1500, 1919], device="cuda")
+    sd["pos_emb.pos_emb"][:, out_ch] += torch.tensor([2.5, -3.0, 1.5, 4.0, -2.0], device="cuda")       # residual-stream outliers
+    for d in range(depth):
+        for ln in ("ln_0", "ln_1"):
+            sd[f"transformer._attn_mods.{d}.{ln}.weight"][out_ch[:3]] *= 6.0                              # gain outliers
+    x_cond = torch.randn(N, seq, W, device="cuda", generator=gen) * 0.05
+    yc = torch.randn(N, 1, W, device="cuda", generator=gen) * 0.05
+    prefix = torch.randint(0, bins, (N, t0), device="cuda", generator=gen)
+
+    def make(fp16, fold_ln, split):
+        monkeypatch.setenv("JB_ATTN_SPLIT_OFF", "0" if split else "1")
+        e = PriorEngine(sd, "", n_batch=N, seq_len=seq, bins=bins, width=W, depth=depth, heads=1, attn_order=2, blocks=128,
+                        y_cond=True, fp16=fp16, fold_ln=fold_ln, want_preds=True, chunk_cap=512)
+        e.set_cond(x_cond, yc)
+        e.set_sampling(temp=1.0, top_k=1)
+        e.tokens[:, :t0] = prefix
+        e.prefill(0, t0)
+        return e
+
+    e32 = make(False, False, False)
+    e32.decode(t0, n_steps)
+    torch.cuda.synchronize()
+    z32 = e32.tokens[:, :t0 + n_steps].clone()
+    p32 = e32.preds[:, t0:t0 + n_steps].cpu().numpy()
+    e32.close()
+    del e32
+    stats = {}
+    for name, fold_ln, split in (("production", True, True), ("reference-ordered", False, False)):
+        e16 = make(True, fold_ln, split)
+        assert e16.fold_ln == fold_ln and (e16.att_parts is not None) == split
+        for i in range(n_steps):                   # teacher-forced: the fp16 engine always sees the fp32 stream's tokens
+            e16.tokens[:, :t0 + i] = z32[:, :t0 + i]
+            e16.decode(t0 + i, 1)
+        torch.cuda.synchronize()
+        p16 = e16.preds[:, t0:t0 + n_steps].cpu().numpy()
+        err = np.abs(p16 - p32)
+        stats[name] = (float(err.max()), float(err.mean()), float((p16.argmax(-1) == p32.argmax(-1)).mean()))
+        e16.close()
+        del e16
+    print("fp16 vs fp32 (max |dlogit|, mean |dlogit|, top-1 agreement), logit std %.3f:" % p32.std(), stats)
+    (mx_p, mean_p, agree_p), (mx_r, mean_r, agree_r) = stats["production"], stats["reference-ordered"]
+    assert mx_p <= 1.5 * mx_r + 1e-3 and mean_p <= 1.25 * mean_r + 1e-4, stats
+    assert agree_p >= agree_r - 0.01 and agree_p >= 0.95, stats

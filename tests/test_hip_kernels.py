@@ -272,14 +272,15 @@ def test_gemv_qkv_append(H, name, dt, tol):
                                        (torch.float32, torch.float16)])
 def test_layernorm(H, din, dout):
     rng = np.random.default_rng(3)
-    x = (rng.standard_normal((37, 200)) * 3 + 1).astype(np.float32)
-    if din == torch.float16:
-        x = h16(x)
-    g = (1 + 0.1 * rng.standard_normal(200)).astype(np.float32)
-    b = (0.1 * rng.standard_normal(200)).astype(np.float32)
-    got = H.layernorm(dev(x, din), dev(g), dev(b), out_dtype=dout).float().cpu().numpy()
-    want = O.layer_norm(x, g, b)
-    assert relerr(got, want) < (2e-3 if dout == torch.float16 else 1e-5)
+    for rows, W in ((37, 200), (130, 1920), (5, 4096), (9, 203), (3, 4104)):     # vector path (W % 8 == 0, <= 4096) and scalar path
+        x = (rng.standard_normal((rows, W)) * 3 + 1).astype(np.float32)
+        if din == torch.float16:
+            x = h16(x)
+        g = (1 + 0.1 * rng.standard_normal(W)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(W)).astype(np.float32)
+        got = H.layernorm(dev(x, din), dev(g), dev(b), out_dtype=dout).float().cpu().numpy()
+        want = O.layer_norm(x, g, b)
+        assert relerr(got, want) < (2e-3 if dout == torch.float16 else 1e-5), (rows, W)
 
 
 def _np_attention(func, q, K, V, H_, bc, prime_r, qpos, fp16):
@@ -323,26 +324,127 @@ def test_attn_decode(H, name, dt, tol, func, H_, d):
         assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (func, t)
 
 
-@pytest.mark.parametrize("parts", [1, 0])
 @pytest.mark.parametrize("func", [1, 2, 3])
-def test_attn_decode_upsampler_shape(H, func, parts):
-    """fp16 MFMA decode attention at the upsamplers' head size (1 head of 480) and block length 128, with the
-    channel-split launch (4 workgroups of 120 channels per sample) and without."""
-    from jukebox_amd import _lib as L
+def test_attn_decode_upsampler_shape(H, func):
+    """fp16 MFMA decode attention at the upsamplers' head size (1 head of 480) and block length 128 (one workgroup per
+    sample)."""
     rng = np.random.default_rng(func)
     N, T, bc, d = 2, 512, 128, 480
     K, V = h16(rng.standard_normal((N, T, d)).astype(np.float32)), h16(rng.standard_normal((N, T, d)).astype(np.float32))
     kc, vc = dev(K, torch.float16), dev(V, torch.float16)
-    L.lib().jb_tune_attn_decode_parts(parts)
+    for t in (0, 1, 127, 128, 130, 300, 511):
+        q = h16(rng.standard_normal((N, 1, d)).astype(np.float32))
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        got = H.attn_decode(func, dev(q[:, 0], torch.float16), kc, vc, 1, bc, t_dev, T).float().cpu().numpy()
+        want = _np_attention(func, q, K, V, 1, bc, None, [t], True)[:, 0]
+        assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max()), (func, t)
+
+
+def _merge_parts(parts, ml):
+    """numpy restatement of the log-sum-exp merge gemv_merge_kernel performs on jb_attn_decode_split's output."""
+    N, P, S = parts.shape
+    Hn = ml.shape[1]
+    d = S // Hn
+    out = np.zeros((N, S), np.float32)
+    for n in range(N):
+        for h in range(Hn):
+            m, l = ml[n, h, :, 0], ml[n, h, :, 1]
+            if not (l > 0).any():
+                continue
+            w = np.where(l > 0, l * np.exp(m - m[l > 0].max()), 0.0)
+            out[n, h * d:(h + 1) * d] = (w[:, None] * parts[n, :, h * d:(h + 1) * d]).sum(0) / w.sum()
+    return out
+
+
+@pytest.mark.parametrize("func", [0, 1, 2, 3, 7])
+@pytest.mark.parametrize("H_,d,bc,T,n_parts", [(1, 480, 128, 1024, 4), (2, 256, 96, 960, 3), (2, 64, 8, 96, 2), (1, 32, 8, 96, 1),
+                                               (1, 480, 128, 8192, 4)])
+def test_attn_decode_split_and_merge(H, func, H_, d, bc, T, n_parts):
+    """Key-split decode attention (jb_attn_decode_split) + the merging attn.c_proj (jb_gemv with x_parts): the merged
+    partial states equal the one-workgroup attention, and the projection fed by them equals the projection of that
+    attention output -- at the released head sizes (1 x 480 upsamplers, 2 x 256 top prior), at block rows 0 and 63 of
+    the transpose pattern (T = 8192, bc = 128), for empty splits (early positions, prev_block in block 0)."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(func * 100 + d + T)
+    N, S = 5, H_ * d
+    prime_r = 448 if T >= 960 else 24
+    cap = prime_r if func == 7 else T
+    f16 = torch.float16
+    K = h16(rng.standard_normal((N, cap, S)).astype(np.float32))
+    V = h16(rng.standard_normal((N, cap, S)).astype(np.float32))
+    kc, vc = dev(K, f16), dev(V, f16)
+    W = h16((rng.standard_normal((S, 208)) / np.sqrt(S)).astype(np.float32))
+    b = (0.1 * rng.standard_normal(208)).astype(np.float32)
+    res = h16(rng.standard_normal((N, 208)).astype(np.float32))
+    pw = H.pack_conv1d_w(dev(W), f16)
+    max_keys = {0: T, 1: bc, 2: (T + bc - 1) // bc, 3: bc, 7: cap}[func]
+    assert L.lib().jb_attn_decode_split_parts(L.F16, d, max_keys) >= 1
+    ts = sorted({0, 1, bc - 1, bc, bc + 1, 2 * bc + 3, T // 2 + 5, T - bc - 1, T - 1})
+    for t in ts:
+        q = h16(rng.standard_normal((N, 1, S)).astype(np.float32))
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        parts, ml = H.attn_decode_split(func, dev(q[:, 0], f16), kc, vc, H_, bc, t_dev, max_keys, n_parts)
+        want = _np_attention(func, q, K, V, H_, bc, prime_r if func == 7 else None, [t], True)[:, 0]
+        merged = _merge_parts(parts.float().cpu().numpy(), ml.cpu().numpy())
+        assert np.isfinite(merged).all()
+        assert np.abs(merged - want).max() < 5e-3 * max(1.0, np.abs(want).max()), (func, t)
+        one = H.attn_decode(func, dev(q[:, 0], f16), kc, vc, H_, bc, t_dev, T)
+        assert np.abs(merged - one.float().cpu().numpy()).max() < 3e-3 * max(1.0, np.abs(want).max()), (func, t)
+        got = H.gemv(None, pw, bias=dev(b), res=dev(res, f16), parts=(parts, ml)).float().cpu().numpy()
+        ref = H.gemv(dev(h16(merged), f16), pw, bias=dev(b), res=dev(res, f16)).float().cpu().numpy()
+        want_p = h16(res + h16(h16(merged) @ W + h16(b)))
+        assert np.abs(got - want_p).max() < 6e-3 * max(1.0, np.abs(want_p).max()), (func, t)
+        assert np.abs(got - ref).max() < 4e-3 * max(1.0, np.abs(want_p).max()), (func, t)
+
+
+@pytest.mark.parametrize("name,dt,tol", DT)
+def test_gemv_second_output(H, name, dt, tol):
+    """jb_gemv out2 / add2: the fp32 copy `float(out) + cond[:, t]` the last mlp.c_proj of the decode step hands to the
+    logits head (autoregressive.py:226-227)."""
+    rng = np.random.default_rng(5)
+    N, K, J, T = 16, 256, 192, 12
+    fp16 = dt == torch.float16
+    r = (lambda x: h16(x)) if fp16 else (lambda x: x)
+    x, W = r(rng.standard_normal((N, K)).astype(np.float32)), r((rng.standard_normal((K, J)) / 16).astype(np.float32))
+    b, res = (0.1 * rng.standard_normal(J)).astype(np.float32), r(rng.standard_normal((N, J)).astype(np.float32))
+    cond = rng.standard_normal((N, T, J)).astype(np.float32)
+    pw = H.pack_conv1d_w(dev(W), dt)
+    want = r(res + r(x @ W + r(b)))
+    for t, add in ((0, True), (7, True), (11, False)):
+        out2 = torch.zeros((N, J), dtype=torch.float32, device="cuda")
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        got = H.gemv(dev(x, dt), pw, bias=dev(b), res=dev(res, dt), out2=out2, add2=dev(cond) if add else None, t_dev=t_dev)
+        g = got.float().cpu().numpy()
+        assert relerr(g, want) < tol
+        want2 = g + (cond[:, t] if add else 0)
+        assert np.abs(out2.cpu().numpy() - want2).max() < 1e-6 * max(1.0, np.abs(want2).max())
+
+
+@pytest.mark.parametrize("v2", [1, 0])
+@pytest.mark.parametrize("func", [0, 1, 3, 7])
+@pytest.mark.parametrize("H_,d,bc", [(1, 480, 128), (2, 64, 8), (1, 120, 8)])
+def test_attn_prefill_v2(H, func, H_, d, bc, v2):
+    """fp16 prefill attention: the default 4-wave kernel sharing vector-staged K/V tiles (jb_tune_attn_prefill_v2(1)) and
+    the one-wave kernel, against fp32 math on the half operands."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(func * 10 + d + 1)
+    N, prime_r = 2, 24
+    T = 520 if bc == 128 else 120
+    S = H_ * d
+    cap = prime_r if func == 7 else T
+    K = h16(rng.standard_normal((N, cap, S)).astype(np.float32))
+    V = h16(rng.standard_normal((N, cap, S)).astype(np.float32))
+    kc, vc = dev(K, torch.float16), dev(V, torch.float16)
+    spans = ((0, 40), (0, 1), (5, 7), (13, 50), (64, 56), (37, 83)) if bc == 8 else ((0, 512), (100, 300), (384, 136), (7, 65))
+    L.lib().jb_tune_attn_prefill_v2(v2)
     try:
-        for t in (0, 1, 127, 128, 130, 300, 511):
-            q = h16(rng.standard_normal((N, 1, d)).astype(np.float32))
-            t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
-            got = H.attn_decode(func, dev(q[:, 0], torch.float16), kc, vc, 1, bc, t_dev, T).float().cpu().numpy()
-            want = _np_attention(func, q, K, V, 1, bc, None, [t], True)[:, 0]
-            assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max()), (func, t)
+        for t0, nq in spans:
+            q = h16(rng.standard_normal((N, nq, S)).astype(np.float32))
+            got = H.attn_prefill(func, dev(q, torch.float16), kc, vc, H_, bc, t0).float().cpu().numpy()
+            want = _np_attention(func, q, K, V, H_, bc, prime_r, list(range(t0, t0 + nq)), False)
+            assert np.abs(got - want).max() < 6e-3 * max(1.0, np.abs(want).max()), (func, t0, nq)
     finally:
-        L.lib().jb_tune_attn_decode_parts(0)
+        L.lib().jb_tune_attn_prefill_v2(1)
 
 
 @pytest.mark.parametrize("name,dt,tol", [("f32", torch.float32, 2e-5), ("f16", torch.float16, 6e-3)])
@@ -381,18 +483,26 @@ def test_sampler(H):
     got = tokens[:, 2].cpu().numpy()
     assert np.array_equal(got, logits.argmax(1)) and got[0] == 3
     assert np.array_equal(preds[:, 2].cpu().numpy(), logits)
-    # top-k support
-    for seed in range(5):
-        H.sample_logits(ld, H.make_sample_params(temp=1.0, top_k=5, seed=seed), tokens, t_dev)
-        got = tokens[:, 2].cpu().numpy()
-        kth = np.sort(logits, 1)[:, -5]
-        assert np.all(logits[np.arange(N), got] >= kth)
-    # nucleus support
-    for seed in range(5):
-        H.sample_logits(ld, H.make_sample_params(temp=1.0, top_p=0.6, seed=seed), tokens, t_dev)
-        got = tokens[:, 2].cpu().numpy()
-        filt = O.filter_logits(logits, top_p=0.6)
-        assert np.all(np.isfinite(filt[np.arange(N), got]))
+    # top-k / nucleus: the set of tokens that can be drawn EQUALS the kept set of filter_logits (ops.py:113-142).  Rows are
+    # built so that every kept entry has probability >= ~4 %: over 64 rows x 40 seeds x 8 positions a kept entry that never
+    # shows up, or a dropped one that does, fails the test.
+    K2 = 24
+    base = rng.standard_normal((N, K2)).astype(np.float32) * 0.3
+    base[:, 8:] -= 6.0                                          # a clear tail
+    l2 = dev(base)
+    tok2 = torch.zeros((N, T), dtype=torch.int64, device="cuda")
+    for kw in (dict(top_k=5), dict(top_k=8), dict(top_p=0.6), dict(top_p=0.9)):
+        seen = np.zeros((N, K2), bool)
+        for seed in range(40):
+            for t in range(T):
+                t_dev.fill_(t)
+                H.sample_logits(l2, H.make_sample_params(temp=1.0, seed=seed, **kw), tok2, t_dev)
+            g = tok2.cpu().numpy()
+            for t in range(T):
+                seen[np.arange(N), g[:, t]] = True
+        kept = np.isfinite(O.filter_logits(base, **kw))
+        assert np.array_equal(seen, kept), kw
+    t_dev.fill_(2)
     # categorical frequencies: identical rows, different sample ids -> softmax(logits / temp)
     row = rng.standard_normal(16).astype(np.float32)
     ld2 = dev(np.tile(row, (64, 1)))
@@ -404,6 +514,74 @@ def test_sampler(H):
     n = counts.sum()
     z = (counts - n * p) / np.sqrt(n * p * (1 - p) + 1e-9)
     assert np.abs(z).max() < 5.0, z
+    # the production vocabulary sizes take the same kernel (2048 upsamplers, 2127 = 2048 + 79 top prior: n2 = 4096)
+    for bins2 in (2048, 2127):
+        lg = rng.standard_normal((16, bins2)).astype(np.float32) * 3
+        tk = torch.zeros((16, T), dtype=torch.int64, device="cuda")
+        H.sample_logits(dev(lg), H.make_sample_params(temp=1.0, top_k=1), tk, t_dev)
+        assert np.array_equal(tk[:, 2].cpu().numpy(), lg.argmax(1))
+        H.sample_logits(dev(lg), H.make_sample_params(temp=0.99, seed=3), tk, t_dev)
+        g = tk[:, 2].cpu().numpy()
+        assert ((0 <= g) & (g < bins2)).all() and (lg[np.arange(16), g] > lg.max(1) - 12).all()
+
+
+def test_sampler_streams(H):
+    """The uniform behind a draw is keyed by (seed, stream_id = level, global sample index, absolute position = pos_base + t):
+    windows, levels, samples and seeds never share it, and the same key always gives the same token (sharded or
+    re-windowed runs reproduce).  Identical flat rows make the token a monotone function of the uniform."""
+    N, bins, T = 32, 1024, 16
+    ld = torch.zeros((N, bins), dtype=torch.float32, device="cuda")
+
+    def draw(t, **kw):
+        tok = torch.zeros((N, T), dtype=torch.int64, device="cuda")
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        H.sample_logits(ld, H.make_sample_params(temp=1.0, **kw), tok, t_dev)
+        return tok[:, t].cpu().numpy()
+
+    a = draw(3, seed=7, sample_base=0, pos_base=0, stream_id=0)
+    assert np.array_equal(a, draw(3, seed=7, sample_base=0, pos_base=0, stream_id=0))
+    assert len(set(a.tolist())) > N // 2                                       # samples differ
+    for other in (dict(seed=8), dict(stream_id=1), dict(pos_base=4096), dict(sample_base=N)):
+        kw = dict(seed=7, sample_base=0, pos_base=0, stream_id=0)
+        kw.update(other)
+        assert (draw(3, **kw) != a).mean() > 0.9, other
+    # absolute position: window start 4096 + position 3 == window start 4000 + position 99 ... (same key, same draw)
+    assert np.array_equal(draw(3, seed=7, pos_base=4096), draw(9, seed=7, pos_base=4090))
+    # global sample index: rows 8.. of a run with sample_base 0 == rows 0.. of the shard that starts at 8
+    assert np.array_equal(a[8:], draw(3, seed=7, sample_base=8)[:N - 8])
+
+
+def test_sample_step_tail(H):
+    """jb_sample_step: token, embedding of the next position written by the drawing workgroup, counter advanced once."""
+    import ctypes as C
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(2)
+    N, bins, W, T = 16, 200, 64, 10
+    logits = rng.standard_normal((N, bins)).astype(np.float32) * 3
+    x_emb = rng.standard_normal((bins, W)).astype(np.float32)
+    pos = rng.standard_normal((T, W)).astype(np.float32)
+    cond = rng.standard_normal((N, T, W)).astype(np.float32)
+    ld, xe, pe, cd = dev(logits), dev(x_emb), dev(pos), dev(cond)
+    params = H.make_sample_params(temp=1.0, top_k=1)
+    for dt in (torch.float16, torch.float32):
+        for t in (0, 4, T - 1):
+            tokens = torch.zeros((N, T), dtype=torch.int64, device="cuda")
+            t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+            ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+            x_next = torch.full((N, W), 7.0, dtype=dt, device="cuda")
+            L.check(L.lib().jb_sample_step(ld.data_ptr(), N, bins, params.data_ptr(), tokens.data_ptr(), tokens.stride(0),
+                                           t_dev.data_ptr(), None, 0, L.dtype_code(dt), x_next.data_ptr(), xe.data_ptr(),
+                                           pe.data_ptr(), cd.data_ptr(), cond.shape[1] * W, W, W, T, ticket.data_ptr(), L.stream()))
+            torch.cuda.synchronize()
+            tok = tokens[:, t].cpu().numpy()
+            assert np.array_equal(tok, logits.argmax(1))
+            assert int(t_dev.item()) == t + 1 and int(ticket.item()) == 0
+            if t + 1 < T:
+                want = x_emb[tok] + pos[t + 1] + cond[:, t + 1]
+                got = x_next.float().cpu().numpy()
+                assert np.abs(got - want).max() < (4e-3 if dt == torch.float16 else 1e-6) * max(1.0, np.abs(want).max())
+            else:
+                assert (x_next == 7.0).all()
 
 
 def test_vq(H):

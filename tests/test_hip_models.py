@@ -256,8 +256,6 @@ def test_top_prior_fp16_against_reference_fp16(models):
     assert (got == want).mean() > 0.85, (got == want).mean()
 
 
-@pytest.mark.skipif(__import__("os").environ.get("JB_EXPERIMENTAL") != "1",
-                    reason="written after the round's GPU budget was spent: enable with JB_EXPERIMENTAL=1, then drop the gate")
 def test_teacher_forced_losses(models, tiny_hps):
     """SimplePrior.z_forward (prior.py:312-347) on the HIP prefill path: loss, bits per token of the lyric and music parts
     and the logits of a given code sequence against the reference (tests/golden/forward.npz), fp32."""

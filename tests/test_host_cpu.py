@@ -232,3 +232,31 @@ def test_restore_model_reads_reference_checkpoints(tiny_hps, tmp_path, monkeypat
     cache.mkdir(parents=True)
     torch.save(dict(model=want, step=7), cache / "prior_level_2.pth.tar")
     assert make_prior(h, vq, "cpu").step == 7
+
+
+def test_names_without_id_tables_raise(monkeypatch):
+    """Mapping an artist / genre NAME needs the reference's id tables; without them the labeller raises instead of
+    conditioning every sample on id 0 (artist_genre_processor.py:27-60 always loads them).  Ids still work."""
+    from jukebox_amd.data.labels import ArtistGenreProcessor, Labeller
+    monkeypatch.delenv("JUKEBOX_IDS_DIR", raising=False)
+    here_ids = os.path.join(ROOT, "jukebox_amd", "data", "ids")
+    if os.path.isdir(here_ids):
+        pytest.skip("id tables are installed next to labels.py")
+    lab = Labeller(5, 0, 1048576, v3=False)
+    with pytest.raises(RuntimeError, match="JUKEBOX_IDS_DIR"):
+        lab.get_label("Alan Jackson", "Country", "", 180 * 44100, 0)
+    with pytest.raises(RuntimeError, match="id tables"):
+        ArtistGenreProcessor(v3=True).get_genre_ids("jazz")
+    y = lab.get_batch_labels_from_ids([dict(artist_id=7, genre_ids=[3], full_tokens=[], total_length=180 * 44100, offset=0)])
+    assert y["y"].shape == (1, 9) and int(y["y"][0, 3]) == 7
+
+
+def test_unknown_names_warn_like_the_reference(monkeypatch, capsys):
+    ids = os.environ.get("JUKEBOX_IDS_DIR") or "/root/reference/jukebox/data/ids"
+    if not os.path.isdir(ids):
+        pytest.skip("artist / genre id tables not available (set JUKEBOX_IDS_DIR)")
+    from jukebox_amd.data.labels import ArtistGenreProcessor
+    ag = ArtistGenreProcessor(v3=False, ids_dir=ids)
+    assert ag.get_artist_id("no such artist anywhere 123") == 0
+    assert "Defaulting to (artist_id, artist) = (0, unknown)" in capsys.readouterr().out
+    assert ag.get_artist_id("Alan Jackson") > 0 and capsys.readouterr().out == ""

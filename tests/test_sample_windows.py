@@ -33,6 +33,7 @@ class DummyPrior:
         self.x_cond = level != levels - 1
         self.n_tokens = 0
         self.calls = []
+        self.kwargs_seen = []
         self.after_publish = None
 
     def to(self, device):
@@ -71,6 +72,7 @@ class DummyPrior:
         assert t.equal(ids, t.arange(int(ids[0]), int(ids[0]) + n_samples))
         assert int(ids[0]) >= sample_base
         self.calls.append((start, z.shape[1], n_tok))
+        self.kwargs_seen.append(dict(kw, sample_base=sample_base))
         LOG.append((self.level, start))
         tap = getattr(self, "window_tap", None)
         if tap is not None:                      # the level pipeline's partial-window publication (SimplePrior._decode_tap)
@@ -288,3 +290,25 @@ def test_command_line_arguments_parse_like_fire():
                       mode="primed", audio_file="a.wav,b.wav", prompt_length_in_seconds=12.5)
     with pytest.raises(AssertionError):
         S._argv_kwargs(["model=1b_lyrics"])
+
+
+def test_seed_and_absolute_positions_reach_the_sampler():
+    """hps.seed is handed to every prior.sample call together with the window's start (pos_base) and the sub-batch's
+    global sample offset (sample_base): the draw of (level, sample, absolute position) does not depend on the window
+    schedule or the batch split.  Without hps.seed a fresh seed is drawn once per job (all levels share it)."""
+    priors, hps, labels, sk = make_setup(n_samples=5, top_tokens=8192 + 1024)
+    hps.seed = 1234
+    S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
+    for level, p in enumerate(priors):
+        assert p.kwargs_seen and all(k["seed"] == 1234 for k in p.kwargs_seen)
+        starts = [c[0] for c in p.calls]
+        assert [k["pos_base"] for k in p.kwargs_seen] == starts
+        bs = sk[level]["max_batch_size"]
+        assert sorted({k["sample_base"] for k in p.kwargs_seen}) == list(range(0, 5, bs))
+    priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=8192)
+    S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
+    seeds = {k["seed"] for p in priors for k in p.kwargs_seen}
+    assert len(seeds) == 1 and isinstance(next(iter(seeds)), int)
+    priors2, hps2, labels2, sk2 = make_setup(n_samples=2, top_tokens=8192)
+    S.ancestral_sample(labels2, sk2, priors2, hps2, save=False, device="cpu")
+    assert {k["seed"] for p in priors2 for k in p.kwargs_seen} != seeds          # unseeded jobs differ, like the reference

@@ -85,7 +85,7 @@ def main():
         eng.decode(a.t0, a.steps, use_graph=use_graph)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / a.steps
-        b = step_bytes(cfg, a.batch, a.t0 + a.steps // 2, 4 if a.fp32 else 2)
+        b = eng.step_bytes(a.t0 + a.steps // 2)
         print(f"  graph={use_graph}: {dt * 1e3:.3f} ms/step  algorithmic {b / 1e9:.3f} GB/step -> {b / dt / 1e12:.2f} TB/s "
               f"({b / dt / 8e12 * 100:.1f}% of 8 TB/s)")
 
