@@ -274,13 +274,16 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
                 if alignments is None and top is not None and top.n_tokens > 0 and \
                         not isinstance(top.labeller, EmptyLabeller) and getattr(top, "alignment_layer", None) is not None \
                         and len(zs[-1][0]) > 0:
-                    # sample.py:118-120 + align.py:85-97 (the HTML viewer itself is not reproduced)
+                    # sample.py:118-120 + align.py:85-97
                     from .align import get_alignment
                     ahps = Hyperparams(levels=len(priors), hop_fraction=hps.hop_fraction)
                     alignments = get_alignment(x, zs, labels[-1], top, sampling_kwargs[-1]["fp16"], ahps, device=device)
                     if not hps.get("keep_priors_resident", False):
                         top.cpu()
                     t.save(dict(alignments=alignments), f"{logdir}/data_align.pth.tar")
+                if "info" in labels[-1] and all("lyrics" in i for i in labels[-1]["info"]):
+                    from .save_html import save_html                      # sample.py:120
+                    save_html(logdir, x, zs, labels[-1], alignments, Hyperparams(levels=len(priors), sr=hps.sr))
     _sample.last_audio = xs
     return zs
 

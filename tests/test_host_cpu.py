@@ -260,3 +260,39 @@ def test_unknown_names_warn_like_the_reference(monkeypatch, capsys):
     assert ag.get_artist_id("no such artist anywhere 123") == 0
     assert "Defaulting to (artist_id, artist) = (0, unknown)" in capsys.readouterr().out
     assert ag.get_artist_id("Alan Jackson") > 0 and capsys.readouterr().out == ""
+
+
+def test_save_html_matches_reference_outputs(tmp_path):
+    """The HTML viewer (f1): files, lyric characters, alignment table, alignment picture and audio equal what the reference's
+    save_html wrote for the same batch (tests/golden/save_html.npz, made by tests/golden/gen_save_html_golden.py)."""
+    import hashlib
+    import json
+    from PIL import Image
+    from scipy.io import wavfile
+    from jukebox_amd.save_html import save_html
+    g = load_golden("save_html")
+    bs, total_length, sr = 2, int(g["total_length"]), int(g["sr"])
+    lyr = [bytes(g[f"lyrics{i}"]).decode() for i in range(bs)]
+    info = [dict(artist=f"artist {i}", genre=f"genre {i}", lyrics=lyr[i], full_tokens=list(range(len(lyr[i])))) for i in range(bs)]
+    zs = [torch.zeros(bs, total_length * 16, dtype=torch.long), torch.zeros(bs, total_length * 4, dtype=torch.long),
+          torch.zeros(bs, total_length, dtype=torch.long)]
+    d = str(tmp_path)
+    save_html(d, torch.from_numpy(g["x"]), zs, dict(info=info), [g[f"align{i}"] for i in range(bs)], Hyperparams(levels=3, sr=sr))
+    top = open(f"{d}/index.html").read()
+    assert top.count("<iframe") == int(g["index_iframes"]) == bs and "src='item_1/index.html'" in top
+    for i in range(bs):
+        assert open(f"{d}/item_{i}/lyrics.json", "rb").read() == bytes(g[f"shown{i}"])
+        assert np.array_equal(np.asarray(json.load(open(f"{d}/item_{i}/align.json")), np.uint8), g[f"align_json{i}"])
+        png = np.asarray(Image.open(f"{d}/item_{i}/align.png"))
+        assert np.array_equal(png[::16, ::16], g[f"align_png_sub{i}"])
+        assert hashlib.sha256(png.tobytes()).digest() == bytes(g[f"align_png_sha{i}"])
+        rate, wav = wavfile.read(f"{d}/item_{i}/audio.wav")
+        assert rate == sr and np.array_equal(wav, g[f"wav{i}"])
+        page = open(f"{d}/item_{i}/index.html").read()
+        n_chars = len(json.load(open(f"{d}/item_{i}/lyrics.json")))
+        assert page.count("<span id=") == n_chars and f"Artist artist {i}, Genre genre {i}" in page
+        assert "<audio id='audio.wav'" in page and "align.json" in page and f"<span id='{i}/0'></span>" in page
+    # no alignment: no picture, no table, no script -- the page still lists audio and lyrics
+    d2 = str(tmp_path / "plain")
+    save_html(d2, torch.from_numpy(g["x"]), zs, dict(info=info), None, Hyperparams(levels=3, sr=sr))
+    assert not os.path.exists(f"{d2}/item_0/align.png") and "<script>" not in open(f"{d2}/item_0/index.html").read()
