@@ -35,6 +35,15 @@ int jb_version(void);
 int jb_stream_priority_range(int* least /* host */, int* greatest /* host */);
 int jb_stream_create(int priority, void** stream /* host, out */);
 int jb_stream_destroy(void* stream);
+/* A stream restricted to the compute units whose bit is set in cu_mask (host array of n_words x 32 bits): keeps
+ * throughput work (another level's decode chain, a look-ahead prefill) off the CUs the latency-bound chain needs.
+ * jb_cu_census (diagnostic) launches n_blocks 64-thread workgroups and reports out[2b] = XCC id, out[2b+1] = HW_ID
+ * register of block b (device array of 2*n_blocks words) -- the mask-bit -> CU mapping is not documented. */
+int jb_stream_create_cu_mask(const uint32_t* cu_mask /* host */, int n_words, void** stream /* host, out */);
+int jb_cu_census(int n_blocks, uint32_t* out, void* stream);
+/* Diagnostic: out[0] = shader-clock cycles, out[1] = 100-MHz ticks elapsed over a spin of spin_ticks ticks on `stream`
+ * (device array of 2 int64): the clock the latency-bound decode chain really runs at. */
+int jb_clock_probe(long long* out, int spin_ticks, void* stream);
 
 /* Bytes of the MFMA-fragment-ordered weight image for a K x J matrix of `dtype`
  * (K padded to 32 (f16) / 16 (f32), J padded to 16). */
@@ -146,10 +155,14 @@ void jb_tune_attn_decode(int threads, int kb);
 int jb_attn_decode_split(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache, int cache_cap,
                          void* parts, float* ml, int n_batch, int n_head, int d_head, int block_ctx, const int* t_dev,
                          int max_keys, int n_parts, void* stream);
-/* Recommended n_parts (1..4) for a layer, 0 when the shape is outside the split kernel's envelope. */
+/* Recommended n_parts (1..4) for a layer; 0 = do not split: the shape is outside the split kernel's envelope, or the key
+ * set is short enough (default: <= 128 keys) for one pass of jb_attn_decode's 8-wave workgroup, where a split only adds
+ * the merge (measured: 2.11 vs 2.37 ms per upsampler step). */
 int jb_attn_decode_split_parts(int dtype, int d_head, int max_keys);
-/* Tuning hook: most splits per (sample, head) (1..4, default 4) and waves per split workgroup for short key sets (default 2). */
+/* Tuning hooks: most splits per (sample, head) (1..4, default 4), waves per split workgroup for short key sets (default 2);
+ * smallest max_keys that is split (default 129). */
 void jb_tune_attn_decode_split(int max_parts, int waves);
+void jb_tune_attn_decode_split_min_keys(int min_keys);
 
 /* Chunked-prefill attention (q_l > 1) on MFMA with LDS-staged k/v tiles and online softmax:
  * queries at positions t0 .. t0+n_q-1 against the caches (already holding those positions).

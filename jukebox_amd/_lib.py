@@ -68,6 +68,9 @@ _SIGS = {
     "jb_stream_priority_range": (i32, [C.POINTER(i32), C.POINTER(i32)]),
     "jb_stream_create": (i32, [i32, C.POINTER(vp)]),
     "jb_stream_destroy": (i32, [vp]),
+    "jb_stream_create_cu_mask": (i32, [vp, i32, C.POINTER(vp)]),
+    "jb_cu_census": (i32, [i32, vp, vp]),
+    "jb_clock_probe": (i32, [vp, i32, vp]),
     "jb_packed_weight_bytes": (i64, [i32, i32, i32]),
     "jb_pack_weight": (i32, [vp, i32, i64, i64, i32, i32, vp, i32, vp]),
     "jb_layernorm_fwd": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, f32, vp]),
@@ -79,6 +82,7 @@ _SIGS = {
     "jb_attn_decode_split": (i32, [i32, vp, i64, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "jb_attn_decode_split_parts": (i32, [i32, i32, i32]),
     "jb_tune_attn_decode_split": (None, [i32, i32]),
+    "jb_tune_attn_decode_split_min_keys": (None, [i32]),
     "jb_tune_gemm_lds": (None, [i32]),
     "jb_tune_attn_prefill_v2": (None, [i32]),
     "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -127,6 +131,8 @@ def lib():
         if env("JB_ATTN_SPLIT") is not None:          # "max_parts,waves"
             mp, wv = (int(v) for v in env("JB_ATTN_SPLIT").split(","))
             l.jb_tune_attn_decode_split(mp, wv)
+        if env("JB_ATTN_SPLIT_MIN_KEYS") is not None:
+            l.jb_tune_attn_decode_split_min_keys(int(env("JB_ATTN_SPLIT_MIN_KEYS")))
         if env("JB_PREFILL_V2") is not None:
             l.jb_tune_attn_prefill_v2(int(env("JB_PREFILL_V2")))
         if env("JB_GEMM_LDS_MIN_ROWS") is not None:
@@ -171,6 +177,18 @@ def priority_streams(classes, device=None):
         raw.append(h)
         streams.append(torch.cuda.ExternalStream(h.value, device=device))
     return streams, raw
+
+
+def cu_mask_stream(mask_bits, device=None):
+    """torch-visible raw HIP stream confined to the CUs whose index is in `mask_bits` (iterable of bit positions < 256).
+    Returns (stream, raw_handle); destroy with destroy_streams([raw_handle])."""
+    import torch
+    words = (C.c_uint32 * 8)()
+    for b in mask_bits:
+        words[b >> 5] |= 1 << (b & 31)
+    h = vp()
+    check(lib().jb_stream_create_cu_mask(words, 8, C.byref(h)))
+    return torch.cuda.ExternalStream(h.value, device=device), h
 
 
 def destroy_streams(raw):

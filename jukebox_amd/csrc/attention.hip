@@ -396,19 +396,24 @@ extern "C" void jb_tune_attn_decode(int threads, int kb) {
     if (kb > 0) g_dec_kb = kb;
     g_dec_mfma = kb >= 0;          // kb < 0 selects the generic (vector-ALU QK^T) kernel for every dtype
 }
-// key-split decode attention: most splits per (sample, head) and waves per split workgroup for short key sets
-static int g_split_max = 4, g_split_waves = 2;
+// key-split decode attention: most splits per (sample, head), waves per split workgroup for short key sets, and the
+// key-set size from which a layer is split at all.  Measured on MI355X (upsampler, N = 16, key sets of <= 128 keys):
+// 2.11 ms per step unsplit vs 2.37-2.41 ms split 2..4 ways -- up to 128 keys are ONE pass of the 8-wave kernel (a wave
+// per 16-key tile), so a split shortens nothing on the critical path and the merge in attn.c_proj costs ~1 us of VALU.
+// Long key sets (dense 6528 keys: 51 tile passes per wave; prime 448 keys: 4) are where the split pays.
+static int g_split_max = 4, g_split_waves = 2, g_split_min_keys = 129;
 extern "C" void jb_tune_attn_decode_split(int max_parts, int waves) {
     if (max_parts >= 1 && max_parts <= 4) g_split_max = max_parts;
     if (waves >= 1 && waves <= 8) g_split_waves = waves;
 }
+extern "C" void jb_tune_attn_decode_split_min_keys(int min_keys) { if (min_keys >= 1) g_split_min_keys = min_keys; }
 static inline bool split_d_ok(int d_head) {
     const int nd = d_head / 32;
     return d_head % 32 == 0 && (nd == 1 || nd == 2 || nd == 4 || nd == 8 || nd == 15 || nd == 16);
 }
 // Splits per (sample, head) for a layer whose key set never exceeds max_keys; 0 = shape not supported (use jb_attn_decode).
 extern "C" int jb_attn_decode_split_parts(int dtype, int d_head, int max_keys) {
-    if (dtype != JB_F16 || !split_d_ok(d_head) || max_keys < 1) return 0;
+    if (dtype != JB_F16 || !split_d_ok(d_head) || max_keys < g_split_min_keys) return 0;
     const int tiles = (max_keys + 15) / 16;
     int parts = (tiles + g_split_waves - 1) / g_split_waves;
     return parts < 1 ? 1 : (parts > g_split_max ? g_split_max : parts);

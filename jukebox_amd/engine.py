@@ -162,9 +162,11 @@ class PriorEngine:
                         c_mlp=e(N * Cc, M))
         # key-split decode attention (fp16 engines whose head size the split kernel takes): partial softmax states
         self.att_parts = self.att_ml = None
-        split_env = os.environ.get("JB_ATTN_SPLIT_OFF", "0") == "1"
-        if not self.only_encode and not split_env and N <= 32 and \
-                L.lib().jb_attn_decode_split_parts(self.code, S // self.H, max(self.block_ctx, 16)) > 0:
+        split_off = os.environ.get("JB_ATTN_SPLIT_OFF", "0") == "1"
+        bc = max(self.block_ctx, 1)
+        max_keys = lambda lay: {0: T, 1: bc, 2: (T + bc - 1) // bc, 3: bc}.get(lay["func"], lay["cap"])
+        if not self.only_encode and not split_off and N <= 32 and \
+                any(L.lib().jb_attn_decode_split_parts(self.code, S // self.H, max_keys(lay)) > 0 for lay in pk.layers):
             self.att_parts = e(N, 4, S)
             self.att_ml = e(N, self.H, 4, 2, dtype=torch.float32)
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)

@@ -230,7 +230,7 @@ def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
     the reference-ordered fp16 path.  Gate: on the upsampler geometry (width 1920, depth 72, block_ctx 64), N = 16, with
     OUTLIER channels in the residual stream and in the LayerNorm gains (what real checkpoints have and what stresses the
     sum-of-squares form of the folded variance), every engine teacher-forced on the fp32 engine's greedy stream:
-      * the production engine's logits are as close to fp32 as those of the reference-ordered fp16 engine (explicit
+      * the production engine's logits (and those of the engine with the key split forced on) are as close to fp32 as those of the reference-ordered fp16 engine (explicit
         LayerNorm, one-workgroup attention: the reference's own rounding points) -- max error within 1.5x, mean within 1.25x;
       * its top-1 agrees with fp32 at least as often as the reference-ordered engine's does (-1 %), and on >= 95 % of the
         positions outright (random-init logits are Gaussian, so ~3 % of the fp32 decisions are near-ties at fp16 noise;
@@ -250,8 +250,12 @@ def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
     yc = torch.randn(N, 1, W, device="cuda", generator=gen) * 0.05
     prefix = torch.randint(0, bins, (N, t0), device="cuda", generator=gen)
 
+    from jukebox_amd import _lib as L
+
     def make(fp16, fold_ln, split):
-        monkeypatch.setenv("JB_ATTN_SPLIT_OFF", "0" if split else "1")
+        # split: None = the default policy (this geometry's key sets are <= 128 keys: not split), True = force the key split
+        monkeypatch.setenv("JB_ATTN_SPLIT_OFF", "1" if split is False else "0")
+        L.lib().jb_tune_attn_decode_split_min_keys(1 if split else 129)
         e = PriorEngine(sd, "", n_batch=N, seq_len=seq, bins=bins, width=W, depth=depth, heads=1, attn_order=2, blocks=128,
                         y_cond=True, fp16=fp16, fold_ln=fold_ln, want_preds=True, chunk_cap=512)
         e.set_cond(x_cond, yc)
@@ -268,9 +272,9 @@ def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
     e32.close()
     del e32
     stats = {}
-    for name, fold_ln, split in (("production", True, True), ("reference-ordered", False, False)):
+    for name, fold_ln, split in (("production", True, None), ("key-split", True, True), ("reference-ordered", False, False)):
         e16 = make(True, fold_ln, split)
-        assert e16.fold_ln == fold_ln and (e16.att_parts is not None) == split
+        assert e16.fold_ln == fold_ln and (e16.att_parts is not None) == bool(split)
         for i in range(n_steps):                   # teacher-forced: the fp16 engine always sees the fp32 stream's tokens
             e16.tokens[:, :t0 + i] = z32[:, :t0 + i]
             e16.decode(t0 + i, 1)
@@ -281,6 +285,9 @@ def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
         e16.close()
         del e16
     print("fp16 vs fp32 (max |dlogit|, mean |dlogit|, top-1 agreement), logit std %.3f:" % p32.std(), stats)
-    (mx_p, mean_p, agree_p), (mx_r, mean_r, agree_r) = stats["production"], stats["reference-ordered"]
-    assert mx_p <= 1.5 * mx_r + 1e-3 and mean_p <= 1.25 * mean_r + 1e-4, stats
-    assert agree_p >= agree_r - 0.01 and agree_p >= 0.95, stats
+    L.lib().jb_tune_attn_decode_split_min_keys(129)
+    mx_r, mean_r, agree_r = stats["reference-ordered"]
+    for name in ("production", "key-split"):
+        mx_p, mean_p, agree_p = stats[name]
+        assert mx_p <= 1.5 * mx_r + 1e-3 and mean_p <= 1.25 * mean_r + 1e-4, (name, stats)
+        assert agree_p >= agree_r - 0.01 and agree_p >= 0.95, (name, stats)

@@ -378,7 +378,9 @@ def test_attn_decode_split_and_merge(H, func, H_, d, bc, T, n_parts):
     res = h16(rng.standard_normal((N, 208)).astype(np.float32))
     pw = H.pack_conv1d_w(dev(W), f16)
     max_keys = {0: T, 1: bc, 2: (T + bc - 1) // bc, 3: bc, 7: cap}[func]
-    assert L.lib().jb_attn_decode_split_parts(L.F16, d, max_keys) >= 1
+    # by default only key sets longer than one pass of the 8-wave kernel are split
+    assert (L.lib().jb_attn_decode_split_parts(L.F16, d, max_keys) >= 1) == (max_keys > 128)
+    assert L.lib().jb_attn_decode_split_parts(L.F16, d + 8, max_keys) == 0 and L.lib().jb_attn_decode_split_parts(L.F32, d, 4096) == 0
     ts = sorted({0, 1, bc - 1, bc, bc + 1, 2 * bc + 3, T // 2 + 5, T - bc - 1, T - 1})
     for t in ts:
         q = h16(rng.standard_normal((N, 1, S)).astype(np.float32))

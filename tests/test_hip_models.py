@@ -151,14 +151,18 @@ def test_pipelined_levels_equal_sequential(models):
     outs = []
     # pipeline_chunk: decode steps between two publications of a window's codes to the level below (0: whole windows);
     # 5 does not divide the windows, so a lower window starts in the middle of an upper one
-    for pipe, chunk in ((False, 0), (True, 0), (True, 5), (True, 256)):
+    for pipe, chunk, bs in ((False, 0, 3), (True, 0, 3), (True, 5, 3), (True, 256, 3), (False, 0, 2)):
         hps = Hyperparams(n_samples=n, sample_length=4608, hop_fraction=[0.5, 0.5, 0.125], sr=22050, name="unused",
-                          keep_priors_resident=True, pipeline_levels=pipe, pipeline_chunk=chunk)
-        zs = S.ancestral_sample(labels, sk, priors, hps, save=False)
+                          keep_priors_resident=True, pipeline_levels=pipe, pipeline_chunk=chunk, seed=5)
+        zs = S.ancestral_sample(labels, [dict(k, max_batch_size=bs) for k in sk], priors, hps, save=False)
         outs.append([z.cpu().numpy() for z in zs])
-    for other in outs[1:]:
+    for other in outs[1:]:            # the last run splits the batch 2 + 1: draws are keyed by the global sample index
         for a, b in zip(outs[0], other):
             assert np.array_equal(a, b)
+    # another seed gives another sample; no seed gives a fresh one per job (the reference's unseeded torch RNG)
+    hps.seed = 6
+    z6 = S.ancestral_sample(labels, sk, priors, hps, save=False)
+    assert not np.array_equal(z6[0].cpu().numpy(), outs[0][0])
 
 
 def test_alignment_matches_reference(models):
