@@ -8,6 +8,14 @@
 // gather (transpose).
 #include "common.h"
 
+// Keeps the compiler from sinking the memory requests written above this point below it (nothing waits here): the decode
+// kernels live on issuing every load of a phase back to back -- left alone, the scheduler parks the 16 value-row loads of
+// a tile behind the QK^T MFMA chain (a third dependent round trip after position and keys).
+__device__ __forceinline__ void jb_issue_fence() { asm volatile("" ::: "memory"); }
+// The same, and additionally everything that consumes `x` (e.g. the MFMA chain fed by a query fragment) stays below it:
+// register-only instructions are otherwise free to be hoisted above the requests the fence was meant to put first.
+template <typename V> __device__ __forceinline__ void jb_issue_fence_before_use(V& x) { asm volatile("" : "+v"(x) :: "memory"); }
+
 // key set of the single query at position t: positions start + i*stride, i < count
 struct KeySet { int start, stride, count; };
 
@@ -101,6 +109,7 @@ __global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ld
                 }
             }
         }
+        jb_issue_fence();
         float part[KB];
 #pragma unroll
         for (int b = 0; b < KB; ++b) {
@@ -173,6 +182,12 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     const int g = lane >> 4, c = lane & 15;
     const int n = blockIdx.x, h = blockIdx.y;
     const int S = n_head * d;
+    // the query does not depend on the position: request it before the position is waited for
+    const f16* qrow = q + (int64_t)n * ldq + h * d;
+    f16x8 qf[ND32];
+#pragma unroll
+    for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+    jb_issue_fence();
     const int t = *t_dev;
     const KeySet ks = decode_key_set(func, t, bc, cap);
     f16* o = out + (int64_t)n * ldo + h * d;
@@ -182,10 +197,6 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     }
     const float scale = 1.0f / sqrtf(sqrtf((float)d));
     const float scale2 = scale * scale;
-    const f16* qrow = q + (int64_t)n * ldq + h * d;
-    f16x8 qf[ND32];
-#pragma unroll
-    for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
     const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
     const f16* vbase = vc + ((int64_t)n * cap) * S + h * d;
     const int c0 = min(lane * 8, d - 8);     // this lane's value channels (lanes past d/8 compute unused duplicates)
@@ -211,6 +222,7 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
             const int vi = min(kbase_i + k, ks.count - 1);
             vv[k] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0);
         }
+        jb_issue_fence_before_use(qf[0]);        // K fragments AND value rows are in flight before the QK^T chain starts
         // ---- scores of keys g*4 + r (identical in all 16 columns) ----
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -293,6 +305,11 @@ __global__ __launch_bounds__(512) void attn_decode_split_kernel(int func, const 
     const int g = lane >> 4, c = lane & 15;
     const int n = blockIdx.x, h = blockIdx.y, split = blockIdx.z;
     const int S = n_head * d;
+    const f16* qrow = q + (int64_t)n * ldq + h * d;
+    f16x8 qf[ND32];
+#pragma unroll
+    for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+    jb_issue_fence();
     const int t = *t_dev;
     const KeySet ks = decode_key_set(func, t, bc, cap);
     f16* o = parts + ((int64_t)n * n_parts + split) * S + h * d;
@@ -305,10 +322,6 @@ __global__ __launch_bounds__(512) void attn_decode_split_kernel(int func, const 
     }
     const float scale = 1.0f / sqrtf(sqrtf((float)d));
     const float scale2 = scale * scale;
-    const f16* qrow = q + (int64_t)n * ldq + h * d;
-    f16x8 qf[ND32];
-#pragma unroll
-    for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
     const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
     const f16* vbase = vc + ((int64_t)n * cap) * S + h * d;
     const int c0 = min(lane * 8, d - 8);     // this lane's value channels (lanes past d/8 compute unused duplicates)
@@ -332,6 +345,7 @@ __global__ __launch_bounds__(512) void attn_decode_split_kernel(int func, const 
             const int vi = min(kbase_i + k, ks.count - 1);
             vv[k] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0);
         }
+        jb_issue_fence_before_use(qf[0]);        // K fragments AND value rows are in flight before the QK^T chain starts
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < ND32; ++dt) sc = jb_mfma(kf[dt], qf[dt], sc);

@@ -441,6 +441,43 @@ __device__ __forceinline__ float frag_sum(typename Frag<T>::vec v) {
 #define JB_STAMP(i) do { } while (0)
 #endif
 
+// Epilogue operands of one thread's output elements, requested UNCONDITIONALLY and early.  A load behind `ptr ? ptr[i] : 0`
+// compiles to a branch whose body ends in s_waitcnt vmcnt(0): every such operand becomes its own dependent memory round
+// trip in front of the MFMAs (and the compiler sinks an unguarded late-use load behind them: the ISA of round 1's kernels
+// had bias -> wait -> residual -> wait -> activations -> wait, three cold round trips where one suffices).  Absent
+// operands are read through a valid dummy address (the weight image) and discarded by a select; jb_issue_fence() keeps the
+// compiler from moving the requests below it (nothing waits there).
+__device__ __forceinline__ void jb_issue_fence() { asm volatile("" ::: "memory"); }
+
+template <typename T, int EPT, int NT>
+struct EpiOperands {
+    float bias[EPT], res[EPT], c1[EPT];
+    __device__ __forceinline__ void request(const GemvParams& p, int jt, int MT) {
+        const float* bias_p = p.epi.bias ? p.epi.bias : reinterpret_cast<const float*>(p.W);
+        const float* c1_p = p.ln_c1 ? p.ln_c1 : reinterpret_cast<const float*>(p.W);
+        const T* res_p = p.epi.res ? (const T*)p.epi.res : reinterpret_cast<const T*>(p.W);
+        const int64_t ldr = p.epi.res ? p.epi.ldr : 0;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int i = threadIdx.x + u * NT;
+            const int row = (i >> 8) * 16 + (i & 15), j = blockIdx.x * 16 + ((i & 63) >> 4) * 4 + ((i >> 6) & 3);
+            const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
+            bias[u] = bias_p[jc];
+            c1[u] = c1_p[jc];
+            res[u] = (float)res_p[(int64_t)rc * ldr + jc];
+        }
+        (void)jt; (void)MT;
+    }
+    __device__ __forceinline__ void finish(const GemvParams& p) {      // after the sums are ready: drop what was not there
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            bias[u] = p.epi.bias ? bias[u] : 0.f;
+            c1[u] = p.ln_c1 ? c1[u] : 0.f;
+            res[u] = p.epi.res ? res[u] : 0.f;
+        }
+    }
+};
+
 template <typename T, int MT, int NW, bool LNS, bool FAST, int NV>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     using V = typename Frag<T>::vec;
@@ -472,19 +509,29 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
         }
     }
     // Epilogue operands of THIS thread's output elements (the MT 16x16 tiles are spread over all threads: flat index
-    // i = (mt, r, l) is element r of fragment lane l of tile mt), requested now so they are long home when the sums
-    // are ready.
+    // i = (mt, r, l) is element r of fragment lane l of tile mt) and, on the plain fast path, the activation fragments of
+    // the first (usually only) batch: everything is in flight before anything is waited for.
     constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);      // elements per thread
+    EpiOperands<T, EPT, NW * 64> eo;
+    eo.request(p, jt, MT);
+    V xf0[(!LNS && FAST) ? WB : 1][MT];
+    if constexpr (!LNS && FAST) {
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+            const int k0 = min(kt0 + i, p.nkt - 1) * KT + g * E;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf0[i][mt] = ld_frag<T>(x + (int64_t)min(mt * 16 + c, p.n_rows - 1) * p.ldx + k0);
+        }
+    }
+    jb_issue_fence();
     int t = 0;
     if (p.epi.qkv_split || p.epi.add2) t = *p.t_dev;
-    float e_bias[EPT], e_res[EPT], e_add2[EPT];
+    float e_add2[EPT];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
         const int i = threadIdx.x + u * NW * 64;
         const int row = (i >> 8) * 16 + (i & 15), j = jt * 16 + ((i & 63) >> 4) * 4 + ((i >> 6) & 3);
         const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
-        e_bias[u] = p.epi.bias ? p.epi.bias[jc] : 0.f;
-        e_res[u] = p.epi.res ? (float)((const T*)p.epi.res)[(int64_t)rc * p.epi.ldr + jc] : 0.f;
         e_add2[u] = p.epi.add2 ? p.epi.add2[(int64_t)rc * p.epi.add2_n + (int64_t)t * p.epi.add2_t + jc] : 0.f;
     }
 
@@ -649,8 +696,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
             }
         }
         if (FAST) {
-            // all activation fragments of the batch are requested before the first MFMA; tiles past kt1 are
-            // neutralised by zeroing their weight fragment (no branch anywhere in the batch)
+            // all activation fragments of the batch are requested before the first MFMA (the first batch's were requested
+            // with the weights, above); tiles past kt1 are neutralised by zeroing their weight fragment (no branch anywhere)
             V xf[WB][MT];
 #pragma unroll
             for (int i = 0; i < WB; ++i) {
@@ -658,8 +705,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int row = min(mt * 16 + c, p.n_rows - 1);
-                    if (LNS) xf[i][mt] = *reinterpret_cast<const V*>(s_x + (int64_t)row * pitch + k0);
-                    else xf[i][mt] = ld_frag<T>(x + (int64_t)row * p.ldx + k0);
+                    if constexpr (LNS) {
+                        xf[i][mt] = *reinterpret_cast<const V*>(s_x + (int64_t)row * pitch + k0);
+                    } else {
+                        if (kb == kt0) xf[i][mt] = xf0[i][mt];
+                        else xf[i][mt] = ld_frag<T>(x + (int64_t)row * p.ldx + k0);
+                    }
                 }
             }
 #pragma unroll
@@ -693,6 +744,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     for (int mt = 0; mt < MT; ++mt) s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
     __syncthreads();
     JB_STAMP(6);
+    eo.finish(p);
     {
         const float* sa = reinterpret_cast<const float*>(s_acc);
 #pragma unroll
@@ -705,7 +757,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += sa[((w * MT + mt) * 64 + l) * 4 + r];
             const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
-            epilogue_store1<T>(p.epi, v, row, j, cache_row, e_bias[u], e_res[u], e_add2[u]);
+            epilogue_store1<T>(p.epi, v, row, j, cache_row, eo.bias[u], eo.res[u], e_add2[u]);
         }
     }
     JB_STAMP(7);
@@ -748,18 +800,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     for (int i = 0; i < NF; ++i)
         wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)min(kt0 + i, p.nkt - 1) * (64 * E)));
     constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);
+    EpiOperands<T, EPT, NW * 64> eo;           // bias, column sums c1, residual: in flight with the weights
+    eo.request(p, jt, MT);
+    jb_issue_fence();
     int t = 0;
     if (p.epi.qkv_split) t = *p.t_dev;
-    float e_bias[EPT], e_res[EPT], e_c1[EPT];
-#pragma unroll
-    for (int u = 0; u < EPT; ++u) {
-        const int i = threadIdx.x + u * NW * 64;
-        const int row = (i >> 8) * 16 + (i & 15), j = jt * 16 + ((i & 63) >> 4) * 4 + ((i >> 6) & 3);
-        const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
-        e_bias[u] = p.epi.bias ? p.epi.bias[jc] : 0.f;
-        e_c1[u] = p.ln_c1[jc];
-        e_res[u] = p.epi.res ? (float)((const T*)p.epi.res)[(int64_t)rc * p.epi.ldr + jc] : 0.f;
-    }
 
     // ---- projection and row statistics, all on MFMA (tiles past kt1 are neutralised by zeroing the activations) ----
     V ones;
@@ -788,6 +833,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
         }
     }
     __syncthreads();
+    eo.finish(p);
     const float* sa = reinterpret_cast<const float*>(s_acc);
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
@@ -804,9 +850,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
         }
         const float mean = sm / (float)p.K;
         const float var = fmaxf(sq / (float)p.K - mean * mean, 0.f);
-        v = (v - mean * e_c1[u]) / sqrtf(var + p.ln_eps);
+        v = (v - mean * eo.c1[u]) / sqrtf(var + p.ln_eps);
         const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
-        epilogue_store1<T>(p.epi, v, row, j, cache_row, e_bias[u], e_res[u]);
+        epilogue_store1<T>(p.epi, v, row, j, cache_row, eo.bias[u], eo.res[u]);
     }
 }
 
@@ -834,15 +880,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_merge_kernel(GemvParams p) {
     const f16* wbase = (const f16*)p.W + ((int64_t)jt * p.nkt) * (64 * E) + (int64_t)lane * E;
 
     constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);
-    float e_bias[EPT], e_res[EPT];
-#pragma unroll
-    for (int u = 0; u < EPT; ++u) {
-        const int i = threadIdx.x + u * NW * 64;
-        const int row = (i >> 8) * 16 + (i & 15), j = jt * 16 + ((i & 63) >> 4) * 4 + ((i >> 6) & 3);
-        const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
-        e_bias[u] = p.epi.bias ? p.epi.bias[jc] : 0.f;
-        e_res[u] = p.epi.res ? (float)((const f16*)p.epi.res)[(int64_t)rc * p.epi.ldr + jc] : 0.f;
-    }
+    EpiOperands<f16, EPT, NW * 64> eo;
+    eo.request(p, jt, MT);
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -869,6 +908,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_merge_kernel(GemvParams p) {
                 }
             }
         }
+        jb_issue_fence();
 #pragma unroll
         for (int i = 0; i < WB; ++i) {
             const V w = keep_frag<f16>(kb + i < kt1, wf[i]);
@@ -899,6 +939,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_merge_kernel(GemvParams p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
     __syncthreads();
+    eo.finish(p);
     const float* sa = reinterpret_cast<const float*>(s_acc);
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
@@ -909,7 +950,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_merge_kernel(GemvParams p) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += sa[((w * MT + mt) * 64 + l) * 4 + r];
-        epilogue_store1<f16>(p.epi, v, row, j, -1, e_bias[u], e_res[u]);
+        epilogue_store1<f16>(p.epi, v, row, j, -1, eo.bias[u], eo.res[u]);
     }
 }
 

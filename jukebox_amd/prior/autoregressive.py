@@ -2,6 +2,7 @@
 (jukebox/prior/autoregressive.py:48-359).  `sample` / `primed_sample` run the whole token loop inside
 the HIP decode engine (jukebox_amd.engine.PriorEngine): one hipGraph replay per token, chunked MFMA
 prefill for the primed part; nothing is computed in torch."""
+import contextlib
 import math
 
 import numpy as np
@@ -199,19 +200,28 @@ class ConditionalAutoregressive2D(nn.Module):
             assert n_prime < sample_tokens
             eng.tokens[:, :n_prime] = x_prime
             eng.prefill(0, n_prime)
-        tap = getattr(self, "decode_tap", None)
-        if tap is None:
-            eng.decode(n_prime, sample_tokens - n_prime)
-        else:
-            # (every, fn): hand the token buffer to fn after every `every` enqueued decode steps, so that a consumer on
-            # another stream can start on a partial window (jukebox_amd.sample._sample_levels_pipelined)
-            every, fn = tap
-            pos = n_prime
-            while pos < sample_tokens:
-                n = min(int(every), sample_tokens - pos)
-                eng.decode(pos, n)
-                fn(eng.tokens, pos, pos + n)
-                pos += n
+        # The token loop.  `decode_stream` (set by the level pipeline) moves it -- and only it -- to a CU-masked stream, so
+        # that concurrently decoding levels do not share compute units; conditioner and prefill stay on the caller's stream.
+        ds = getattr(self, "decode_stream", None)
+        cur = t.cuda.current_stream(eng.device) if ds is not None else None
+        if ds is not None:
+            ds.wait_stream(cur)
+        with (t.cuda.stream(ds) if ds is not None else contextlib.nullcontext()):
+            tap = getattr(self, "decode_tap", None)
+            if tap is None:
+                eng.decode(n_prime, sample_tokens - n_prime)
+            else:
+                # (every, fn): hand the token buffer to fn after every `every` enqueued decode steps, so that a consumer on
+                # another stream can start on a partial window (jukebox_amd.sample._sample_levels_pipelined)
+                every, fn = tap
+                pos = n_prime
+                while pos < sample_tokens:
+                    n = min(int(every), sample_tokens - pos)
+                    eng.decode(pos, n)
+                    fn(eng.tokens, pos, pos + n)
+                    pos += n
+        if ds is not None:
+            cur.wait_stream(ds)
         x = eng.tokens[:, :sample_tokens].clone()
         x = self.postprocess(x, sample_tokens)
         if get_preds:

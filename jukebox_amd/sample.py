@@ -117,12 +117,30 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     prios = [-1, -1, 0, 0]
     stream_of = {level: t.cuda.Stream(device=device, priority=prios[min(i, 3)]) if on_gpu else None
                  for i, level in enumerate(order)}
+    # Spatial partition for the token loops.  A decode step is a chain of ~360 latency-bound launches of <= 128
+    # workgroups; three chains sharing all 256 CUs slow each other to 2.86 ms per step (2.11 alone).  With the chains on
+    # DISJOINT compute units -- the long pole (lowest level) on 128 CUs, the two upper levels on 64 each
+    # (hipExtStreamCreateWithCUMask; mask bit i is CU i / 8 of XCD i % 8, so a contiguous bit range takes the same CUs
+    # of every XCD) -- the long pole runs at 2.32 ms while the others decode (tools/cu_mask_probe.py), and at its solo
+    # speed afterwards (its kernels never need more than 128 CUs).  Only the token loop moves to the masked stream:
+    # conditioner and prefill are throughput work and keep the level's unmasked stream (ConditionalAutoregressive2D._run).
+    masked_raw = []
+    if on_gpu and len(order) > 1 and hps.get("cu_partition", os.environ.get("JB_CU_PARTITION", "1") != "0"):
+        from . import _lib as L
+        shares = [range(0, 128), range(128, 192), range(192, 256)]
+        for i, level in enumerate(order[:3]):
+            ar = getattr(priors[level], "prior", None)
+            if ar is None or not hasattr(ar, "_run"):
+                continue
+            s_, h_ = L.cu_mask_stream(shares[i], device=device)
+            masked_raw.append((ar, h_))
+            ar.decode_stream = s_
 
-    def new_event(stream):
+    def new_event(stream=None):
         if not on_gpu:
             return None
         ev = t.cuda.Event()
-        ev.record(stream)
+        ev.record(t.cuda.current_stream(device) if stream is None else stream)
         return ev
 
     def worker(level):
@@ -163,7 +181,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                         # window-relative music tokens [lo, hi), all new (the primed part is never decoded)
                         assert start + lo >= known
                         zbuf[level][:, start + lo:start + hi] = tok
-                        ev = new_event(stream)
+                        ev = new_event()                 # the current stream: the token loop may run on its own (CU-masked) stream
                         with cond:
                             progress[level] = start + hi
                             ready_event[level] = ev
@@ -200,6 +218,11 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         th.join()
     if on_gpu:
         t.cuda.synchronize(device)
+    if masked_raw:
+        from . import _lib as L
+        for ar, h_ in masked_raw:
+            ar.decode_stream = None
+        L.destroy_streams([h_ for _, h_ in masked_raw])
     if errors:
         raise errors[0]
     return zs_local
