@@ -124,7 +124,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # of every XCD) -- the long pole runs at 2.32 ms while the others decode (tools/cu_mask_probe.py), and at its solo
     # speed afterwards (its kernels never need more than 128 CUs).  Only the token loop moves to the masked stream:
     # conditioner and prefill are throughput work and keep the level's unmasked stream (ConditionalAutoregressive2D._run).
-    masked_raw = []
+    masked_raw, la_stream = [], None
     if on_gpu and len(order) > 1 and hps.get("cu_partition", os.environ.get("JB_CU_PARTITION", "1") != "0"):
         from . import _lib as L
         shares = [range(0, 128), range(128, 192), range(192, 256)]
@@ -135,6 +135,8 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
             s_, h_ = L.cu_mask_stream(shares[i], device=device)
             masked_raw.append((ar, h_))
             ar.decode_stream = s_
+        la_stream, h_ = L.cu_mask_stream(range(128, 256), device=device)     # look-ahead of the lowest level: the other half
+        masked_raw.append((None, h_))
 
     def new_event(stream=None):
         if not on_gpu:
@@ -158,7 +160,16 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 started = getattr(_sample, "level_start", None)
                 if callable(started):
                     started(level)
-                for start, sample_tokens in _level_plan(prior, zs_local[level].shape[1], total_length, hop_length):
+                plan = _level_plan(prior, zs_local[level].shape[1], total_length, hop_length)
+                # Look-ahead (lowest level only -- the long pole): while window i decodes in one engine, the other engine
+                # is conditioned for window i + 1 and prefilled with window i's new tokens as they are published, on a
+                # stream confined to the CUs the token loops of this level never use.
+                ar = getattr(prior, "prior", None)
+                can_look = on_gpu and level == order[0] and chunk > 0 and hps.get("lookahead_prefill", True) and \
+                    hasattr(prior, "prepare_window") and prior.x_cond and not prior.single_enc_dec and prior.n_tokens == 0 and \
+                    (level + 1) in sample_levels and local_hps.n_samples <= kw["max_batch_size"] and la_stream is not None
+                prepared = None
+                for i, (start, sample_tokens) in enumerate(plan):
                     if prior.x_cond and (level + 1) in sample_levels:
                         need = (start + prior.n_ctx) // prior.cond_downsample
                         with cond:
@@ -176,12 +187,34 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                         view[level + 1] = zbuf[level + 1]          # only [start/cd, end/cd) is read: published above
                     known = int(zs_local[level].shape[1])
                     tapped = local_hps.n_samples <= k["max_batch_size"] and chunk > 0
+                    # this window: use what was prepared for it (if anything); arm the look-ahead for the next one when
+                    # the upper level has already produced the codes that window is conditioned on
+                    if ar is not None:
+                        ar.engine_slot = i % 2 if can_look else 0
+                        ar.prepared_window = prepared if (prepared is not None and prepared.start == start) else None
+                    prepared, nxt_hop = None, 0
+                    if can_look and tapped and sample_tokens is None and i + 1 < len(plan) and plan[i + 1][1] is None:
+                        nxt = plan[i + 1][0]
+                        need_n = (nxt + prior.n_ctx) // prior.cond_downsample
+                        with cond:
+                            ok = progress[level + 1] >= need_n
+                            ev_n = ready_event.get(level + 1)
+                        if ok:
+                            la_stream.wait_stream(stream)
+                            if ev_n is not None:
+                                la_stream.wait_event(ev_n)
+                            prepared = prior.prepare_window(view, lab, nxt, local_hps.n_samples, bool(k.get("fp16", False)),
+                                                            (i + 1) % 2, la_stream)
+                            nxt_hop = nxt - start
 
-                    def publish(lo, hi, tok, start=start, known=known):
+                    def publish(lo, hi, tok, start=start, known=known, prepared=prepared, nxt_hop=nxt_hop):
                         # window-relative music tokens [lo, hi), all new (the primed part is never decoded)
                         assert start + lo >= known
                         zbuf[level][:, start + lo:start + hi] = tok
                         ev = new_event()                 # the current stream: the token loop may run on its own (CU-masked) stream
+                        if prepared is not None and hi > nxt_hop:
+                            a = max(lo, nxt_hop)         # these tokens are primed tokens of the next window
+                            prepared.feed(tok[:, a - lo:], a - nxt_hop, hi - nxt_hop, after=ev)
                         with cond:
                             progress[level] = start + hi
                             ready_event[level] = ev
@@ -192,6 +225,8 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                         out = sample_single_window(view, lab, k, level, prior, start, local_hps)
                     finally:
                         prior.window_tap = None
+                        if ar is not None:
+                            ar.prepared_window = None
                     new_len = int(out[level].shape[1])
                     if not tapped:
                         zbuf[level][:, known:new_len] = out[level][:, known:new_len]
@@ -206,11 +241,21 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                     stream.synchronize()
                 if callable(callback):
                     callback(level)
+                # This level's audio (VQVAE.decode of its codes, sample.py:105) right away, on the level's stream, while the
+                # levels below are still sampling -- the upper levels' decodes leave the end of the job.  (The codes of the
+                # levels above are complete: this level has consumed all of them.)
+                if on_gpu and hps.get("decode_audio_early", True):
+                    with cond:
+                        zs_now = list(zs_local)
+                    early_audio[level] = prior.decode(zs_now[level:], start_level=level, bs_chunks=max(1, zs_now[level].shape[0]))
+                    stream.synchronize()
         except BaseException as e:          # noqa: BLE001 -- re-raised in the caller
             with cond:
                 errors.append(e)
                 cond.notify_all()
 
+    early_audio = {}
+    _sample_levels_pipelined.early_audio = early_audio
     threads = [threading.Thread(target=worker, args=(l,), name=f"level{l}") for l in levels]
     for th in threads:
         th.start()
@@ -221,7 +266,8 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     if masked_raw:
         from . import _lib as L
         for ar, h_ in masked_raw:
-            ar.decode_stream = None
+            if ar is not None:
+                ar.decode_stream = None
         L.destroy_streams([h_ for _, h_ in masked_raw])
     if errors:
         raise errors[0]
@@ -281,7 +327,9 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
             prior.cpu()                          # sample.py:104: drops the engine's device copies
             empty_cache()
         zs[level] = gather_shards(zs_local[level], hps.n_samples)
-        x_local = prior.decode(zs_local[level:], start_level=level, bs_chunks=max(1, zs_local[level].shape[0]))
+        early = getattr(_sample_levels_pipelined, "early_audio", {}) if pipelined else {}
+        x_local = early.pop(level) if level in early else \
+            prior.decode(zs_local[level:], start_level=level, bs_chunks=max(1, zs_local[level].shape[0]))
         xs[level] = x_local
         _sample.level_done = getattr(_sample, "level_done", None)
         if callable(_sample.level_done) and not pipelined:
