@@ -383,6 +383,9 @@ def main():
     step_ms = (time.perf_counter() - ts) / n_probe * 1e3
     breakdown["level0_decode_ms_per_token_step"] = round(step_ms, 4)
     breakdown["launches_per_token_step"] = eng.launches_per_step
+    tl = getattr(S._sample_levels_pipelined, "timeline", None)
+    if tl and os.environ.get("JB_BENCH_TIMELINE") == "1":        # per-window schedule of the last step (diagnostics)
+        breakdown["timeline"] = [list(x) for x in tl]
     step_bytes = eng.step_bytes(4096 if not tiny else 64)
     breakdown["level0_decode_step_algorithmic_gb"] = round(step_bytes / 1e9, 4)
     breakdown["level0_decode_step_frac_of_hbm_peak"] = round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -7,6 +7,7 @@ random streams, and the generated codes are all-gathered once per level (SURVEY.
 the whole job redundantly on every rank with identical seeds (sample.py:110-113)."""
 import contextlib
 import os
+import time
 
 import torch as t
 
@@ -165,7 +166,8 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 # is conditioned for window i + 1 and prefilled with window i's new tokens as they are published, on a
                 # stream confined to the CUs the token loops of this level never use.
                 ar = getattr(prior, "prior", None)
-                can_look = on_gpu and level == order[0] and chunk > 0 and hps.get("lookahead_prefill", True) and \
+                can_look = on_gpu and level == order[0] and chunk > 0 and \
+                    hps.get("lookahead_prefill", os.environ.get("JB_LOOKAHEAD", "1") != "0") and \
                     hasattr(prior, "prepare_window") and prior.x_cond and not prior.single_enc_dec and prior.n_tokens == 0 and \
                     (level + 1) in sample_levels and local_hps.n_samples <= kw["max_batch_size"] and la_stream is not None
                 prepared = None
@@ -221,9 +223,12 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                             cond.notify_all()
 
                     prior.window_tap = (chunk, publish) if tapped else None
+                    t_w = time.perf_counter()
                     try:
                         out = sample_single_window(view, lab, k, level, prior, start, local_hps)
                     finally:
+                        timeline.append((level, start, round(t_w - t_job, 3), round(time.perf_counter() - t_job, 3),
+                                         ar is not None and getattr(ar, "prepared_window", None) is not None))
                         prior.window_tap = None
                         if ar is not None:
                             ar.prepared_window = None
@@ -256,6 +261,9 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
 
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
+    # (level, window start, seconds into the job at which the window's sampling began / ended, look-ahead used) per window
+    timeline, t_job = [], time.perf_counter()
+    _sample_levels_pipelined.timeline = timeline
     threads = [threading.Thread(target=worker, args=(l,), name=f"level{l}") for l in levels]
     for th in threads:
         th.start()
