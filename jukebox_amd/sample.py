@@ -128,16 +128,25 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     masked_raw, la_stream = [], None
     if on_gpu and len(order) > 1 and hps.get("cu_partition", os.environ.get("JB_CU_PARTITION", "1") != "0"):
         from . import _lib as L
-        shares = [range(0, 128), range(128, 192), range(192, 256)]
-        for i, level in enumerate(order[:3]):
+        # lowest level: CUs 0..127 of the mask space; the level above: 128..255; the top level (short-lived) unmasked.
+        # JB_CU_SHARES="0-127,128-255,none" / JB_LOOKAHEAD_CUS="128-255" override (experiments).
+        def _rng(spec):
+            if spec in ("none", ""):
+                return None
+            lo_, hi_ = spec.split("-")
+            return range(int(lo_), int(hi_) + 1)
+        shares = [_rng(x) for x in os.environ.get("JB_CU_SHARES", "0-127,128-255,none").split(",")]
+        for i, level in enumerate(order[:len(shares)]):
             ar = getattr(priors[level], "prior", None)
-            if ar is None or not hasattr(ar, "_run"):
+            if ar is None or not hasattr(ar, "_run") or shares[i] is None:
                 continue
             s_, h_ = L.cu_mask_stream(shares[i], device=device)
             masked_raw.append((ar, h_))
             ar.decode_stream = s_
-        la_stream, h_ = L.cu_mask_stream(range(128, 256), device=device)     # look-ahead of the lowest level: the other half
-        masked_raw.append((None, h_))
+        la_bits = _rng(os.environ.get("JB_LOOKAHEAD_CUS", "128-255"))
+        if la_bits is not None:
+            la_stream, h_ = L.cu_mask_stream(la_bits, device=device)         # look-ahead of the lowest level
+            masked_raw.append((None, h_))
 
     def new_event(stream=None):
         if not on_gpu:

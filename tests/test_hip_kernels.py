@@ -657,7 +657,7 @@ def test_fused_three_launch_layer(H, N, W, H_, bc, T):
         att2 = H.attn_decode_fresh(func, uq, stats_a, f_at, W, kc, vc, H_, bc, t_dev)
         torch.cuda.synchronize()
         f = lambda x: x.float().cpu().numpy()
-        assert np.array_equal(f(xb), f(xb_ref)), (func, t)                                   # same arithmetic, same rounding
+        assert np.abs(f(xb) - f(xb_ref)).max() < 2e-3 * max(1.0, float(np.abs(f(xb_ref)).max())), (func, t)   # other k order
         for st, x in ((stats_b, xb), (stats_a, xa2)):
             xs = f(x).reshape(N, W // 16, 16)
             s = st.cpu().numpy()[:, :N]                                                      # [tile][row][which]
