@@ -164,43 +164,6 @@ int jb_attn_decode_split_parts(int dtype, int d_head, int max_keys);
 void jb_tune_attn_decode_split(int max_parts, int waves);
 void jb_tune_attn_decode_split_min_keys(int min_keys);
 
-/* ---- decode step with three launches per layer (fp16, n_rows <= 16; see jukebox_amd/csrc/fused_layer.hip) -------------
- * The projection behind a residual add is taken from the operands of the add, and its LayerNorm is applied by the consumer:
- *   launch A:  x_b = x_a + att.Wp + bp (tiles + per-tile partial row sums of x_b, x_b^2)   |   u_f = x_b.W'f - mean_b*c1f
- *   launch B:  h = gelu(rstd_b*u_f + b'f) on load;  x_a' = x_b + h.Wp2 + bp2 (tiles + partials)   |   u_qkv = x_a'.W'a (next layer)
- *   launch C:  q,k,v = rstd_a'*(u_qkv - mean_a'*c1a) + b'a for the workgroup's own sample; k/v append; attention
- * Replaces, per layer, ResAttnBlock's sample branch (jukebox/transformer/transformer.py:62-66,82-86): ln_0 + attn.c_attn,
- * attn.c_proj, ln_1 + mlp.c_fc + quick_gelu, mlp.c_proj and the two residual adds -- 3 launches instead of 5.
- * Images (all prepared once at bind time):  W'f = diag(g1).Wf;  Wfa = packed [W'f ; Wp.W'f]  ((W+S) x M);  kf = bp.W'f;
- * c1f = column sums of W'f;  wsum_p[k] = sum_j Wp[k][j] (half);  sum_bp = sum(bp);  bff16 = half(b1.Wf + bf);
- * Wfb = packed [W'a ; Wp2.W'a] ((W+M) x 3S) with W'a = diag(g0').Wa of the NEXT layer;  ka = bp2.W'a.
- * stats_*: [W/16][16][2] fp32 partial (sum, sum of squares) per 16-column tile and row. */
-typedef struct jb_fused_a_args {
-    int n_rows, W, S, M;
-    const void* xa; int64_t ldx;                 /* residual stream in, half [n][W] */
-    const void* att; int64_t lda;                /* attention output, half [n][S] */
-    const void* Wp; const float* bp;             /* packed S x W, bias */
-    void* xb; int64_t ldb; float* stats_b;       /* out: x_b half [n][W], partials */
-    const void* Wfa; const float* kf; const float* c1f; const void* wsum_p; float sum_bp;
-    void* uf; int64_t ldu;                       /* out: un-normalised c_fc (mean removed), half [n][M] */
-} jb_fused_a_args;
-int jb_fused_a(const jb_fused_a_args* args /* host */, void* stream);
-typedef struct jb_fused_b_args {
-    int n_rows, W, M, n_stats; float ln_eps;
-    const void* xb; int64_t ldb; const void* uf; int64_t ldu; const float* stats_b; const void* bff16;
-    const void* Wp2; const float* bp2; void* xa_out; int64_t ldo; float* stats_a;
-    float* out2; int64_t ldo2; const float* add2; int64_t add2_n_stride, add2_t_stride; const int* t_dev;   /* as jb_gemv_args */
-    int J2;                                      /* 3S, or 0 for the last layer (no next c_attn) */
-    const void* Wfb; const float* ka; float* uq; int64_t ldq;   /* out: x_a'.W'a + ka, fp32 [n][J2] */
-} jb_fused_b_args;
-int jb_fused_b(const jb_fused_b_args* args /* host */, void* stream);
-/* Launch C: single-query attention (as jb_attn_decode, patterns 0/1/2/3/7, fp16, d_head = 32 x {1,2,4,8,15,16}) whose
- * workgroups first finish q, k, v of their sample from u (fp32 [n][3*n_head*d_head]: q | k | v), the partials and
- * c1a / ba ([3S] fp32), append k / v at *t_dev and attend (the position's own key comes from on-chip memory). */
-int jb_attn_decode_fresh(int attn_func, const float* uq, int64_t ldq, const float* stats, int n_stats, const float* c1a,
-                         const float* ba, int width, float ln_eps, void* kcache, void* vcache, int cache_cap, void* out,
-                         int64_t ldo, int n_batch, int n_head, int d_head, int block_ctx, const int* t_dev, void* stream);
-
 /* Chunked-prefill attention (q_l > 1) on MFMA with LDS-staged k/v tiles and online softmax:
  * queries at positions t0 .. t0+n_q-1 against the caches (already holding those positions).
  * Replaces FactoredAttention.forward(sample=True) with q_l > 1 -- _pad_to_block_ctx, the masked
@@ -282,10 +245,6 @@ typedef struct jb_layer {
      * diag(gamma)·W, beta·W + b, column sums.  NULL = the decode step normalises rows in the projection kernel.
      * Prefill always uses w_attn / w_fc with an explicit LayerNorm. */
     const void *w_attn_f, *w_fc_f; const float *b_attn_f, *b_fc_f, *c1_attn, *c1_fc;
-    /* three-launch decode layer (jb_engine_cfg.fused3; see jb_fused_a / jb_fused_b): images of THIS layer's launch A
-     * (w_fa, k_f, wsum_p, sum_bp, b_fc_f16) and launch B (w_fb = [W'a ; Wp2.W'a] and k_a of the NEXT layer's c_attn; NULL in
-     * the last layer, wsum unused). */
-    const void *w_fa, *w_fb, *wsum_p, *b_fc_f16; const float *k_f, *k_a; float sum_bp;
 } jb_layer;
 
 typedef struct jb_engine_cfg {
@@ -306,9 +265,6 @@ typedef struct jb_engine_cfg {
      * att_ml [n][n_head][4][2] fp32; NULL = one workgroup per (sample, head) (jb_attn_decode) */
     void* att_parts; float* att_ml;
     unsigned* ticket;                                      /* device counter for jb_sample_step, zero-initialised */
-    /* three launches per layer (fp16, n_batch <= 16, no cross-attention layers, every layer with folded images and
-     * w_fa / w_fb): u_f half [n][M], u_q fp32 [n][3S], stats_a / stats_b fp32 [W/16][16][2] */
-    int fused3; void* u_f; float* u_q; float *stats_a, *stats_b;
     /* prefill work buffers for chunks of <= chunk_cap positions */
     int chunk_cap;
     void *c_xa, *c_xb, *c_h, *c_q, *c_att, *c_mlp;          /* [n*chunk_cap][W|W|W|S|S|M] */
@@ -332,8 +288,7 @@ int jb_engine_set_encoder_kv(void* handle, void* stream);
 /* Prefill positions t0..t0+n_t-1 (tokens already in cfg.tokens): fills the k/v caches, leaves *t_dev = t0+n_t. */
 int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
 /* Run n_steps decode steps starting at position t0 (sets *t_dev = t0 and embeds position t0 first).  One step =
- * L x [c_attn | attention | attn.c_proj | mlp.c_fc | mlp.c_proj] | logits | sample + embed(t+1) + counter: 5 L + 2 launches
- * (cfg.fused3: c_attn(0) | L x [attention | A | B] | logits | sample...: 3 L + 3 launches).
+ * L x [c_attn | attention | attn.c_proj | mlp.c_fc | mlp.c_proj] | logits | sample + embed(t+1) + counter: 5 L + 2 launches.
  * use_graph != 0 captures one step into a hipGraph on first use and replays it. */
 int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
 /* Measurement aid: n_steps passes over all layers launching only the LayerNorm-fused projections (attn.c_attn and

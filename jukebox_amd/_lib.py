@@ -36,20 +36,6 @@ class GemvArgs(C.Structure):
                 ("x_parts", vp), ("x_ml", vp), ("n_parts", i32), ("n_head", i32), ("d_head", i32)]
 
 
-class FusedAArgs(C.Structure):
-    _fields_ = [("n_rows", i32), ("W", i32), ("S", i32), ("M", i32), ("xa", vp), ("ldx", i64), ("att", vp), ("lda", i64),
-                ("Wp", vp), ("bp", vp), ("xb", vp), ("ldb", i64), ("stats_b", vp),
-                ("Wfa", vp), ("kf", vp), ("c1f", vp), ("wsum_p", vp), ("sum_bp", f32), ("uf", vp), ("ldu", i64)]
-
-
-class FusedBArgs(C.Structure):
-    _fields_ = [("n_rows", i32), ("W", i32), ("M", i32), ("n_stats", i32), ("ln_eps", f32),
-                ("xb", vp), ("ldb", i64), ("uf", vp), ("ldu", i64), ("stats_b", vp), ("bff16", vp),
-                ("Wp2", vp), ("bp2", vp), ("xa_out", vp), ("ldo", i64), ("stats_a", vp),
-                ("out2", vp), ("ldo2", i64), ("add2", vp), ("add2_n_stride", i64), ("add2_t_stride", i64), ("t_dev", vp),
-                ("J2", i32), ("Wfb", vp), ("ka", vp), ("uq", vp), ("ldq", i64)]
-
-
 class SampleParams(C.Structure):
     _fields_ = [("temp", f32), ("top_k", i32), ("top_p", f32), ("sample_base", i32), ("seed", C.c_uint64),
                 ("pos_base", i32), ("stream_id", i32)]
@@ -60,8 +46,7 @@ class Layer(C.Structure):
                 ("b_attn", vp), ("b_proj", vp), ("b_fc", vp), ("b_proj2", vp),
                 ("ln0_g", vp), ("ln0_b", vp), ("ln1_g", vp), ("ln1_b", vp),
                 ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("w_enc_k", vp), ("w_enc_v", vp), ("b_enc_kv", vp),
-                ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp),
-                ("w_fa", vp), ("w_fb", vp), ("wsum_p", vp), ("b_fc_f16", vp), ("k_f", vp), ("k_a", vp), ("sum_bp", f32)]
+                ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp)]
 
 
 class EngineCfg(C.Structure):
@@ -71,7 +56,6 @@ class EngineCfg(C.Structure):
                 ("x_cond", vp), ("xc_n_stride", i64), ("xc_t_stride", i64), ("add_cond_after", i32), ("encoder_kv", vp), ("enc_len", i32), ("hidden_out", vp), ("hidden_n_stride", i64),
                 ("x_a", vp), ("x_b", vp), ("q", vp), ("att", vp), ("mlp", vp), ("xf", vp), ("logits", vp),
                 ("att_parts", vp), ("att_ml", vp), ("ticket", vp),
-                ("fused3", i32), ("u_f", vp), ("u_q", vp), ("stats_a", vp), ("stats_b", vp),
                 ("chunk_cap", i32), ("c_xa", vp), ("c_xb", vp), ("c_h", vp), ("c_q", vp), ("c_att", vp),
                 ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
                 ("preds", vp), ("preds_n_stride", i64), ("sample_params", vp),
@@ -95,9 +79,6 @@ _SIGS = {
     "jb_gemv_ln_fold_supported": (i32, [i32, i32, i32, i32]),
     "jb_attn_decode": (i32, [i32, i32, vp, i64, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "jb_tune_attn_decode": (None, [i32, i32]),
-    "jb_fused_a": (i32, [C.POINTER(FusedAArgs), vp]),
-    "jb_fused_b": (i32, [C.POINTER(FusedBArgs), vp]),
-    "jb_attn_decode_fresh": (i32, [i32, vp, i64, vp, i32, vp, vp, i32, f32, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, vp]),
     "jb_attn_decode_split": (i32, [i32, vp, i64, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "jb_attn_decode_split_parts": (i32, [i32, i32, i32]),
     "jb_tune_attn_decode_split": (None, [i32, i32]),

@@ -403,223 +403,6 @@ __global__ __launch_bounds__(512) void attn_decode_split_kernel(int func, const 
     if (threadIdx.x == 0) { oml[0] = m; oml[1] = lsum; }
 }
 
-static inline bool split_d_ok(int d_head);
-
-// Launch C of the three-launch decode layer (fused_layer.hip): the single-query attention of attn_decode_mfma_kernel, whose
-// workgroup first FINISHES its own sample's q, k, v.  Launch B left u = x_a'.W'a (fp32, [n][3S]: q | k | v) and the per-tile
-// partial sums of the x_a' rows; here
-//     mean, rstd of row n  <-  the partials (n_stats x {sum, sum of squares}; a wave reduction)
-//     q, k, v[j] = round(rstd * (u[j] - mean * c1a[j]) + round(b'a[j]))          (the folded LayerNorm + c_attn epilogue)
-// for the 3 d channels of this (sample, head), into LDS; k and v are appended to the cache at position t (as the c_attn
-// epilogue did) and -- the position's own key being part of every causal key set -- patched into the tile fragments from
-// LDS instead of being read back.  The key / value tile requests depend only on the position, so they are issued BEFORE
-// the prologue's arithmetic and barrier: the prologue hides behind the k/v round trip.
-template <int ND32>
-__global__ __launch_bounds__(512) void attn_decode_fresh_kernel(int func, const float* __restrict__ uq, int64_t ldq,
-                                                                const float* __restrict__ stats, int n_stats,
-                                                                const float* __restrict__ c1a, const float* __restrict__ ba,
-                                                                int width, float ln_eps, f16* __restrict__ kc,
-                                                                f16* __restrict__ vc, int cap, f16* __restrict__ out, int64_t ldo,
-                                                                int n_head, int bc, const int* __restrict__ t_dev) {
-    constexpr int d = ND32 * 32;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nw = blockDim.x >> 6;
-    float* s_ml = smem;                      // [nw][2]
-    float* s_pw = smem + 2 * nw;             // [nw][16]
-    float* s_o = s_pw + 16 * nw;             // [nw][d]
-    f16* s_qkv = reinterpret_cast<f16*>(s_o + nw * d);   // [3][d]: q, k_t, v_t of this (sample, head)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, c = lane & 15;
-    const int n = blockIdx.x, h = blockIdx.y;
-    const int S = n_head * d;
-
-    // ---- prologue requests (independent of the position) ----
-    float ps1[4], ps2[4];                    // partial sums of row n: lanes cover tiles lane, lane + 64, ...
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int tile = min(lane + 64 * i, n_stats - 1);
-        const float2 v = *reinterpret_cast<const float2*>(stats + (int64_t)tile * 32 + n * 2);
-        ps1[i] = lane + 64 * i < n_stats ? v.x : 0.f;
-        ps2[i] = lane + 64 * i < n_stats ? v.y : 0.f;
-    }
-    constexpr int PER = (3 * d + 511) / 512;
-    float u_[PER], c1_[PER], b_[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int idx = min((int)threadIdx.x + 512 * i, 3 * d - 1);
-        const int which = idx / d, ch = idx - which * d;
-        const int j = which * S + h * d + ch;
-        u_[i] = uq[(int64_t)n * ldq + j];
-        c1_[i] = c1a[j];
-        b_[i] = ba[j];
-    }
-    jb_issue_fence();
-    const int t = *t_dev;
-    const KeySet ks = decode_key_set(func, t, bc, cap);
-    const bool append = t < cap && func != JB_ATTN_CROSS;
-    // the position's own key is the last key of the causal patterns (never of prev_block / cross; prime only while t < cap)
-    const bool fresh = append && (func == JB_ATTN_DENSE || func == JB_ATTN_BLOCK || func == JB_ATTN_TRANSPOSE_BLOCK || func == JB_ATTN_PRIME);
-    const int fresh_key = fresh ? ks.count - 1 : -1;
-    const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
-    const f16* vbase = vc + ((int64_t)n * cap) * S + h * d;
-    const int c0 = min(lane * 8, d - 8);
-    const int ntiles = (ks.count + 15) >> 4;
-
-    // ---- key / value requests of this wave's first tile: before the prologue is waited for ----
-    f16x8 kf[ND32], vv[16];
-    auto request = [&](int tt) {
-        const int kbase_i = tt * 16;
-        const int ki = min(kbase_i + c, max(ks.count - 1, 0));
-        const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * S + g * 8;
-#pragma unroll
-        for (int dt = 0; dt < ND32; ++dt) kf[dt] = ld_frag<f16>(kr + dt * 32);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int vi = min(kbase_i + k, max(ks.count - 1, 0));
-            vv[k] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0);
-        }
-    };
-    if (wave < ntiles) request(wave);
-    jb_issue_fence();
-
-    // ---- finish q, k, v of this (sample, head) ----
-    float s1 = (ps1[0] + ps1[1]) + (ps1[2] + ps1[3]), s2 = (ps2[0] + ps2[1]) + (ps2[2] + ps2[3]);
-    s1 = jb_wave_sum(s1);
-    s2 = jb_wave_sum(s2);
-    const float mean = s1 / (float)width;
-    const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)width - mean * mean, 0.f) + ln_eps);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int idx = threadIdx.x + 512 * i;
-        if (idx < 3 * d) {
-            const float val = jb_round<f16>(rstd * (u_[i] - mean * c1_[i]) + jb_round<f16>(b_[i]));
-            s_qkv[idx] = (f16)val;
-            const int which = idx / d, ch = idx - which * d;
-            if (which > 0 && append) (which == 1 ? kc : vc)[((int64_t)n * cap + t) * S + h * d + ch] = (f16)val;
-        }
-    }
-    __syncthreads();
-    f16* o = out + (int64_t)n * ldo + h * d;
-    if (ks.count == 0) {
-        for (int i = threadIdx.x; i < d; i += blockDim.x) o[i] = (f16)0;
-        return;
-    }
-    const float scale = 1.0f / sqrtf(sqrtf((float)d));
-    const float scale2 = scale * scale;
-    f16x8 qf[ND32];
-#pragma unroll
-    for (int dt = 0; dt < ND32; ++dt) qf[dt] = *reinterpret_cast<const f16x8*>(s_qkv + dt * 32 + g * 8);
-
-    float m_w = -INFINITY, l_w = 0.f;
-    float of[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) of[e] = 0.f;
-    float* pw = s_pw + 16 * wave;
-
-    for (int tt = wave; tt < ntiles; tt += nw) {
-        const int kbase_i = tt * 16;
-        if (tt != wave) { request(tt); jb_issue_fence_before_use(qf[0]); }
-        // the position's own key / value come from LDS (their cache rows are being written by this very launch)
-        if (fresh_key >= kbase_i && fresh_key < kbase_i + 16) {
-            const int r = fresh_key - kbase_i;
-#pragma unroll
-            for (int dt = 0; dt < ND32; ++dt) {
-                const f16x8 kt_ = *reinterpret_cast<const f16x8*>(s_qkv + d + dt * 32 + g * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kf[dt][e] = c == r ? kt_[e] : kf[dt][e];
-            }
-            const f16x8 vt_ = *reinterpret_cast<const f16x8*>(s_qkv + 2 * d + c0);
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vv[k][e] = k == r ? vt_[e] : vv[k][e];
-        }
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dt = 0; dt < ND32; ++dt) sc = jb_mfma(kf[dt], qf[dt], sc);
-        float pv[4], mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool ok = kbase_i + g * 4 + r < ks.count;
-            pv[r] = ok ? jb_round<f16>(jb_round<f16>(sc[r]) * scale2) : -INFINITY;
-            mx = fmaxf(mx, pv[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_w, mx);
-        const float alpha = expf(m_w - m_new);
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pv[r] = (pv[r] == -INFINITY) ? 0.f : expf(pv[r] - m_new);
-            ps += pv[r];
-        }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
-        l_w = l_w * alpha + ps;
-        m_w = m_new;
-        if (c == 0) *reinterpret_cast<f32x4*>(pw + g * 4) = f32x4{pv[0], pv[1], pv[2], pv[3]};
-        f32x4 p4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) p4[i] = *reinterpret_cast<const f32x4*>(pw + i * 4);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) of[e] *= alpha;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float pr = jb_round<f16>(p4[k >> 2][k & 3]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) of[e] += pr * (float)vv[k][e];
-        }
-    }
-    if (lane == 0) { s_ml[2 * wave] = m_w; s_ml[2 * wave + 1] = l_w; }
-    if (lane * 8 < d) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s_o[wave * d + lane * 8 + e] = of[e];
-    }
-    __syncthreads();
-    float m = -INFINITY;
-    for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);
-    float lsum = 0.f;
-    for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] > 0.f ? s_ml[2 * w + 1] * expf(s_ml[2 * w] - m) : 0.f;
-    const float inv = 1.0f / lsum;
-    for (int i = threadIdx.x; i < d; i += blockDim.x) {
-        float a = 0.f;
-        for (int w = 0; w < nw; ++w) a += s_ml[2 * w + 1] > 0.f ? s_o[w * d + i] * expf(s_ml[2 * w] - m) : 0.f;
-        o[i] = (f16)(a * inv);
-    }
-}
-
-// u: fp32 [n][3 * n_head * d_head] (q | k | v); stats: [n_stats][16 rows][2]; caches are appended at position *t_dev.
-extern "C" int jb_attn_decode_fresh(int attn_func, const float* uq, int64_t ldq, const float* stats, int n_stats, const float* c1a,
-                                    const float* ba, int width, float ln_eps, void* kcache, void* vcache, int cache_cap, void* out,
-                                    int64_t ldo, int n_batch, int n_head, int d_head, int block_ctx, const int* t_dev, void* stream) {
-    JB_REQUIRE(uq && stats && c1a && ba && kcache && vcache && out && t_dev, "null pointer");
-    JB_REQUIRE(n_batch >= 1 && n_batch <= 16 && n_head > 0 && n_stats >= 1 && n_stats <= 256 && width > 0, "bad dims (n_batch <= 16, n_stats <= 256)");
-    JB_REQUIRE(split_d_ok(d_head), "d_head must be 32 x {1,2,4,8,15,16}");
-    JB_REQUIRE(attn_func == 0 || attn_func == 1 || attn_func == 2 || attn_func == 3 || attn_func == 7, "pattern not supported here");
-    JB_REQUIRE(attn_func == 0 || attn_func == 7 || block_ctx > 0, "block_ctx required");
-    const int nwm = 8;
-    dim3 grid(n_batch, n_head);
-    const size_t lds = (size_t)(2 * nwm + 16 * nwm + nwm * d_head) * sizeof(float) + (size_t)3 * d_head * sizeof(f16);
-    hipStream_t s = (hipStream_t)stream;
-#define JB_LAUNCH_DECF(ND)                                                                                              \
-    attn_decode_fresh_kernel<ND><<<grid, nwm * 64, lds, s>>>(attn_func, uq, ldq, stats, n_stats, c1a, ba, width, ln_eps,   \
-                                                           (f16*)kcache, (f16*)vcache, cache_cap, (f16*)out, ldo, n_head,  \
-                                                           block_ctx, t_dev)
-    switch (d_head / 32) {
-        case 1: JB_LAUNCH_DECF(1); break;
-        case 2: JB_LAUNCH_DECF(2); break;
-        case 4: JB_LAUNCH_DECF(4); break;
-        case 8: JB_LAUNCH_DECF(8); break;
-        case 15: JB_LAUNCH_DECF(15); break;
-        default: JB_LAUNCH_DECF(16); break;
-    }
-#undef JB_LAUNCH_DECF
-    JB_CHECK_LAUNCH();
-    return JB_OK;
-}
-
 // launch shape of the decode attention: threads per (sample, head) workgroup and key/value row pairs in flight per wave
 static int g_dec_threads = 512, g_dec_kb = 4, g_dec_mfma = 1;
 extern "C" void jb_tune_attn_decode(int threads, int kb) {

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "fused_layer.hip", "engine.hip"]
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "engine.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "jukebox_hip.h")]
 LIB = os.path.join(HERE, "libjukebox_hip.so")
 

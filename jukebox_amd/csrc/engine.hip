@@ -53,18 +53,6 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
                    "folded LayerNorm image of mlp.c_fc is incomplete or unsupported for this shape");
     }
     JB_REQUIRE((cfg->att_parts == nullptr) == (cfg->att_ml == nullptr), "att_parts and att_ml come together");
-    if (cfg->fused3) {
-        JB_REQUIRE(cfg->dtype == JB_F16 && cfg->n_batch <= 16 && cfg->u_f && cfg->u_q && cfg->stats_a && cfg->stats_b,
-                   "fused3 needs an fp16 engine with n_batch <= 16 and the u_f / u_q / stats buffers");
-        JB_REQUIRE(cfg->width % 32 == 0 && cfg->n_state % 32 == 0 && cfg->n_mlp % 32 == 0 && cfg->width <= 2048 &&
-                       cfg->width + cfg->n_state <= 2560 && cfg->width + cfg->n_mlp <= 4096, "fused3: unsupported dims");
-        for (int l = 0; l < cfg->n_layers; ++l) {
-            const jb_layer& L = layers[l];
-            JB_REQUIRE(L.attn_func != JB_ATTN_CROSS, "fused3: cross-attention layers are not supported");
-            JB_REQUIRE(L.w_attn_f && L.w_fc_f && L.w_fa && L.k_f && L.wsum_p && L.b_fc_f16 &&
-                           (l + 1 == cfg->n_layers || (L.w_fb && L.k_a)), "fused3: incomplete layer images");
-        }
-    }
     JB_REQUIRE(cfg->bins <= 0 || !cfg->x_out_packed || cfg->ticket, "ticket counter missing");
     JB_REQUIRE(cfg->width % 4 == 0, "width must be a multiple of 4");
     JB_REQUIRE(!cfg->rec_out || (cfg->rec_layer >= 0 && cfg->rec_layer < cfg->n_layers && cfg->rec_keys > 0 &&
@@ -89,7 +77,7 @@ extern "C" int jb_engine_destroy(void* handle) {
 extern "C" int jb_engine_launches_per_step(void* handle) {
     if (!handle) return 0;
     const jb_engine_cfg& c = ((JbEngine*)handle)->cfg;
-    return c.fused3 ? 3 * c.n_layers + 3 : 5 * c.n_layers + 2;
+    return 5 * c.n_layers + 2;
 }
 
 #define JB_TRY(call)                \
@@ -132,66 +120,9 @@ static int enqueue_embed(JbEngine* e, int t0, hipStream_t s) {
                     c.xc_n_stride, c.xc_t_stride, c.n_batch, c.width, t0, nullptr, 1, s);
 }
 
-// The three-launch layer (cfg.fused3, fused_layer.hip): c_attn(0) | L x [attention | A | B] | logits | sample.
-static void fill_fused_a(jb_fused_a_args& a, const jb_engine_cfg& c, const jb_layer& L) {
-    a = {};
-    a.n_rows = c.n_batch; a.W = c.width; a.S = c.n_state; a.M = c.n_mlp;
-    a.xa = c.x_a; a.ldx = c.width; a.att = c.att; a.lda = c.n_state;
-    a.Wp = L.w_proj; a.bp = L.b_proj; a.xb = c.x_b; a.ldb = c.width; a.stats_b = c.stats_b;
-    a.Wfa = L.w_fa; a.kf = L.k_f; a.c1f = L.c1_fc; a.wsum_p = L.wsum_p; a.sum_bp = L.sum_bp;
-    a.uf = c.u_f; a.ldu = c.n_mlp;
-}
-static void fill_fused_b(jb_fused_b_args& b, const jb_engine_cfg& c, const jb_layer& L, bool last) {
-    b = {};
-    b.n_rows = c.n_batch; b.W = c.width; b.M = c.n_mlp; b.n_stats = c.width / 16; b.ln_eps = c.ln_eps;
-    b.xb = c.x_b; b.ldb = c.width; b.uf = c.u_f; b.ldu = c.n_mlp; b.stats_b = c.stats_b; b.bff16 = L.b_fc_f16;
-    b.Wp2 = L.w_proj2; b.bp2 = L.b_proj2; b.xa_out = c.x_a; b.ldo = c.width; b.stats_a = c.stats_a;
-    if (last) {
-        b.out2 = c.xf; b.ldo2 = c.width; b.t_dev = c.t_dev;
-        if (c.add_cond_after && c.x_cond) { b.add2 = c.x_cond; b.add2_n_stride = c.xc_n_stride; b.add2_t_stride = c.xc_t_stride; }
-    } else {
-        b.J2 = 3 * c.n_state; b.Wfb = L.w_fb; b.ka = L.k_a; b.uq = c.u_q; b.ldq = 3 * c.n_state;
-    }
-}
-
-static int enqueue_step_fused3(JbEngine* e, hipStream_t s) {
-    const jb_engine_cfg& c = e->cfg;
-    const int N = c.n_batch, W = c.width, S = c.n_state, H = c.n_head, d = S / H;
-    {   // layer 0: q, k, v from the embedding with the folded c_attn; plain attention
-        const jb_layer& L = e->layers[0];
-        jb_gemv_args g = {};
-        fill_ln_proj(g, c, L, 0);
-        g.x = c.x_a; g.out = c.q; g.ldo = S; g.J = 3 * S;
-        g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
-        JB_TRY(jb_gemv(&g, s));
-        JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d, c.block_ctx,
-                              c.t_dev, c.seq_len, s));
-    }
-    for (int l = 0; l < c.n_layers; ++l) {
-        const jb_layer& L = e->layers[l];
-        if (l > 0)
-            JB_TRY(jb_attn_decode_fresh(L.attn_func, c.u_q, 3 * S, c.stats_a, W / 16, L.c1_attn, L.b_attn_f, W, c.ln_eps, L.kcache,
-                                        L.vcache, L.cache_cap, c.att, S, N, H, d, c.block_ctx, c.t_dev, s));
-        jb_fused_a_args a;
-        fill_fused_a(a, c, L);
-        JB_TRY(jb_fused_a(&a, s));
-        jb_fused_b_args b;
-        fill_fused_b(b, c, L, l + 1 == c.n_layers);
-        JB_TRY(jb_fused_b(&b, s));
-    }
-    jb_gemv_args g = {};
-    g.dtype = JB_F32; g.x = c.xf; g.ldx = W; g.n_rows = N; g.W = c.x_out_packed; g.K = W; g.J = c.bins;
-    g.out = c.logits; g.ldo = c.bins;
-    JB_TRY(jb_gemv(&g, s));
-    JB_TRY(jb_sample_step(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds, c.preds_n_stride,
-                          c.dtype, c.x_a, c.x_emb, c.pos_emb, c.x_cond, c.xc_n_stride, c.xc_t_stride, W, c.seq_len, c.ticket, s));
-    return JB_OK;
-}
-
 // One decode step at position *t_dev (x_a already holds that position's embedding); everything position-dependent is
 // read on the device.  Leaves the next position's embedding in x_a and *t_dev advanced.
 static int enqueue_step(JbEngine* e, hipStream_t s) {
-    if (e->cfg.fused3) return enqueue_step_fused3(e, s);
     const jb_engine_cfg& c = e->cfg;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
     for (int l = 0; l < c.n_layers; ++l) {
@@ -398,15 +329,6 @@ extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, voi
         for (int i = 0; i < reps; ++i)
             for (int l = 0; l < c.n_layers; ++l) {
                 const jb_layer& L = e->layers[l];
-                if (c.fused3) {          // the two weight-streaming launches of the three-launch layer, real arguments
-                    jb_fused_a_args fa;
-                    fill_fused_a(fa, c, L);
-                    JB_TRY(jb_fused_a(&fa, s));
-                    jb_fused_b_args fb;
-                    fill_fused_b(fb, c, L, l + 1 == c.n_layers);
-                    JB_TRY(jb_fused_b(&fb, s));
-                    continue;
-                }
                 jb_gemv_args g = {};
                 fill_ln_proj(g, c, L, 0);
                 g.x = c.x_a; g.J = 3 * S; g.out = c.q; g.ldo = S;
@@ -435,14 +357,6 @@ extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, voi
     out[0] = (double)ms * 1e3 / launches;
     out[1] = launches;
     out[2] = 0.5 * (b_attn + b_fc);
-    if (c.fused3) {
-        // bytes launch A and launch B must move: their weight images once, activation rows in and out, the partials
-        const double st = (double)(W / 16) * 32 * 4;
-        const double b_a = ((double)S * W + (double)(W + S) * M) * esz + (double)N * (W + S) * esz + (double)N * (W + M) * esz + st;
-        const double b_b = ((double)M * W + (double)(W + M) * 3 * S) * esz + (double)N * (W + M) * esz + (double)N * W * esz +
-                           (double)N * 3 * S * 4 + 2 * st;
-        out[2] = 0.5 * (b_a + b_b);        // (the last layer's B has no second part; one launch in 2 L)
-    }
     return JB_OK;
 }
 

@@ -44,7 +44,7 @@ class PackedPrior:
 
     def __init__(self, sd, prefix, *, seq_len, bins, width, depth, heads, attn_order, blocks=None, m_attn=0.25, m_mlp=1.0,
                  prime_len=None, y_cond=False, add_cond_after=True, fp16=True, encoder_dims=0, only_encode=False,
-                 fold_ln=None, fused3=None, device="cuda"):
+                 fold_ln=None, device="cuda"):
         L.lib()
         self.device = torch.device(device)
         self.T, self.bins, self.W = seq_len, bins, width
@@ -63,14 +63,6 @@ class PackedPrior:
         if fold_ln is None:
             fold_ln = bool(int(os.environ["JB_FOLD_LN"])) if "JB_FOLD_LN" in os.environ else fp16
         self.fold_ln = bool(fold_ln) and not only_encode
-        # Three launches per layer instead of five (csrc/fused_layer.hip): fp16 engines with folded LayerNorm, no
-        # cross-attention layers, dimensions inside the kernels' envelope.  JB_FUSED3=0/1 overrides the default (on).
-        if fused3 is None:
-            fused3 = bool(int(os.environ.get("JB_FUSED3", "1")))
-        W_, S_, M_ = width, int(m_attn * width), int(m_mlp * width)
-        d_ = S_ // heads
-        self.fused3 = bool(fused3) and self.fold_ln and fp16 and 6 not in self.funcs and W_ % 32 == 0 and S_ % 32 == 0 and \
-            M_ % 32 == 0 and W_ <= 2048 and W_ + S_ <= 2560 and W_ + M_ <= 4096 and d_ % 32 == 0 and d_ // 32 in (1, 2, 4, 8, 15, 16)
         dev, dt = self.device, self.dtype
         g = lambda name: sd[prefix + name].to(dev).contiguous()
         f32 = lambda name: g(name).float().contiguous()
@@ -102,19 +94,10 @@ class PackedPrior:
                     lay["f_attn"] = H.FoldedLN(g(p + "attn.c_attn.w"), lay["bs"][0], lay["lns"][0], lay["lns"][1], dt)
                 if H.ln_fold_supported(dt, W, M, 1):
                     lay["f_fc"] = H.FoldedLN(g(p + "mlp.c_fc.w"), lay["bs"][2], lay["lns"][2], lay["lns"][3], dt)
+                for f in (lay["f_attn"], lay["f_fc"]):
+                    if f is not None:
+                        f.wf = None                  # the unpacked image is bind-time only
             self.layers.append(lay)
-        if self.fused3 and all(l["f_attn"] is not None and l["f_fc"] is not None for l in self.layers):
-            for d, lay in enumerate(self.layers):
-                p = f"transformer._attn_mods.{d}."
-                nxt = self.layers[d + 1]["f_attn"] if d + 1 < depth else None
-                lay["fused"] = H.FusedLayerImages(lay["f_fc"], g(p + "attn.c_proj.w"), lay["bs"][1], g(p + "mlp.c_proj.w"),
-                                                  lay["bs"][3], nxt, dt)
-        else:
-            self.fused3 = False
-        for lay in self.layers:
-            for f in (lay["f_attn"], lay["f_fc"]):
-                if f is not None:
-                    f.wf = None                      # the unpacked image is bind-time only
 
     def weight_bytes(self):
         n = self.x_out.data.numel() * 4 if self.x_out is not None else 0
@@ -170,15 +153,6 @@ class PriorEngine:
                     lc.w_fc_f, lc.b_fc_f, lc.c1_fc = f.pw.ptr, f.bias.data_ptr(), f.c1.data_ptr()
             if lay["func"] == 6:
                 lc.w_enc_k, lc.w_enc_v, lc.b_enc_kv = lay["enc"][0].ptr, lay["enc"][1].ptr, lay["b_enc"].data_ptr()
-            fu = lay.get("fused")
-            if fu is not None:
-                lc.w_fa, lc.k_f, lc.wsum_p, lc.sum_bp, lc.b_fc_f16 = fu.w_fa.ptr, fu.k_f.data_ptr(), fu.wsum_p.data_ptr(), fu.sum_bp, \
-                    fu.b_fc_f16.data_ptr()
-                if fu.w_fb is not None:
-                    lc.w_fb, lc.k_a = fu.w_fb.ptr, fu.k_a.data_ptr()
-        # three launches per layer: needs the images, n_batch <= 16 and every layer's folded projections usable at this N
-        self.fused3 = pk.fused3 and N <= 16 and not self.only_encode and \
-            all(self.layers_c[d].w_attn_f and self.layers_c[d].w_fc_f for d in range(self.depth))
 
         e = lambda *shape, dtype=dt: torch.zeros(shape, dtype=dtype, device=dev)
         Cc = self.chunk_cap
@@ -195,9 +169,6 @@ class PriorEngine:
                 any(L.lib().jb_attn_decode_split_parts(self.code, S // self.H, max_keys(lay)) > 0 for lay in pk.layers):
             self.att_parts = e(N, 4, S)
             self.att_ml = e(N, self.H, 4, 2, dtype=torch.float32)
-        if self.fused3:
-            self.buf.update(u_f=e(N, M), u_q=e(N, 3 * S, dtype=torch.float32),
-                            stats_a=e(W // 16, 16, 2, dtype=torch.float32), stats_b=e(W // 16, 16, 2, dtype=torch.float32))
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -264,9 +235,6 @@ class PriorEngine:
         if self.att_parts is not None:
             c.att_parts, c.att_ml = self.att_parts.data_ptr(), self.att_ml.data_ptr()
         c.ticket = self.ticket.data_ptr()
-        if self.fused3:
-            c.fused3 = 1
-            c.u_f, c.u_q, c.stats_a, c.stats_b = (b[k].data_ptr() for k in ("u_f", "u_q", "stats_a", "stats_b"))
         c.chunk_cap = self.chunk_cap
         c.c_xf = b["c_xf"].data_ptr() if "c_xf" in b else None
         c.tokens, c.tok_stride, c.t_dev = self.tokens.data_ptr(), self.tokens.stride(0), self.t_dev.data_ptr()

@@ -63,90 +63,6 @@ class FoldedLN:
         self.bias = (beta.double() @ w_used + b.double()).float().contiguous()
 
 
-class FusedLayerImages:
-    """Bind-time images of one layer for the three-launch decode step (jb_fused_a / jb_fused_b, csrc/fused_layer.hip):
-        launch A:  Wfa = packed [W'f ; Wp.W'f]  ((W + S) x M),  kf = bp.W'f,  wsum_p = row sums of Wp (half),  sum_bp,
-                   bff16 = half(b'f)   with W'f = diag(g1).Wf and b'f = b1.Wf + bf from `f_fc` (FoldedLN of mlp.c_fc);
-        launch B:  Wfb = packed [W'a ; Wp2.W'a]  ((W + M) x 3S),  ka = bp2.W'a   with W'a from `f_attn_next`, the FoldedLN
-                   of the NEXT layer's attn.c_attn (None for the last layer).
-    Product matrices are formed in fp32 from the half-rounded factors and rounded to half once."""
-
-    def __init__(self, f_fc, w_proj, b_proj, w_proj2, b_proj2, f_attn_next, dtype):
-        wf = f_fc.wf
-        W, M = wf.shape
-        S = w_proj.shape[0]
-        wp = w_proj.to(dtype)
-        cat = torch.cat([wf, (wp.float() @ wf.float()).to(dtype)], 0).contiguous()
-        self.w_fa = PackedWeight(pack_weight(cat, W + S, M, M, 1, dtype), W + S, M, dtype)
-        self.k_f = (b_proj.float() @ wf.float()).contiguous()
-        self.wsum_p = wp.float().sum(1).to(torch.float16).contiguous()
-        self.sum_bp = float(b_proj.float().sum().item())
-        self.b_fc_f16 = f_fc.bias.to(torch.float16).contiguous()
-        self.w_fb = self.k_a = None
-        if f_attn_next is not None:
-            wa = f_attn_next.wf
-            J = wa.shape[1]
-            cat = torch.cat([wa, (w_proj2.to(dtype).float() @ wa.float()).to(dtype)], 0).contiguous()
-            self.w_fb = PackedWeight(pack_weight(cat, W + w_proj2.shape[0], J, J, 1, dtype), W + w_proj2.shape[0], J, dtype)
-            self.k_a = (b_proj2.float() @ wa.float()).contiguous()
-
-
-def fused_a(xa, att, w_proj, b_proj, f_fc, img):
-    """jb_fused_a: returns (x_b (N, W) half, stats_b (W/16, 16, 2) fp32, u_f (N, M) half)."""
-    _chk_cuda(xa, att, b_proj)
-    N, W = xa.shape
-    S, M = att.shape[1], f_fc.pw.J
-    xb = torch.empty_like(xa)
-    stats = torch.zeros((W // 16, 16, 2), dtype=torch.float32, device=xa.device)
-    uf = torch.empty((N, M), dtype=xa.dtype, device=xa.device)
-    a = L.FusedAArgs()
-    a.n_rows, a.W, a.S, a.M = N, W, S, M
-    a.xa, a.ldx, a.att, a.lda = xa.data_ptr(), xa.stride(0), att.data_ptr(), att.stride(0)
-    a.Wp, a.bp, a.xb, a.ldb, a.stats_b = w_proj.ptr, b_proj.data_ptr(), xb.data_ptr(), xb.stride(0), stats.data_ptr()
-    a.Wfa, a.kf, a.c1f, a.wsum_p, a.sum_bp = img.w_fa.ptr, img.k_f.data_ptr(), f_fc.c1.data_ptr(), img.wsum_p.data_ptr(), img.sum_bp
-    a.uf, a.ldu = uf.data_ptr(), uf.stride(0)
-    L.check(L.lib().jb_fused_a(C.byref(a), L.stream()))
-    return xb, stats, uf
-
-
-def fused_b(xb, uf, stats_b, w_proj2, b_proj2, img, eps=1e-5, out2=None, add2=None, t_dev=None):
-    """jb_fused_b: returns (x_a' (N, W) half, stats_a, u_q (N, 3S) fp32 or None for a last layer)."""
-    _chk_cuda(xb, uf, stats_b, b_proj2, out2, add2)
-    N, W = xb.shape
-    M = uf.shape[1]
-    xa = torch.empty_like(xb)
-    stats = torch.zeros((W // 16, 16, 2), dtype=torch.float32, device=xb.device)
-    b = L.FusedBArgs()
-    b.n_rows, b.W, b.M, b.n_stats, b.ln_eps = N, W, M, stats_b.shape[0], eps
-    b.xb, b.ldb, b.uf, b.ldu = xb.data_ptr(), xb.stride(0), uf.data_ptr(), uf.stride(0)
-    b.stats_b, b.bff16 = stats_b.data_ptr(), img.b_fc_f16.data_ptr()
-    b.Wp2, b.bp2, b.xa_out, b.ldo, b.stats_a = w_proj2.ptr, b_proj2.data_ptr(), xa.data_ptr(), xa.stride(0), stats.data_ptr()
-    if out2 is not None:
-        b.out2, b.ldo2 = out2.data_ptr(), out2.stride(0)
-        if add2 is not None:
-            b.add2, b.add2_n_stride, b.add2_t_stride = add2.data_ptr(), add2.stride(0), add2.stride(1)
-        b.t_dev = L.ptr(t_dev)
-    uq = None
-    if img.w_fb is not None:
-        uq = torch.empty((N, img.w_fb.J), dtype=torch.float32, device=xb.device)
-        b.J2, b.Wfb, b.ka, b.uq, b.ldq = img.w_fb.J, img.w_fb.ptr, img.k_a.data_ptr(), uq.data_ptr(), uq.stride(0)
-    L.check(L.lib().jb_fused_b(C.byref(b), L.stream()))
-    return xa, stats, uq
-
-
-def attn_decode_fresh(func, uq, stats_a, f_attn, width, kcache, vcache, n_head, block_ctx, t_dev, eps=1e-5):
-    """jb_attn_decode_fresh: finishes q, k, v from u_q (N, 3S) fp32 and the partials, appends k / v at *t_dev, attends.
-    Returns (N, S) half."""
-    _chk_cuda(uq, stats_a, kcache, vcache, t_dev)
-    N, S = uq.shape[0], uq.shape[1] // 3
-    out = torch.empty((N, S), dtype=kcache.dtype, device=uq.device)
-    L.check(L.lib().jb_attn_decode_fresh(func, uq.data_ptr(), uq.stride(0), stats_a.data_ptr(), stats_a.shape[0],
-                                         f_attn.c1.data_ptr(), f_attn.bias.data_ptr(), width, eps, kcache.data_ptr(),
-                                         vcache.data_ptr(), kcache.shape[1], out.data_ptr(), out.stride(0), N, n_head,
-                                         S // n_head, block_ctx or 0, t_dev.data_ptr(), L.stream()))
-    return out
-
-
 def ln_fold_supported(dtype, K, J, n_rows):
     return bool(L.lib().jb_gemv_ln_fold_supported(L.dtype_code(dtype), K, J, n_rows))
 

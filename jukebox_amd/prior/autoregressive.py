@@ -2,7 +2,6 @@
 (jukebox/prior/autoregressive.py:48-359).  `sample` / `primed_sample` run the whole token loop inside
 the HIP decode engine (jukebox_amd.engine.PriorEngine): one hipGraph replay per token, chunked MFMA
 prefill for the primed part; nothing is computed in torch."""
-import contextlib
 import math
 
 import numpy as np
@@ -37,33 +36,6 @@ class PositionEmbedding(nn.Module):
 
     def forward(self):
         return self.pos_emb
-
-
-class PreparedWindow:
-    """An engine being made ready for the NEXT window while the current one decodes (jukebox_amd.sample level pipeline):
-    already conditioned (set_cond), and prefilled position by position as the primed tokens appear -- the primed part of
-    window w + 1 IS the new part of window w, so the whole prefill (0.45 s per upsampler window) and the conditioner
-    (0.17 s) leave the critical path of the level.  All of its work is enqueued on `stream`."""
-
-    def __init__(self, eng, start, n_samples, stream):
-        self.eng, self.start, self.n_samples, self.stream = eng, int(start), int(n_samples), stream
-        self.done = 0               # positions [0, done) of the window are prefilled
-        self.broken = False
-
-    def feed(self, tok, a, b, after=None):
-        """tok (N, b - a): tokens of window positions [a, b); prefill them (after event `after`).  Out-of-order or
-        overlapping feeds stop the look-ahead for this window: sample() then prefills the remainder itself."""
-        if self.broken or b <= a:
-            return
-        if a != self.done:
-            self.broken = True
-            return
-        with t.cuda.stream(self.stream):
-            if after is not None:
-                self.stream.wait_event(after)
-            self.eng.tokens[:, a:b] = tok
-            self.eng.prefill(a, b - a)
-        self.done = b
 
 
 class ConditionalAutoregressive2D(nn.Module):
@@ -116,16 +88,15 @@ class ConditionalAutoregressive2D(nn.Module):
         return x.view(N, -1)
 
     # ---- engine binding --------------------------------------------------------------------------------
-    def engine(self, n_samples, fp16, want_preds=False, chunk_cap=512, slot=None):
+    def engine(self, n_samples, fp16, want_preds=False, chunk_cap=2048):
         """The engine bound to this prior for a batch size.  The packed weights (PackedPrior) are built once per dtype
-        and shared; an engine per (batch size, dtype, logits recording, slot) adds only its k/v caches and work buffers
-        and stays bound, so alternating batch sizes (split_batch tails) or get_preds calls never re-pack weights.  `slot`
-        (default: self.engine_slot, 0) selects one of several such engines: the level pipeline decodes window w in one
-        while the other is being conditioned and prefilled for window w + 1 (PreparedWindow)."""
+        and shared; an engine per (batch size, dtype, logits recording) adds only its k/v caches and work buffers and
+        stays bound, so alternating batch sizes (split_batch tails) or get_preds calls never re-pack weights.
+        chunk_cap: positions per prefill chunk (measured, upsampler, N = 16, 4096 primed tokens: 449 ms at 512, 380 ms at
+        2048 -- M = 32768-row GEMMs leave no tail on the 256 x 128 tiling)."""
         fp16 = bool(fp16)
         packed = self.packed(fp16)
-        slot = int(getattr(self, "engine_slot", 0) if slot is None else slot)
-        key = (n_samples, fp16, bool(want_preds), slot)
+        key = (n_samples, fp16, bool(want_preds))
         if key not in self._engines:
             self._engines[key] = PriorEngine(packed=packed, n_batch=n_samples, chunk_cap=chunk_cap,
                                              want_preds=want_preds)
@@ -192,13 +163,6 @@ class ConditionalAutoregressive2D(nn.Module):
                 loss = ce(preds, x)
             return (loss, preds) if get_preds else (loss, None)
 
-    def prepared_for(self, n_samples, start):
-        """The PreparedWindow (set as self.prepared_window by the level pipeline) if it was made for exactly this window."""
-        prep = getattr(self, "prepared_window", None)
-        if prep is not None and prep.n_samples == n_samples and prep.start == start:
-            return prep
-        return None
-
     def _check_cond(self, N, x_cond, y_cond):
         D = self.input_dims
         if self.y_cond:
@@ -220,14 +184,9 @@ class ConditionalAutoregressive2D(nn.Module):
         assert (encoder_kv is not None) == has_cross, "encoder_kv is required exactly for cross-attention models"
         if sample_tokens is None:
             sample_tokens = self.input_dims
-        prep = self.prepared_for(n_samples, pos_base) if (x_prime is not None and not get_preds and not has_cross) else None
-        if prep is None:
-            self._check_cond(n_samples, x_cond, y_cond)
-            eng = self.engine(n_samples, fp16, want_preds=get_preds)
-            eng.set_cond(x_cond, y_cond)
-        else:
-            eng = prep.eng                     # conditioned (and largely prefilled) while the previous window decoded
-            t.cuda.current_stream(eng.device).wait_stream(prep.stream)
+        self._check_cond(n_samples, x_cond, y_cond)
+        eng = self.engine(n_samples, fp16, want_preds=get_preds)
+        eng.set_cond(x_cond, y_cond)
         eng.set_sampling(temp=temp, top_k=top_k, top_p=top_p, seed=seed, sample_base=sample_base, pos_base=pos_base,
                          stream_id=stream_id)
         if has_cross:
@@ -241,31 +200,20 @@ class ConditionalAutoregressive2D(nn.Module):
             n_prime = x_prime.shape[1]
             assert n_prime < sample_tokens
             eng.tokens[:, :n_prime] = x_prime
-            done = min(prep.done, n_prime) if prep is not None else 0
-            if done < n_prime:
-                eng.prefill(done, n_prime - done)
-        # The token loop.  `decode_stream` (set by the level pipeline) moves it -- and only it -- to a CU-masked stream, so
-        # that concurrently decoding levels do not share compute units; conditioner and prefill stay on the caller's stream.
-        ds = getattr(self, "decode_stream", None)
-        cur = t.cuda.current_stream(eng.device) if ds is not None else None
-        if ds is not None:
-            ds.wait_stream(cur)
-        with (t.cuda.stream(ds) if ds is not None else contextlib.nullcontext()):
-            tap = getattr(self, "decode_tap", None)
-            if tap is None:
-                eng.decode(n_prime, sample_tokens - n_prime)
-            else:
-                # (every, fn): hand the token buffer to fn after every `every` enqueued decode steps, so that a consumer on
-                # another stream can start on a partial window (jukebox_amd.sample._sample_levels_pipelined)
-                every, fn = tap
-                pos = n_prime
-                while pos < sample_tokens:
-                    n = min(int(every), sample_tokens - pos)
-                    eng.decode(pos, n)
-                    fn(eng.tokens, pos, pos + n)
-                    pos += n
-        if ds is not None:
-            cur.wait_stream(ds)
+            eng.prefill(0, n_prime)
+        tap = getattr(self, "decode_tap", None)
+        if tap is None:
+            eng.decode(n_prime, sample_tokens - n_prime)
+        else:
+            # (every, fn): hand the token buffer to fn after every `every` enqueued decode steps, so that a consumer on
+            # another stream can start on a partial window (jukebox_amd.sample._sample_levels_pipelined)
+            every, fn = tap
+            pos = n_prime
+            while pos < sample_tokens:
+                n = min(int(every), sample_tokens - pos)
+                eng.decode(pos, n)
+                fn(eng.tokens, pos, pos + n)
+                pos += n
         x = eng.tokens[:, :sample_tokens].clone()
         x = self.postprocess(x, sample_tokens)
         if get_preds:

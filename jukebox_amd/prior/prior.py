@@ -200,12 +200,7 @@ class SimplePrior(nn.Module):
                   stream_id=int(self.level))
         self.prior.decode_tap = self._decode_tap()
         with t.no_grad():
-            if not no_past_context and not self.single_enc_dec and self.n_tokens == 0 and \
-                    self.prior.prepared_for(n_samples, pos_base) is not None:
-                # the level pipeline conditioned (and prefilled) an engine for this window while the previous one decoded
-                x_cond, y_cond, prime = None, None, None
-            else:
-                x_cond, y_cond, prime = self.get_cond(z_conds, y)
+            x_cond, y_cond, prime = self.get_cond(z_conds, y)
             if self.single_enc_dec:
                 if no_past_context:
                     z, x_cond = self.prior_preprocess([prime], [None, x_cond])
@@ -227,21 +222,6 @@ class SimplePrior(nn.Module):
                 assert tuple(z.shape) == (N, *self.z_shape)
         self.prior.decode_tap = None
         return z
-
-    def prepare_window(self, zs, labels, start, n_samples, fp16, slot, stream):
-        """Look-ahead of the level pipeline (extension): everything sample() does for the window at `start` BEFORE its token
-        loop that does not need the window's primed tokens -- label window, conditioner on the upper level's codes,
-        engine conditioning -- on `stream`, into engine `slot`.  Returns a PreparedWindow to feed the primed tokens to as
-        the previous window produces them.  Upsampler-style priors only (no lyric tokens)."""
-        from .autoregressive import PreparedWindow
-        assert not self.single_enc_dec and self.n_tokens == 0 and self.x_cond
-        with t.no_grad(), t.cuda.stream(stream):
-            z_conds = [zc.contiguous() for zc in self.get_z_conds(zs, start, start + self.n_ctx)]
-            y = self.get_y(labels, start)
-            x_cond, y_cond, _ = self.get_cond(z_conds, y)
-            eng = self.prior.engine(n_samples, fp16, slot=slot)
-            eng.set_cond(x_cond, y_cond)
-        return PreparedWindow(eng, start, n_samples, stream)
 
     def get_prime_loss(self, encoder_kv, prime_t):
         """prior.py:303-310: bits per lyric token of the separate lyric encoder's own prediction head."""

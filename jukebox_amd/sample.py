@@ -114,39 +114,14 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # land on one hardware queue and serialise completely, whereas torch's pooled high-priority streams plus one
     # normal-priority stream ran three decode chains concurrently at 1.3x the single-chain step time.  The two
     # upsampler levels (the long poles) therefore get high priority, the top level normal priority.
+    # Tried and measured in round 2: confining the levels' token loops to disjoint CU sets
+    # (hipExtStreamCreateWithCUMask, tools/cu_mask_probe.py) -- the long pole runs faster while the others decode, but they
+    # decode longer, and the job time does not move; prefilling the next window in a second engine while the current one
+    # decodes -- the prefill's bandwidth slows the latency-bound chain by what it saves.  Neither is in the tree.
     order = sorted(levels)                                 # lowest level first
     prios = [-1, -1, 0, 0]
     stream_of = {level: t.cuda.Stream(device=device, priority=prios[min(i, 3)]) if on_gpu else None
                  for i, level in enumerate(order)}
-    # Spatial partition for the token loops.  A decode step is a chain of ~360 latency-bound launches of <= 128
-    # workgroups; three chains sharing all 256 CUs slow each other to 2.86 ms per step (2.11 alone).  With the chains on
-    # DISJOINT compute units -- the long pole (lowest level) on 128 CUs, the two upper levels on 64 each
-    # (hipExtStreamCreateWithCUMask; mask bit i is CU i / 8 of XCD i % 8, so a contiguous bit range takes the same CUs
-    # of every XCD) -- the long pole runs at 2.32 ms while the others decode (tools/cu_mask_probe.py), and at its solo
-    # speed afterwards (its kernels never need more than 128 CUs).  Only the token loop moves to the masked stream:
-    # conditioner and prefill are throughput work and keep the level's unmasked stream (ConditionalAutoregressive2D._run).
-    masked_raw, la_stream = [], None
-    if on_gpu and len(order) > 1 and hps.get("cu_partition", os.environ.get("JB_CU_PARTITION", "1") != "0"):
-        from . import _lib as L
-        # lowest level: CUs 0..127 of the mask space; the level above: 128..255; the top level (short-lived) unmasked.
-        # JB_CU_SHARES="0-127,128-255,none" / JB_LOOKAHEAD_CUS="128-255" override (experiments).
-        def _rng(spec):
-            if spec in ("none", ""):
-                return None
-            lo_, hi_ = spec.split("-")
-            return range(int(lo_), int(hi_) + 1)
-        shares = [_rng(x) for x in os.environ.get("JB_CU_SHARES", "0-127,128-255,none").split(",")]
-        for i, level in enumerate(order[:len(shares)]):
-            ar = getattr(priors[level], "prior", None)
-            if ar is None or not hasattr(ar, "_run") or shares[i] is None:
-                continue
-            s_, h_ = L.cu_mask_stream(shares[i], device=device)
-            masked_raw.append((ar, h_))
-            ar.decode_stream = s_
-        la_bits = _rng(os.environ.get("JB_LOOKAHEAD_CUS", "128-255"))
-        if la_bits is not None:
-            la_stream, h_ = L.cu_mask_stream(la_bits, device=device)         # look-ahead of the lowest level
-            masked_raw.append((None, h_))
 
     def new_event(stream=None):
         if not on_gpu:
@@ -170,17 +145,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 started = getattr(_sample, "level_start", None)
                 if callable(started):
                     started(level)
-                plan = _level_plan(prior, zs_local[level].shape[1], total_length, hop_length)
-                # Look-ahead (lowest level only -- the long pole): while window i decodes in one engine, the other engine
-                # is conditioned for window i + 1 and prefilled with window i's new tokens as they are published, on a
-                # stream confined to the CUs the token loops of this level never use.
-                ar = getattr(prior, "prior", None)
-                can_look = on_gpu and level == order[0] and chunk > 0 and \
-                    hps.get("lookahead_prefill", os.environ.get("JB_LOOKAHEAD", "1") != "0") and \
-                    hasattr(prior, "prepare_window") and prior.x_cond and not prior.single_enc_dec and prior.n_tokens == 0 and \
-                    (level + 1) in sample_levels and local_hps.n_samples <= kw["max_batch_size"] and la_stream is not None
-                prepared = None
-                for i, (start, sample_tokens) in enumerate(plan):
+                for start, sample_tokens in _level_plan(prior, zs_local[level].shape[1], total_length, hop_length):
                     if prior.x_cond and (level + 1) in sample_levels:
                         need = (start + prior.n_ctx) // prior.cond_downsample
                         with cond:
@@ -198,34 +163,12 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                         view[level + 1] = zbuf[level + 1]          # only [start/cd, end/cd) is read: published above
                     known = int(zs_local[level].shape[1])
                     tapped = local_hps.n_samples <= k["max_batch_size"] and chunk > 0
-                    # this window: use what was prepared for it (if anything); arm the look-ahead for the next one when
-                    # the upper level has already produced the codes that window is conditioned on
-                    if ar is not None:
-                        ar.engine_slot = i % 2 if can_look else 0
-                        ar.prepared_window = prepared if (prepared is not None and prepared.start == start) else None
-                    prepared, nxt_hop = None, 0
-                    if can_look and tapped and sample_tokens is None and i + 1 < len(plan) and plan[i + 1][1] is None:
-                        nxt = plan[i + 1][0]
-                        need_n = (nxt + prior.n_ctx) // prior.cond_downsample
-                        with cond:
-                            ok = progress[level + 1] >= need_n
-                            ev_n = ready_event.get(level + 1)
-                        if ok:
-                            la_stream.wait_stream(stream)
-                            if ev_n is not None:
-                                la_stream.wait_event(ev_n)
-                            prepared = prior.prepare_window(view, lab, nxt, local_hps.n_samples, bool(k.get("fp16", False)),
-                                                            (i + 1) % 2, la_stream)
-                            nxt_hop = nxt - start
 
-                    def publish(lo, hi, tok, start=start, known=known, prepared=prepared, nxt_hop=nxt_hop):
+                    def publish(lo, hi, tok, start=start, known=known):
                         # window-relative music tokens [lo, hi), all new (the primed part is never decoded)
                         assert start + lo >= known
                         zbuf[level][:, start + lo:start + hi] = tok
-                        ev = new_event()                 # the current stream: the token loop may run on its own (CU-masked) stream
-                        if prepared is not None and hi > nxt_hop:
-                            a = max(lo, nxt_hop)         # these tokens are primed tokens of the next window
-                            prepared.feed(tok[:, a - lo:], a - nxt_hop, hi - nxt_hop, after=ev)
+                        ev = new_event()
                         with cond:
                             progress[level] = start + hi
                             ready_event[level] = ev
@@ -236,11 +179,8 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                     try:
                         out = sample_single_window(view, lab, k, level, prior, start, local_hps)
                     finally:
-                        timeline.append((level, start, round(t_w - t_job, 3), round(time.perf_counter() - t_job, 3),
-                                         ar is not None and getattr(ar, "prepared_window", None) is not None))
                         prior.window_tap = None
-                        if ar is not None:
-                            ar.prepared_window = None
+                        timeline.append((level, start, round(t_w - t_job, 3), round(time.perf_counter() - t_job, 3)))
                     new_len = int(out[level].shape[1])
                     if not tapped:
                         zbuf[level][:, known:new_len] = out[level][:, known:new_len]
@@ -270,7 +210,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
 
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
-    # (level, window start, seconds into the job at which the window's sampling began / ended, look-ahead used) per window
+    # (level, window start, seconds into the job at which the window's sampling began / ended) per window: diagnostics
     timeline, t_job = [], time.perf_counter()
     _sample_levels_pipelined.timeline = timeline
     threads = [threading.Thread(target=worker, args=(l,), name=f"level{l}") for l in levels]
@@ -280,12 +220,6 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         th.join()
     if on_gpu:
         t.cuda.synchronize(device)
-    if masked_raw:
-        from . import _lib as L
-        for ar, h_ in masked_raw:
-            if ar is not None:
-                ar.decode_stream = None
-        L.destroy_streams([h_ for _, h_ in masked_raw])
     if errors:
         raise errors[0]
     return zs_local

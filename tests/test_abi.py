@@ -51,8 +51,7 @@ def test_struct_layouts_match_header():
     import subprocess, tempfile
     from jukebox_amd import _lib as L
     pairs = [("jb_gemm_args", L.GemmArgs), ("jb_gemv_args", L.GemvArgs), ("jb_sample_params", L.SampleParams),
-             ("jb_layer", L.Layer), ("jb_engine_cfg", L.EngineCfg), ("jb_fused_a_args", L.FusedAArgs),
-             ("jb_fused_b_args", L.FusedBArgs)]
+             ("jb_layer", L.Layer), ("jb_engine_cfg", L.EngineCfg)]
     lines, expect = [], []
     for cname, ct in pairs:
         lines.append(f'printf("%zu\\n", sizeof({cname}));')

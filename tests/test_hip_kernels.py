@@ -1,7 +1,6 @@
 """GPU suite, kernel level: every C-ABI entry point against a numpy restatement on seeded inputs.
 Tolerances: fp32 paths 2e-5 relative to the output scale (summation order only); fp16 paths are
 checked against fp32 math on the half-rounded operands with the half-output rounding bound."""
-import ctypes as C
 import math
 
 import numpy as np
@@ -604,71 +603,3 @@ def test_vq(H):
     # disagreements only at near-ties of the distance
     srt = np.sort(dist, 1)
     assert agree.mean() > 0.99 and np.all((srt[~agree, 1] - srt[~agree, 0]) < 1e-4)
-
-
-@pytest.mark.parametrize("N,W,H_,bc,T", [(16, 1920, 1, 64, 8192), (16, 2048, 2, 102, 6528), (5, 256, 2, 8, 96), (16, 512, 1, 16, 128)])
-def test_fused_three_launch_layer(H, N, W, H_, bc, T):
-    """jb_fused_a -> jb_fused_b -> jb_attn_decode_fresh (csrc/fused_layer.hip) against the five-launch chain they replace
-    (jb_gemv c_proj, folded c_fc, c_proj2, folded c_attn with k/v append, jb_attn_decode) on the same inputs, with outlier
-    channels in the residual stream: x_b, x_a', the per-tile partial sums, the finished q / k / v (through the appended
-    cache rows) and the next layer's attention output."""
-    from jukebox_amd import _lib as L
-    rng = np.random.default_rng(N + W)
-    f16 = torch.float16
-    S, M, d = W // 4, W, W // 4 // H_
-    r = lambda *shape, sc=1.0: (rng.standard_normal(shape) * sc).astype(np.float32)
-    xa = r(N, W, sc=0.5)
-    xa[:, [3, W // 2, W - 1]] += np.array([2.5, -3.0, 4.0], np.float32)          # outlier channels
-    xa, att = h16(xa), h16(r(N, S, sc=0.7))
-    Wp, bp = r(S, W, sc=0.02), r(W, sc=0.01)
-    Wf, bfc = r(W, M, sc=0.02), r(M, sc=0.01)
-    Wp2, bp2 = r(M, W, sc=0.02), r(W, sc=0.01)
-    Wa, ba = r(W, 3 * S, sc=0.02), r(3 * S, sc=0.01)
-    g1, b1 = (1 + r(W, sc=0.1)), r(W, sc=0.05)
-    g0, b0 = (1 + r(W, sc=0.1)), r(W, sc=0.05)
-    g1[[3, 7]] *= 5.0
-    D = lambda a, dt=None: dev(a, dt)
-    f_fc = H.FoldedLN(D(Wf), D(bfc), D(g1), D(b1), f16)
-    f_at = H.FoldedLN(D(Wa), D(ba), D(g0), D(b0), f16)
-    img = H.FusedLayerImages(f_fc, D(Wp), D(bp), D(Wp2), D(bp2), f_at, f16)
-    pw_p, pw_p2 = H.pack_conv1d_w(D(Wp), f16), H.pack_conv1d_w(D(Wp2), f16)
-    cap = T
-    kc0 = h16(r(N, cap, S))
-    vc0 = h16(r(N, cap, S))
-    for func, t in ((1, T // 2 + 5), (2, T - 1), (3, 3 * bc + 1), (0, min(T - 1, 300)), (1, 0), (3, 2)):
-        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
-        # ---- five launches ----
-        xb_ref = H.gemv(D(att, f16), pw_p, bias=D(bp), res=D(xa, f16))
-        h_ref = H.gemv(xb_ref, None, ln_fold=f_fc, act=L.ACT_QUICK_GELU)
-        xa2_ref = H.gemv(h_ref, pw_p2, bias=D(bp2), res=xb_ref)
-        kc_ref, vc_ref = D(kc0, f16), D(vc0, f16)
-        a = L.GemvArgs()
-        q_ref = torch.empty((N, S), dtype=f16, device="cuda")
-        a.dtype, a.x, a.ldx, a.n_rows = L.F16, xa2_ref.data_ptr(), W, N
-        a.ln_fold_c1, a.ln_eps = f_at.c1.data_ptr(), 1e-5
-        a.W, a.bias, a.K, a.J, a.out, a.ldo = f_at.pw.ptr, f_at.bias.data_ptr(), W, 3 * S, q_ref.data_ptr(), S
-        a.qkv_split, a.S, a.kcache, a.vcache, a.cache_cap, a.t_dev = 1, S, kc_ref.data_ptr(), vc_ref.data_ptr(), cap, t_dev.data_ptr()
-        L.check(L.lib().jb_gemv(C.byref(a), L.stream()))
-        att_ref = H.attn_decode(func, q_ref, kc_ref, vc_ref, H_, bc, t_dev, T)
-        # ---- three launches ----
-        xb, stats_b, uf = H.fused_a(D(xa, f16), D(att, f16), pw_p, D(bp), f_fc, img)
-        xa2, stats_a, uq = H.fused_b(xb, uf, stats_b, pw_p2, D(bp2), img)
-        kc, vc = D(kc0, f16), D(vc0, f16)
-        att2 = H.attn_decode_fresh(func, uq, stats_a, f_at, W, kc, vc, H_, bc, t_dev)
-        torch.cuda.synchronize()
-        f = lambda x: x.float().cpu().numpy()
-        assert np.abs(f(xb) - f(xb_ref)).max() < 2e-3 * max(1.0, float(np.abs(f(xb_ref)).max())), (func, t)   # other k order
-        for st, x in ((stats_b, xb), (stats_a, xa2)):
-            xs = f(x).reshape(N, W // 16, 16)
-            s = st.cpu().numpy()[:, :N]                                                      # [tile][row][which]
-            assert np.allclose(s[..., 0].T, xs.sum(-1), atol=1e-3) and np.allclose(s[..., 1].T, (xs ** 2).sum(-1), rtol=1e-4, atol=1e-3)
-        scale = max(1.0, float(np.abs(f(xa2_ref)).max()))
-        assert np.abs(f(xa2) - f(xa2_ref)).max() < 6e-3 * scale, (func, t)
-        # q / k / v as the next layer sees them: appended cache rows and the attention output
-        if func != 6:
-            assert np.abs(f(kc[:, t]) - f(kc_ref[:, t])).max() < 8e-3 * max(1.0, float(np.abs(f(kc_ref[:, t])).max())), (func, t)
-            assert np.abs(f(vc[:, t]) - f(vc_ref[:, t])).max() < 8e-3 * max(1.0, float(np.abs(f(vc_ref[:, t])).max())), (func, t)
-            untouched = np.ones(cap, bool)
-            untouched[t] = False
-            assert np.array_equal(f(kc)[:, untouched], kc0[:, untouched]) and np.array_equal(f(vc)[:, untouched], vc0[:, untouched])
-        assert np.abs(f(att2) - f(att_ref)).max() < 8e-3 * max(1.0, float(np.abs(f(att_ref)).max())), (func, t)
