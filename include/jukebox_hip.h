@@ -24,11 +24,7 @@ typedef enum { JB_ACT_NONE = 0, JB_ACT_RELU = 1, JB_ACT_QUICK_GELU = 2 } jb_act;
 /* attention patterns: jukebox/transformer/factored_attention.py:57-66 */
 typedef enum {
     JB_ATTN_DENSE = 0, JB_ATTN_BLOCK = 1, JB_ATTN_TRANSPOSE_BLOCK = 2, JB_ATTN_PREV_BLOCK = 3,
-    JB_ATTN_CROSS = 6, JB_ATTN_PRIME = 7,
-    /* jb_attn_decode / jb_attn_decode_split only: the transpose_block pattern on caches stored block-transposed (the mirror
-     * written through jb_gemm_args.kcache2 / jb_gemv_args.kcache2): the query's keys are one contiguous run of rows instead
-     * of a stride-block_ctx gather (61 KB apart at the upsamplers' sizes: measured 8.4 vs 6.4 us per launch) */
-    JB_ATTN_TRANSPOSE_BLOCK_T = 12
+    JB_ATTN_CROSS = 6, JB_ATTN_PRIME = 7
 } jb_attn_func;
 
 const char* jb_last_error(void);
@@ -94,10 +90,6 @@ typedef struct jb_gemm_args {
     float res_scale;
     int qkv_split, S;
     void* kcache; void* vcache; int cache_cap, cache_t0;
-    /* optional block-transposed mirror of the caches, written alongside (transpose_block layers): position p of a sample
-     * also goes to row (p % perm_bc) * (cache_cap / perm_bc) + p / perm_bc, so that the keys p, p - bc, p - 2bc, ... a
-     * decode query of that pattern reads are CONTIGUOUS rows (JB_ATTN_TRANSPOSE_BLOCK_T in jb_attn_decode).  NULL = none. */
-    void* kcache2; void* vcache2; int perm_bc;
 } jb_gemm_args;
 int jb_gemm(const jb_gemm_args* args /* host */, void* stream);
 /* Flat problems (one tap, unit strides) of at least `min_rows` output rows use the LDS-staged 256x128-tile kernel
@@ -135,7 +127,6 @@ typedef struct jb_gemv_args {
      *     x[n][k] = sum_s w_s * x_parts[(n*n_parts + s)*K + k],  w_s from x_ml[((n*n_head + k/d_head)*n_parts + s)*2 + {0,1}]
      * rounded to half once (the attention output of factored_attention.py:107-108).  attn.c_proj of the decode step. */
     const void* x_parts; const float* x_ml; int n_parts, n_head, d_head;
-    void* kcache2; void* vcache2; int perm_bc;   /* block-transposed cache mirror, as in jb_gemm_args */
 } jb_gemv_args;
 int jb_gemv(const jb_gemv_args* args /* host */, void* stream);
 /* 1 if jb_gemv accepts ln_fold_c1 for this problem (whole k-tiles, the rows' operand fragments fit in registers). */
@@ -246,7 +237,6 @@ typedef struct jb_layer {
     const float *ln0_g, *ln0_b, *ln1_g, *ln1_b;
     void *kcache, *vcache;                                 /* [n_batch][cache_cap][n_state], engine dtype */
     int cache_cap;
-    void *kcache_t, *vcache_t;                             /* transpose_block layers: block-transposed mirror (or NULL) */
     /* cross-attention layers (attn_func 6, factored_attention.py:46-48,273-287): w_attn is n_in x n_state (query only);
      * c_enc_kv is given as its key and value halves, each n_in x n_state, with the (2*n_state) bias; the caches hold
      * the projected encoder states, cache_cap = encoder length. */

@@ -22,8 +22,7 @@ class GemmArgs(C.Structure):
                 ("n_seq", i32), ("t_in", i32), ("t_out", i32), ("in_seq_stride", i64), ("out_seq_stride", i64),
                 ("K", i32), ("J", i32), ("n_taps", i32), ("in_stride", i32), ("shift", i32 * 4),
                 ("out_stride", i32), ("out_offset", i32), ("pre_relu", i32), ("act", i32), ("res_scale", f32),
-                ("qkv_split", i32), ("S", i32), ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("cache_t0", i32),
-                ("kcache2", vp), ("vcache2", vp), ("perm_bc", i32)]
+                ("qkv_split", i32), ("S", i32), ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("cache_t0", i32)]
 
 
 class GemvArgs(C.Structure):
@@ -34,8 +33,7 @@ class GemvArgs(C.Structure):
                 ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp),
                 ("ln_fold_c1", vp),
                 ("out2", vp), ("ldo2", i64), ("add2", vp), ("add2_n_stride", i64), ("add2_t_stride", i64),
-                ("x_parts", vp), ("x_ml", vp), ("n_parts", i32), ("n_head", i32), ("d_head", i32),
-                ("kcache2", vp), ("vcache2", vp), ("perm_bc", i32)]
+                ("x_parts", vp), ("x_ml", vp), ("n_parts", i32), ("n_head", i32), ("d_head", i32)]
 
 
 class SampleParams(C.Structure):
@@ -47,8 +45,7 @@ class Layer(C.Structure):
     _fields_ = [("attn_func", i32), ("w_attn", vp), ("w_proj", vp), ("w_fc", vp), ("w_proj2", vp),
                 ("b_attn", vp), ("b_proj", vp), ("b_fc", vp), ("b_proj2", vp),
                 ("ln0_g", vp), ("ln0_b", vp), ("ln1_g", vp), ("ln1_b", vp),
-                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("kcache_t", vp), ("vcache_t", vp),
-                ("w_enc_k", vp), ("w_enc_v", vp), ("b_enc_kv", vp),
+                ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("w_enc_k", vp), ("w_enc_v", vp), ("b_enc_kv", vp),
                 ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp)]
 
 

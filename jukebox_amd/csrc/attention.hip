@@ -25,8 +25,6 @@ __device__ __forceinline__ KeySet decode_key_set(int func, int t, int bc, int ca
         case JB_ATTN_DENSE: k.count = t + 1; break;
         case JB_ATTN_BLOCK: k.start = (t / bc) * bc; k.count = t - k.start + 1; break;
         case JB_ATTN_TRANSPOSE_BLOCK: k.start = t % bc; k.stride = bc; k.count = t / bc + 1; break;
-        // the same keys on a block-transposed cache (row (p % bc) * (cap / bc) + p / bc holds position p): contiguous
-        case JB_ATTN_TRANSPOSE_BLOCK_T: k.start = (t % bc) * (cap / bc); k.count = t / bc + 1; break;
         case JB_ATTN_PREV_BLOCK: {
             int blk = t / bc;
             if (blk > 0) { k.start = (blk - 1) * bc; k.count = bc; }   // block 0: zero rows -> output 0

@@ -53,10 +53,6 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
                    "folded LayerNorm image of mlp.c_fc is incomplete or unsupported for this shape");
     }
     JB_REQUIRE((cfg->att_parts == nullptr) == (cfg->att_ml == nullptr), "att_parts and att_ml come together");
-    for (int l = 0; l < cfg->n_layers; ++l)
-        JB_REQUIRE(!layers[l].kcache_t || (layers[l].vcache_t && layers[l].attn_func == JB_ATTN_TRANSPOSE_BLOCK && cfg->block_ctx > 0 &&
-                                           layers[l].cache_cap % cfg->block_ctx == 0),
-                   "a transposed cache mirror belongs to a transpose_block layer whose cache length is a multiple of block_ctx");
     JB_REQUIRE(cfg->bins <= 0 || !cfg->x_out_packed || cfg->ticket, "ticket counter missing");
     JB_REQUIRE(cfg->width % 4 == 0, "width must be a multiple of 4");
     JB_REQUIRE(!cfg->rec_out || (cfg->rec_layer >= 0 && cfg->rec_layer < cfg->n_layers && cfg->rec_keys > 0 &&
@@ -140,24 +136,19 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
         } else {
             g.J = 3 * S;
             g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
-            if (L.kcache_t) { g.kcache2 = L.kcache_t; g.vcache2 = L.vcache_t; g.perm_bc = c.block_ctx; }
         }
         JB_TRY(jb_gemv(&g, s));
-        // a transpose_block layer reads its keys from the block-transposed mirror: one contiguous run instead of a gather
-        const int afunc = (L.attn_func == JB_ATTN_TRANSPOSE_BLOCK && L.kcache_t) ? JB_ATTN_TRANSPOSE_BLOCK_T : L.attn_func;
-        const void* kread = afunc == JB_ATTN_TRANSPOSE_BLOCK_T ? L.kcache_t : L.kcache;
-        const void* vread = afunc == JB_ATTN_TRANSPOSE_BLOCK_T ? L.vcache_t : L.vcache;
         // attention, then attn.c_proj + residual: x_b = x_a + a
         const int parts = layer_split_parts(c, L);
         g = {};
         g.dtype = c.dtype; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
         g.out = c.x_b; g.ldo = W; g.res = c.x_a; g.ldr = W;
         if (parts > 0) {
-            JB_TRY(jb_attn_decode_split(afunc, c.q, S, kread, vread, L.cache_cap, c.att_parts, c.att_ml, N, H, d,
+            JB_TRY(jb_attn_decode_split(L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att_parts, c.att_ml, N, H, d,
                                         c.block_ctx, c.t_dev, layer_max_keys(c, L), parts, s));
             g.x_parts = c.att_parts; g.x_ml = c.att_ml; g.n_parts = parts; g.n_head = H; g.d_head = d;
         } else {
-            JB_TRY(jb_attn_decode(c.dtype, afunc, c.q, S, kread, vread, L.cache_cap, c.att, S, N, H, d,
+            JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
                                   c.block_ctx, c.t_dev, c.seq_len, s));
             g.x = c.att;
         }
@@ -280,7 +271,6 @@ extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
             } else {
                 base(g, c.c_h, W, W, L.w_attn, L.b_attn, 3 * S, c.c_q, S);
                 g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.cache_t0 = p0;
-                if (L.kcache_t) { g.kcache2 = L.kcache_t; g.vcache2 = L.vcache_t; g.perm_bc = c.block_ctx; }
             }
             JB_TRY(jb_gemm(&g, s));
             JB_TRY(jb_attn_prefill(c.dtype, L.attn_func, c.c_q, L.kcache, L.vcache, L.cache_cap, c.c_att, N, H, d,

@@ -67,9 +67,6 @@ struct EpiParams {
     int J, act; float res_scale;
     int qkv_split, S;
     void* kcache; void* vcache; int cache_cap;
-    // optional block-transposed mirror of the caches (transpose_block layers): position p of a sample is also written to row
-    // (p % perm_bc) * (cache_cap / perm_bc) + p / perm_bc, where the keys p, p - bc, p - 2 bc, ... of a decode query are contiguous
-    void* kcache2; void* vcache2; int perm_bc;
     int vec_out;        // 4 consecutive columns may be stored as one vector
     // decode step, last layer: a second fp32 copy out2[row][j] = value + add2[row*add2_n + t*add2_t + j] (t = *t_dev) --
     // `x.float() + cond` before the logits head (autoregressive.py:226-227), fused into mlp.c_proj's epilogue
@@ -126,12 +123,6 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& p, f32x4 acc, in
             } else if (cache_row >= 0) {
                 T* c = (T*)(part == 1 ? p.kcache : p.vcache);
                 c[cache_row * p.S + jj] = (T)v[r];
-                if (p.kcache2) {
-                    const int64_t n = cache_row / p.cache_cap;
-                    const int ct = (int)(cache_row - n * p.cache_cap);
-                    const int64_t row2 = n * p.cache_cap + (int64_t)(ct % p.perm_bc) * (p.cache_cap / p.perm_bc) + ct / p.perm_bc;
-                    ((T*)(part == 1 ? p.kcache2 : p.vcache2))[row2 * p.S + jj] = (T)v[r];
-                }
             }
         }
     }
@@ -151,15 +142,7 @@ __device__ __forceinline__ void epilogue_store1(const EpiParams& p, float x, int
     } else {
         const int part = j / p.S, jj = j - part * p.S;
         if (part == 0) ((T*)p.out)[orow * p.ldo + jj] = (T)x;
-        else if (cache_row >= 0) {
-            ((T*)(part == 1 ? p.kcache : p.vcache))[cache_row * p.S + jj] = (T)x;
-            if (p.kcache2) {
-                const int64_t n = cache_row / p.cache_cap;
-                const int ct = (int)(cache_row - n * p.cache_cap);
-                const int64_t row2 = n * p.cache_cap + (int64_t)(ct % p.perm_bc) * (p.cache_cap / p.perm_bc) + ct / p.perm_bc;
-                ((T*)(part == 1 ? p.kcache2 : p.vcache2))[row2 * p.S + jj] = (T)x;
-            }
-        }
+        else if (cache_row >= 0) ((T*)(part == 1 ? p.kcache : p.vcache))[cache_row * p.S + jj] = (T)x;
     }
 }
 
@@ -376,7 +359,6 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     JB_REQUIRE(a->K > 0 && a->J > 0 && a->n_seq > 0 && a->t_out > 0 && a->t_in > 0, "empty problem");
     JB_REQUIRE(a->n_taps >= 1 && a->n_taps <= 4, "n_taps must be 1..4");
     JB_REQUIRE(!a->qkv_split || (a->S > 0 && a->J == 3 * a->S && a->kcache && a->vcache), "bad qkv split");
-    JB_REQUIRE(!a->kcache2 || (a->vcache2 && a->perm_bc > 0 && a->cache_cap % a->perm_bc == 0), "bad transposed cache mirror");
     const int esz = a->dtype == JB_F16 ? 2 : 4;
     const int E = a->dtype == JB_F16 ? 8 : 4;
     GemmParams p;
@@ -397,7 +379,6 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     p.epi.J = a->J; p.epi.act = a->act; p.epi.res_scale = a->res_scale;
     p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
     p.epi.cache_cap = a->cache_cap;
-    p.epi.kcache2 = a->qkv_split ? a->kcache2 : nullptr; p.epi.vcache2 = a->vcache2; p.epi.perm_bc = a->perm_bc;
     p.epi.vec_out = !a->qkv_split && (a->ldo % 4 == 0) && aligned_to(a->out, 4 * esz);
     p.epi.out2 = nullptr; p.epi.ldo2 = 0; p.epi.add2 = nullptr; p.epi.add2_n = p.epi.add2_t = 0;
     dim3 grid((unsigned)((p.m_total + 255) / 256), (unsigned)((p.njt + 3) / 4));
@@ -1089,7 +1070,6 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     JB_REQUIRE(a->n_rows >= 1 && a->n_rows <= 64, "n_rows must be 1..64");
     JB_REQUIRE(a->K > 0 && a->J > 0, "empty problem");
     JB_REQUIRE(!a->qkv_split || (a->S > 0 && a->J == 3 * a->S && a->kcache && a->vcache && a->t_dev), "bad qkv split");
-    JB_REQUIRE(!a->kcache2 || (a->vcache2 && a->perm_bc > 0 && a->cache_cap % a->perm_bc == 0), "bad transposed cache mirror");
     JB_REQUIRE(!a->out2 || (a->ldo2 >= a->J && (!a->add2 || a->t_dev)), "bad second output (out2 / add2 need ldo2 >= J and t_dev)");
     JB_REQUIRE(!a->out2 || (!a->ln_gamma && !a->ln_fold_c1 && !a->x_parts), "out2 is available on the plain projection only");
     if (a->x_parts) {
@@ -1126,7 +1106,6 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     p.epi.J = a->J; p.epi.act = a->act; p.epi.res_scale = 1.0f;
     p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
     p.epi.cache_cap = a->cache_cap;
-    p.epi.kcache2 = a->qkv_split ? a->kcache2 : nullptr; p.epi.vcache2 = a->vcache2; p.epi.perm_bc = a->perm_bc;
     p.epi.vec_out = !a->qkv_split && (a->ldo % 4 == 0) && aligned_to(a->out, 4 * esz);
     p.epi.out2 = a->out2; p.epi.ldo2 = a->ldo2; p.epi.add2 = a->out2 ? a->add2 : nullptr;
     p.epi.add2_n = a->add2_n_stride; p.epi.add2_t = a->add2_t_stride;

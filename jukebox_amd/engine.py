@@ -131,8 +131,7 @@ class PriorEngine:
         dev, dt = self.device, self.dtype
         N, T, S, W, M = self.N, self.T, self.S, self.W, self.M
         self.layers_c = (L.Layer * self.depth)()
-        self.kcaches, self.vcaches, self.kcaches_t, self.vcaches_t = [], [], [], []
-        mirror = os.environ.get("JB_TRANSPOSE_MIRROR", "1") != "0" and not self.only_encode
+        self.kcaches, self.vcaches = [], []
         for d, lay in enumerate(pk.layers):
             kc = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
             vc = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
@@ -144,14 +143,6 @@ class PriorEngine:
             lc.b_attn, lc.b_proj, lc.b_fc, lc.b_proj2 = (b.data_ptr() for b in lay["bs"])
             lc.ln0_g, lc.ln0_b, lc.ln1_g, lc.ln1_b = (t.data_ptr() for t in lay["lns"])
             lc.kcache, lc.vcache, lc.cache_cap = kc.data_ptr(), vc.data_ptr(), lay["cap"]
-            if lay["func"] == 2 and mirror and self.block_ctx > 0 and lay["cap"] % self.block_ctx == 0:
-                # transpose_block layers: a block-transposed mirror of the caches, written alongside, in which the keys a
-                # decode query reads (p, p - bc, p - 2 bc, ...) are contiguous rows (JB_ATTN_TRANSPOSE_BLOCK_T)
-                kt = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
-                vt = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
-                self.kcaches_t.append(kt)
-                self.vcaches_t.append(vt)
-                lc.kcache_t, lc.vcache_t = kt.data_ptr(), vt.data_ptr()
             if self.fold_ln:
                 j_attn = S if lay["func"] == 6 else 3 * S
                 f = lay["f_attn"]
@@ -298,7 +289,7 @@ class PriorEngine:
         return float(L.lib().jb_engine_step_bytes(self.handle, int(t)))
 
     def cache_bytes(self):
-        return sum(k.numel() * k.element_size() * 2 for k in self.kcaches + self.kcaches_t)
+        return sum(k.numel() * k.element_size() * 2 for k in self.kcaches)
 
     def weight_bytes(self):
         return self.packed.weight_bytes()

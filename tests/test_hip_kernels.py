@@ -603,61 +603,3 @@ def test_vq(H):
     # disagreements only at near-ties of the distance
     srt = np.sort(dist, 1)
     assert agree.mean() > 0.99 and np.all((srt[~agree, 1] - srt[~agree, 0]) < 1e-4)
-
-
-def test_transposed_cache_mirror(H):
-    """The block-transposed mirror of a transpose_block layer's caches: jb_gemv / jb_gemm (qkv_split) write position p also
-    to row (p % bc) * (cap / bc) + p / bc, and jb_attn_decode with JB_ATTN_TRANSPOSE_BLOCK_T on the mirror equals the
-    transpose_block pattern on the plain cache (the same keys, contiguous instead of strided)."""
-    from jukebox_amd import _lib as L
-    rng = np.random.default_rng(9)
-    for dt, tol in ((torch.float16, 4e-3), (torch.float32, 1e-5)):
-        N, S, bc, cap, H_ = 3, 64, 8, 96, 2
-        nb = cap // bc
-        perm = lambda p: (p % bc) * nb + p // bc
-        r = (lambda x: h16(x)) if dt == torch.float16 else (lambda x: x)
-        K, V = r(rng.standard_normal((N, cap, S)).astype(np.float32)), r(rng.standard_normal((N, cap, S)).astype(np.float32))
-        Kt, Vt = np.zeros_like(K), np.zeros_like(V)
-        for p_ in range(cap):
-            Kt[:, perm(p_)], Vt[:, perm(p_)] = K[:, p_], V[:, p_]
-        for t in (0, 7, 8, 9, 50, 95):
-            q = r(rng.standard_normal((N, S)).astype(np.float32))
-            t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
-            a = H.attn_decode(2, dev(q, dt), dev(K, dt), dev(V, dt), H_, bc, t_dev, cap).float().cpu().numpy()
-            b = H.attn_decode(12, dev(q, dt), dev(Kt, dt), dev(Vt, dt), H_, bc, t_dev, cap).float().cpu().numpy()
-            assert np.abs(a - b).max() < tol * max(1.0, np.abs(a).max()), (dt, t)
-        # writers: decode step (jb_gemv) at position t, prefill chunk (jb_gemm) at positions t0..t0+n-1
-        Kdim = 32
-        x = r(rng.standard_normal((N, Kdim)).astype(np.float32))
-        W = r((rng.standard_normal((Kdim, 3 * S)) / 6).astype(np.float32))
-        pw = H.pack_conv1d_w(dev(W), dt)
-        for t in (0, 13, 95):
-            kc, vc, k2, v2 = (torch.zeros((N, cap, S), dtype=dt, device="cuda") for _ in range(4))
-            out = torch.empty((N, S), dtype=dt, device="cuda")
-            t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
-            a = L.GemvArgs()
-            xd = dev(x, dt)
-            a.dtype, a.x, a.ldx, a.n_rows = L.dtype_code(dt), xd.data_ptr(), Kdim, N
-            a.W, a.K, a.J, a.out, a.ldo = pw.ptr, Kdim, 3 * S, out.data_ptr(), S
-            a.qkv_split, a.S, a.kcache, a.vcache, a.cache_cap, a.t_dev = 1, S, kc.data_ptr(), vc.data_ptr(), cap, t_dev.data_ptr()
-            a.kcache2, a.vcache2, a.perm_bc = k2.data_ptr(), v2.data_ptr(), bc
-            L.check(L.lib().jb_gemv(C.byref(a), L.stream()))
-            torch.cuda.synchronize()
-            assert torch.equal(k2[:, perm(t)], kc[:, t]) and torch.equal(v2[:, perm(t)], vc[:, t]) and kc[:, t].abs().sum() > 0
-            assert int((k2 != 0).any(-1).sum()) == N and int((v2 != 0).any(-1).sum()) == N        # nothing else was touched
-        n_q, t0 = 21, 30
-        hq = r(rng.standard_normal((N * n_q, Kdim)).astype(np.float32))
-        kc, vc, k2, v2 = (torch.zeros((N, cap, S), dtype=dt, device="cuda") for _ in range(4))
-        g = L.GemmArgs()
-        hd = dev(hq, dt)
-        qo = torch.empty((N * n_q, S), dtype=dt, device="cuda")
-        g.dtype, g.A, g.lda, g.W, g.tap_stride = L.dtype_code(dt), hd.data_ptr(), Kdim, pw.ptr, pw.tap_stride
-        g.out, g.ldo, g.n_seq, g.t_in, g.t_out, g.in_seq_stride, g.out_seq_stride = qo.data_ptr(), S, N, n_q, n_q, n_q, n_q
-        g.K, g.J, g.n_taps, g.in_stride, g.out_stride, g.res_scale = Kdim, 3 * S, 1, 1, 1, 1.0
-        g.qkv_split, g.S, g.kcache, g.vcache, g.cache_cap, g.cache_t0 = 1, S, kc.data_ptr(), vc.data_ptr(), cap, t0
-        g.kcache2, g.vcache2, g.perm_bc = k2.data_ptr(), v2.data_ptr(), bc
-        L.check(L.lib().jb_gemm(C.byref(g), L.stream()))
-        torch.cuda.synchronize()
-        for p_ in range(cap):
-            assert torch.equal(k2[:, perm(p_)], kc[:, p_]) and torch.equal(v2[:, perm(p_)], vc[:, p_])
-        assert kc[:, t0:t0 + n_q].abs().sum() > 0 and kc[:, :t0].abs().sum() == 0
