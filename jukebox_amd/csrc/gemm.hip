@@ -914,23 +914,28 @@ __global__ __launch_bounds__(NW * 64) void gemv_merge_kernel(GemvParams p) {
             const V w = keep_frag<f16>(kb + i < kt1, wf[i]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                // log-sum-exp weights of the parts (hardware exp2 / rcp: this sits on the critical path of every workgroup;
+                // an empty part has l = 0 and a zero row, so no select is needed below)
                 float m = mm[i][mt][0];
 #pragma unroll
                 for (int s = 1; s < PMAX; ++s) m = fmaxf(m, mm[i][mt][s]);
                 float ws[PMAX], tot = 0.f;
 #pragma unroll
                 for (int s = 0; s < PMAX; ++s) {
-                    ws[s] = ll[i][mt][s] > 0.f ? ll[i][mt][s] * expf(mm[i][mt][s] - m) : 0.f;
+                    const float ex = __builtin_amdgcn_exp2f((mm[i][mt][s] - m) * 1.4426950408889634f);
+                    ws[s] = ll[i][mt][s] > 0.f ? ll[i][mt][s] * ex : 0.f;
                     tot += ws[s];
                 }
-                const float inv = tot > 0.f ? 1.0f / tot : 0.f;        // no key at all (prev_block in block 0): a = 0
+                const float inv = tot > 0.f ? __builtin_amdgcn_rcpf(tot) : 0.f;   // no key at all (prev_block in block 0): a = 0
+#pragma unroll
+                for (int s = 0; s < PMAX; ++s) ws[s] *= inv;
                 V xv;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     float a = 0.f;
 #pragma unroll
-                    for (int s = 0; s < PMAX; ++s) a += ws[s] > 0.f ? ws[s] * (float)ph[i][mt][s][e] : 0.f;
-                    xv[e] = (f16)(a * inv);
+                    for (int s = 0; s < PMAX; ++s) a = fmaf(ws[s], (float)ph[i][mt][s][e], a);
+                    xv[e] = (f16)a;
                 }
                 acc[mt] = jb_mfma(w, xv, acc[mt]);
             }

@@ -8,7 +8,7 @@ from jukebox_amd.prior.conditioners import Conditioner
 
 dev = torch.device("cuda:0")
 cfg = CFGS["up"]
-eng = PriorEngine(random_state(cfg, dev), "", n_batch=16, fp16=True, chunk_cap=int(sys.argv[1]) if len(sys.argv) > 1 else 512, **cfg)
+eng = PriorEngine(random_state(cfg, dev), "", n_batch=16, fp16=True, chunk_cap=int(sys.argv[1]) if len(sys.argv) > 1 else 2048, **cfg)
 eng.set_cond(torch.randn(16, cfg["seq_len"], cfg["width"], device=dev) * 0.01, torch.randn(16, 1, cfg["width"], device=dev) * 0.01)
 eng.tokens.random_(0, cfg["bins"])
 for n in (512, 4096):
