@@ -188,22 +188,6 @@ __device__ inline float philox_uniform(uint64_t seed, uint32_t stream, uint32_t 
     return (float)(c0 >> 8) * (1.0f / 16777216.0f);
 }
 
-// In-LDS bitonic sort, descending, n2 = power of two >= count (padding = -inf).
-__device__ inline void bitonic_sort_desc(float* a, int n2) {
-    for (int k = 2; k <= n2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    bool desc = (i & k) == 0;
-                    float x = a[i], y = a[ixj];
-                    if (desc ? (x < y) : (x > y)) { a[i] = y; a[ixj] = x; }
-                }
-            }
-            __syncthreads();
-        }
-}
-
 // 256-thread block primitives on wave shuffles: a wave-level step (6 cross-lane ops) plus one 4-entry LDS exchange.
 // `scratch` holds 8 floats; every call ends with the block synchronised and scratch reusable.
 __device__ __forceinline__ float wave_scan_incl(float v) {
@@ -231,6 +215,14 @@ __device__ __forceinline__ float block_scan_incl(float v, float* scratch, float*
     __syncthreads();
     *total = tot;
     return inc + base;
+}
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = jb_wave_sum(v);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    __syncthreads();
+    return r;
 }
 __device__ __forceinline__ float block_max(float v, float* scratch) {
     v = jb_wave_max(v);
@@ -269,7 +261,6 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                                                      int64_t preds_n_stride, SampleTail tail) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_x = sm;              // [bins] filtered, temperature-scaled logits
-    float* s_sort = sm + n2;      // [n2] sort scratch (top-k / nucleus only)
     __shared__ float s_f[8];
     __shared__ int s_i[8];
     __shared__ int s_pick, s_owner;
@@ -301,30 +292,52 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         __syncthreads();
     } else {
         if (top_k > 1 || P.top_p > 0.f) {
-            for (int i = tid; i < n2; i += 256) s_sort[i] = i < bins ? s_x[i] : -INFINITY;
-            __syncthreads();
-            bitonic_sort_desc(s_sort, n2);
-            int keep = top_k;                                  // keep everything >= the k-th largest
-            if (top_k <= 1) {
-                // nucleus (ops.py:129-141): sorted entry i >= 1 is dropped iff the cumulative probability of entries
-                // 0..i-1 exceeds top_p, i.e. keep = 1 + #{j <= bins-2 : cumprob_j <= top_p}
-                const float mx = s_sort[0];
-                float e[16], loc = 0.f;
-                const int c2 = (n2 + 255) / 256, l2 = tid * c2;
-                for (int u = 0; u < c2 && u < 16; ++u) { e[u] = l2 + u < bins ? expf(s_sort[l2 + u] - mx) : 0.f; loc += e[u]; }
-                float tot;
-                float cum = block_scan_incl(loc, s_f, &tot) - loc;
-                int cnt = 0;
-                for (int u = 0; u < c2 && u < 16; ++u) {
-                    cum += e[u];
-                    if (l2 + u <= bins - 2 && cum / tot <= P.top_p) ++cnt;
-                }
-                keep = 1 + block_sum_int(cnt, s_i);
+            // filter_logits (ops.py:113-142) without a sort: the threshold is found by bisection over the 32 bits of an
+            // order-preserving integer key, every probe one block-wide count (top-k) or mass (nucleus) from registers --
+            // wave shuffles plus a 4-entry LDS exchange per probe.
+            //   top-k  : keep x  <=>  x >= k-th largest           = largest key T with #{key >= T} >= k
+            //   nucleus: entry i >= 1 of the descending order is dropped iff the mass of the entries before it exceeds
+            //            top_p, i.e. keep x  <=>  mass{y > x} <= top_p  <=>  key(x) >= smallest T with mass{key > T} <= top_p
+            constexpr int CH = 16;                             // bins <= 4096
+            unsigned key[CH];
+            float ex[CH];
+            float mloc = -INFINITY;
+            for (int i = lo; i < hi; ++i) mloc = fmaxf(mloc, s_x[i]);
+            const float mx = block_max(mloc, s_f);
+            float tl = 0.f;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const bool in = lo + u < hi;
+                const float v = in ? s_x[lo + u] : -INFINITY;
+                const unsigned b = __float_as_uint(v);
+                key[u] = in ? (b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u)) : 0u;      // ascending with the float order
+                ex[u] = in ? expf(v - mx) : 0.f;
+                tl += ex[u];
             }
-            const float thr = s_sort[keep - 1];
-            __syncthreads();
-            for (int i = tid; i < bins; i += 256)
-                if (s_x[i] < thr) s_x[i] = -INFINITY;
+            unsigned T;
+            if (top_k > 1) {
+                T = 0u;
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned cand = T | (1u << bit);
+                    int cnt = 0;
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) cnt += (lo + u < hi && key[u] >= cand) ? 1 : 0;
+                    if (block_sum_int(cnt, s_i) >= top_k) T = cand;
+                }
+            } else {
+                const float budget = P.top_p * block_sum(tl, s_f);
+                T = 0xFFFFFFFFu;
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned cand = T & ~(1u << bit);
+                    float above = 0.f;
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) above += (lo + u < hi && key[u] > cand) ? ex[u] : 0.f;
+                    if (block_sum(above, s_f) <= budget) T = cand;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (lo + u < hi && key[u] < T) s_x[lo + u] = -INFINITY;
             __syncthreads();
         }
         // Categorical(logits).sample(): inverse CDF in index order.  Thread i owns the contiguous indices [lo, hi); the
@@ -399,7 +412,7 @@ static int launch_sample(const float* logits, int n_batch, int bins, const jb_sa
     int n2 = 1;
     while (n2 < bins) n2 <<= 1;
     if (n2 > 4096) JB_UNSUPPORTED("vocabulary too large for the LDS sampler (bins <= 4096)");
-    const size_t lds = (size_t)2 * n2 * sizeof(float);
+    const size_t lds = (size_t)n2 * sizeof(float);
     sample_kernel<<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds, preds_n_stride, tail);
     JB_CHECK_LAUNCH();
     return JB_OK;
