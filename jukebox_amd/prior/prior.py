@@ -88,82 +88,90 @@ class SimplePrior(nn.Module):
             self.labeller = EmptyLabeller()
 
     def get_y(self, labels, start, get_indices=False):
-        """prior.py:140-156: per-window label matrix (sample_length of this level, shifted offset, re-windowed lyrics)."""
+        """The label matrix of the window that starts at token `start`: this level's window length, the offset moved to the
+        window, and the lyric tokens re-windowed around it (prior.py:140-156).  None for unlabelled models."""
         if isinstance(self.labeller, EmptyLabeller):
             return None
         y = labels["y"].clone()
+        y[:, 1] += int(start * self.raw_to_tokens)
         y[:, 2] = int(self.sample_length)
-        y[:, 1:2] = y[:, 1:2] + int(start * self.raw_to_tokens)
         indices = self.labeller.set_y_lyric_tokens(y, labels)
         return (y, indices) if get_indices else y
 
     def get_z_conds(self, zs, start, end):
-        """prior.py:158-166."""
-        if self.level != self.levels - 1:
-            assert start % self.cond_downsample == end % self.cond_downsample == 0
-            z_cond = zs[self.level + 1][:, start // self.cond_downsample:end // self.cond_downsample]
-            assert z_cond.shape[1] == self.n_ctx // self.cond_downsample
-            return [z_cond]
-        return None
+        """The upper level's codes under the window [start, end): one tensor in a list, None at the top (prior.py:158-166)."""
+        if self.level == self.levels - 1:
+            return None
+        cd = self.cond_downsample
+        assert start % cd == 0 and end % cd == 0
+        z_cond = zs[self.level + 1][:, start // cd:end // cd]
+        assert z_cond.shape[1] == self.n_ctx // cd
+        return [z_cond]
 
     def prior_preprocess(self, xs, conds):
-        """prior.py:168-185: shift each vocabulary into the merged one, zero-pad missing conditioning."""
+        """single_enc_dec models: lyric tokens and music codes become ONE sequence over the merged vocabulary (each part
+        shifted by the sizes of the parts before it), their conditioning one tensor, zeros where a part has none
+        (prior.py:168-185)."""
         N = xs[0].shape[0]
-        for i in range(len(xs)):
-            bins, shift = int(self.prior_bins[i]), int(self.prior_bins_shift[i])
-            assert (0 <= xs[i]).all() and (xs[i] < bins).all()
-            xs[i] = (xs[i] + shift).view(N, -1)
-        for i in range(len(conds)):
-            if conds[i] is None:
-                conds[i] = t.zeros((N, self.prior_dims[i], self.prior_width), dtype=t.float, device=xs[0].device)
-            else:
-                assert tuple(conds[i].shape) == (N, self.prior_dims[i], self.prior_width)
-        return t.cat(xs, dim=1), t.cat(conds, dim=1)
+        parts = []
+        for x, bins, shift in zip(xs, self.prior_bins, self.prior_bins_shift):
+            assert bool(((x >= 0) & (x < int(bins))).all())
+            parts.append(x.reshape(N, -1) + int(shift))
+        cond_parts = []
+        for cond, dims in zip(conds, self.prior_dims):
+            want = (N, dims, self.prior_width)
+            if cond is None:
+                cond = t.zeros(want, dtype=t.float, device=xs[0].device)
+            assert tuple(cond.shape) == want
+            cond_parts.append(cond)
+        return t.cat(parts, dim=1), t.cat(cond_parts, dim=1)
 
     def prior_postprocess(self, z):
-        """prior.py:187-203: drop the lyric part, un-shift, clamp ids sampled from the lyric range to 0."""
-        N = z.shape[0]
-        dims = (self.prior_dims[0], z.shape[1] - self.prior_dims[0])
-        xs = list(t.split(z, dims, dim=1))
-        for i in range(len(xs)):
-            shape = self.prior_shapes[i]
-            bins, shift = int(self.prior_bins[i]), int(self.prior_bins_shift[i])
-            xs[i] = t.clamp((xs[i] - shift).view(N, -1, *shape[1:]), min=0)
-            assert (xs[i] < bins).all()
-        return xs[-1]
+        """Inverse of prior_preprocess for the music part: the lyric prefix is dropped, the vocabulary shift undone, and
+        an id sampled from the lyric range (possible: one softmax covers both) becomes code 0 (prior.py:187-203)."""
+        n_lyric = self.prior_dims[0]
+        music = z[:, n_lyric:] - int(self.prior_bins_shift[-1])
+        music = music.clamp(min=0).reshape(z.shape[0], -1, *self.prior_shapes[-1][1:])
+        assert bool((music < int(self.prior_bins[-1])).all())
+        lyric = z[:, :n_lyric] - int(self.prior_bins_shift[0])
+        assert bool((lyric.clamp(min=0) < int(self.prior_bins[0])).all())
+        return music
 
     def x_emb(self, z_conds):
-        z_conds = z_conds[:self.cond_level - self.level]
-        assert len(z_conds) == len(self.conditioner_blocks) == self.cond_level - self.level
+        """Upper-level codes -> (N, n_ctx, width) conditioning through this level's conditioner block(s), coarsest first."""
+        n_blocks = self.cond_level - self.level
+        z_conds = z_conds[:n_blocks]
+        assert len(z_conds) == len(self.conditioner_blocks) == n_blocks
         x_cond = None
-        for z_cond, block in reversed(list(zip(z_conds, self.conditioner_blocks))):
-            x_cond = block(z_cond, x_cond)
+        for k in range(n_blocks - 1, -1, -1):
+            x_cond = self.conditioner_blocks[k](z_conds[k], x_cond)
         return x_cond
 
+    def _levels(self, start_level, end_level):
+        return (self.level if start_level is None else start_level), (self.levels if end_level is None else end_level)
+
     def encode(self, x, start_level=None, end_level=None, bs_chunks=1):
-        start_level = self.level if start_level is None else start_level
-        end_level = self.levels if end_level is None else end_level
+        lo, hi = self._levels(start_level, end_level)
         with t.no_grad():
-            return self.encoder(x, start_level=start_level, end_level=end_level, bs_chunks=bs_chunks)
+            return self.encoder(x, start_level=lo, end_level=hi, bs_chunks=bs_chunks)
 
     def decode(self, zs, start_level=None, end_level=None, bs_chunks=1):
-        start_level = self.level if start_level is None else start_level
-        end_level = self.levels if end_level is None else end_level
-        assert len(zs) == end_level - start_level
+        lo, hi = self._levels(start_level, end_level)
+        assert len(zs) == hi - lo
         with t.no_grad():
-            return self.decoder(zs, start_level=start_level, end_level=end_level, bs_chunks=bs_chunks)
+            return self.decoder(zs, start_level=lo, end_level=hi, bs_chunks=bs_chunks)
 
     def get_cond(self, z_conds, y):
-        """prior.py:234-243."""
+        """(x_cond, y_cond, lyric tokens) of one window: the label columns of y go through the label conditioner, its lyric
+        columns are returned as they are, the upper-level codes through the conditioner; models without an upper level
+        are conditioned on the labels' timing signal instead (prior.py:234-243)."""
+        prime = None
         if y is not None:
-            assert y.shape[1] == 4 + self.y_emb.max_bow_genre_size + self.n_tokens
-            n_labels = y.shape[1] - self.n_tokens
+            n_labels = 4 + self.y_emb.max_bow_genre_size
+            assert y.shape[1] == n_labels + self.n_tokens
             y, prime = y[:, :n_labels], y[:, n_labels:]
-        else:
-            y, prime = None, None
         y_cond, y_pos = self.y_emb(y) if self.y_cond else (None, None)
-        x_cond = self.x_emb(z_conds) if self.x_cond else y_pos
-        return x_cond, y_cond, prime
+        return (self.x_emb(z_conds) if self.x_cond else y_pos), y_cond, prime
 
     def get_encoder_kv(self, prime, fp16=False, sample=False):
         """prior.py:285-301: lyric tokens -> encoder activations -> projection -> LayerNorm (fp32), half when fp16."""
