@@ -119,7 +119,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # decode longer, and the job time does not move; prefilling the next window in a second engine while the current one
     # decodes -- the prefill's bandwidth slows the latency-bound chain by what it saves.  Neither is in the tree.
     order = sorted(levels)                                 # lowest level first
-    prios = [int(v) for v in os.environ.get("JB_LEVEL_PRIOS", "-1,-1,0,0").split(",")] + [0, 0, 0, 0]
+    prios = [-1, -1, 0, 0]      # (round 2: every assignment of priorities to the levels measured the same job time)
     stream_of = {level: t.cuda.Stream(device=device, priority=prios[min(i, 3)]) if on_gpu else None
                  for i, level in enumerate(order)}
 

@@ -3,7 +3,9 @@ itself (tests/golden/gen_golden.py).  Tolerances: float32 summation-order differ
 import numpy as np
 import pytest
 
-from conftest import load_golden, sub_state
+import os
+
+from conftest import ROOT, load_golden, sub_state
 from oracle import ops
 from oracle.autoregressive import ConditionalAutoregressive2D, split_chunks
 from oracle.prior import SimplePrior
@@ -282,3 +284,25 @@ def test_teacher_forced_losses(tiny_hps):
         for k in ("bpd", "prime_loss", "gen_loss"):
             assert abs(float(m[k]) - float(f[f"{tag}.{k}"])) < 2e-5, (tag, k, m[k], f[f"{tag}.{k}"])
         assert abs(float(loss) - float(f[f"{tag}.loss"])) < 2e-5, (tag, loss, f[f"{tag}.loss"])
+
+
+def test_cpu_baseline_window_plan_matches_the_sampling_driver():
+    """oracle/time_reference.py integrates the reference's per-step CPU time over the workload's decode steps and primed
+    tokens: its window plan must be the one the sampling driver walks (get_starts + sample_single_window bookkeeping)."""
+    import importlib.util
+    from jukebox_amd.utils.sample_utils import get_starts
+    spec = importlib.util.spec_from_file_location("time_reference", os.path.join(ROOT, "oracle", "time_reference.py"))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    for total, n_ctx, hop in ((110240, 8192, 4096), (27560, 8192, 4096), (6890, 6144, 768), (8192, 8192, 4096), (5000, 8192, 4096),
+                              (33072, 8192, 4096), (100, 48, 6)):
+        decode, primed, have = 0, 0, 0
+        if total < n_ctx:
+            decode = total
+        else:
+            for s in get_starts(total, n_ctx, hop):
+                new = s + n_ctx - have
+                decode, primed, have = decode + new, primed + (n_ctx - new if have else 0), s + n_ctx
+            assert have == total
+        assert tr.window_plan(total, n_ctx, hop) == (decode, primed)
+        assert decode == total                    # every token of the level is decoded exactly once
