@@ -73,6 +73,7 @@ from jukebox_amd.make_models import MODELS, make_prior, make_vqvae  # noqa: E402
 from jukebox_amd.utils import dist_adapter as dist  # noqa: E402
 from jukebox_amd.utils.dist_utils import setup_dist_from_env  # noqa: E402
 
+_JSON_OUT = sys.stdout
 BUDGET_S = float(os.environ.get("JB_BENCH_BUDGET_S", "1400"))
 T_ORIGIN = float(os.environ.get("JB_BENCH_T0", repr(T_PROC)))
 
@@ -240,7 +241,7 @@ def roofline_only(a, device):
     out = dict(roofline=projection_roofline(eng, 4096, 16), level0_decode_ms_per_token_step=round(ms, 4),
                launches_per_token_step=eng.launches_per_step, weights_gb=round(eng.weight_bytes() / 1e9, 3),
                kv_cache_gb=round(eng.cache_bytes() / 1e9, 3))
-    print(json.dumps(out))
+    print(json.dumps(out), file=_JSON_OUT, flush=True)
 
 
 def timed_steps(step_fn, requested, world, device, tail_reserve_s, sync):
@@ -294,16 +295,20 @@ def dry_run(a, rank, world, device):
     done, dt, per_step, _ = timed_steps(lambda: time.sleep(0.02 * (1 + rank)), max(a.steps, 1), world, device, 0.0, lambda: None)
     if rank != 0:
         return
-    print(json.dumps(dict(metric=BASELINE_METRIC, value=round(audio * done / dt, 4), unit="audio_s/s", n_gpus=world, steps=done,
+    line = json.dumps(dict(metric=BASELINE_METRIC, value=round(audio * done / dt, 4), unit="audio_s/s", n_gpus=world, steps=done,
                           warmup=0, steps_requested=a.steps, warmup_requested=a.warmup, ms_per_step=round(dt / done * 1e3, 1),
                           higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f16",
                           data="dry-run (no GPU work; launcher / rank bootstrap / step loop only)",
                           config=dict(workload="dry-run", samples_per_gpu=a.samples_per_gpu, parallelism=f"sample-sharded x{world}"),
-                          dist=dist_info(world), roofline=None, cpu_baseline=None)))
+                          dist=dist_info(world), roofline=None, cpu_baseline=None))
+    print(line, file=_JSON_OUT, flush=True)
 
 
 def main():
     a = _parse_args()
+    # stdout carries the ONE JSON line and nothing else: the samplers' progress messages go to stderr
+    global _JSON_OUT
+    _JSON_OUT, sys.stdout = sys.stdout, sys.stderr
     rank, local_rank, device = setup_dist_from_env()
     world = dist.get_world_size()
     assert world == a.gpus, f"running as {world} rank(s) but --gpus {a.gpus} (launch with torch.distributed.run or let bench.py spawn the ranks)"
@@ -411,7 +416,7 @@ def main():
             total_steps = sum(sample_length // p.raw_to_tokens for p in priors)
             cb = cpu_baseline_port(priors[0], a.samples_per_gpu, a.cpu_steps if not tiny else 4, total_steps, audio_seconds_per_step)
         out["cpu_baseline"] = cb
-    print(json.dumps(out))
+    print(json.dumps(out), file=_JSON_OUT, flush=True)
 
 
 if __name__ == "__main__":
