@@ -127,6 +127,11 @@ typedef struct jb_gemv_args {
      *     x[n][k] = sum_s w_s * x_parts[(n*n_parts + s)*K + k],  w_s from x_ml[((n*n_head + k/d_head)*n_parts + s)*2 + {0,1}]
      * rounded to half once (the attention output of factored_attention.py:107-108).  attn.c_proj of the decode step. */
     const void* x_parts; const float* x_ml; int n_parts, n_head, d_head;
+    /* optional v' column group of a q/k/v split: J = 2*S + (vcache ? S : 0) + wide, columns [J - wide, J) are written to
+     * rows of `wide` elements of vcache_wide (same row numbering as kcache).  Single-head models project the value
+     * through attn.c_proj once, when it is cached: v' = LN(x)·(Wv·Wp) -- see jb_attn_decode_wide; the decode step of a
+     * wide-value layer passes vcache = NULL (q | k | v'). */
+    void* vcache_wide; int wide;
 } jb_gemv_args;
 int jb_gemv(const jb_gemv_args* args /* host */, void* stream);
 /* 1 if jb_gemv accepts ln_fold_c1 for this problem (whole k-tiles, the rows' operand fragments fit in registers). */
@@ -140,6 +145,17 @@ int jb_gemv_ln_fold_supported(int dtype, int K, int J, int n_rows);
 int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache,
                    int cache_cap, void* out, int64_t ldo, int n_batch, int n_head, int d_head,
                    int block_ctx, const int* t_dev, int max_len, void* stream);
+
+/* Wide-value form of jb_attn_decode for single-head fp16 layers (d_head = n_state a multiple of 32): vcache_w rows hold
+ * v' = v·Wp (width elements), so   x_out[n] = res[n] + (sum_k p_k v'_k + bias)   is the residual stream after the
+ * attention sub-block (ResAttnBlock: x + c_proj(attn), jukebox/transformer/transformer.py:62-66 with
+ * factored_attention.py:104-108,118-121) and no attn.c_proj launch follows.  One workgroup per (sample, slice of d_head
+ * output channels): width / d_head slices, each re-deriving the probabilities from the same keys.  bias = attn.c_proj's.
+ * Returns JB_ERR_ARG when the shape is not supported (callers then keep jb_attn_decode + attn.c_proj). */
+int jb_attn_decode_wide(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache_w, int cache_cap,
+                        const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
+                        int width, int block_ctx, const int* t_dev, int max_len, void* stream);
+int jb_attn_decode_wide_supported(int attn_func, int d_head, int width, int block_ctx, int max_len);
 
 /* Tuning hook: workgroup size (multiple of 64, <= 1024) and key/value row pairs in flight per wave (2, 4 or 8) of
  * the generic kernel of jb_attn_decode (defaults 512 / 4; a value <= 0 keeps the current one).  kb < 0 disables the
@@ -245,6 +261,13 @@ typedef struct jb_layer {
      * diag(gamma)·W, beta·W + b, column sums.  NULL = the decode step normalises rows in the projection kernel.
      * Prefill always uses w_attn / w_fc with an explicit LayerNorm. */
     const void *w_attn_f, *w_fc_f; const float *b_attn_f, *b_fc_f, *c1_attn, *c1_fc;
+    /* optional wide-value form of a single-head self-attention layer (fp16 engines, needs the folded images): vcache_w
+     * [n_batch][cache_cap][width] holds v' = v·Wp, the value already carried through attn.c_proj, so the decode step's
+     * attention writes the residual stream directly (jb_attn_decode_wide) and the attn.c_proj launch disappears.
+     * w_attn_fw / b_attn_fw / c1_attn_w: folded decode image [Wq | Wk | Wv·Wp] (width x (2 n_state + width)).
+     * Prefill keeps its own attention over kcache / vcache and attn.c_proj; it additionally fills vcache_w with
+     * v·Wp (one GEMM per sample over the v rows it has just cached, weights w_proj).  NULL = off. */
+    const void* w_attn_fw; const float *b_attn_fw, *c1_attn_w; void* vcache_w;
 } jb_layer;
 
 typedef struct jb_engine_cfg {

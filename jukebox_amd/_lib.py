@@ -33,7 +33,8 @@ class GemvArgs(C.Structure):
                 ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("t_dev", vp),
                 ("ln_fold_c1", vp),
                 ("out2", vp), ("ldo2", i64), ("add2", vp), ("add2_n_stride", i64), ("add2_t_stride", i64),
-                ("x_parts", vp), ("x_ml", vp), ("n_parts", i32), ("n_head", i32), ("d_head", i32)]
+                ("x_parts", vp), ("x_ml", vp), ("n_parts", i32), ("n_head", i32), ("d_head", i32),
+                ("vcache_wide", vp), ("wide", i32)]
 
 
 class SampleParams(C.Structure):
@@ -46,7 +47,8 @@ class Layer(C.Structure):
                 ("b_attn", vp), ("b_proj", vp), ("b_fc", vp), ("b_proj2", vp),
                 ("ln0_g", vp), ("ln0_b", vp), ("ln1_g", vp), ("ln1_b", vp),
                 ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("w_enc_k", vp), ("w_enc_v", vp), ("b_enc_kv", vp),
-                ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp)]
+                ("w_attn_f", vp), ("w_fc_f", vp), ("b_attn_f", vp), ("b_fc_f", vp), ("c1_attn", vp), ("c1_fc", vp),
+                ("w_attn_fw", vp), ("b_attn_fw", vp), ("c1_attn_w", vp), ("vcache_w", vp)]
 
 
 class EngineCfg(C.Structure):
@@ -81,6 +83,9 @@ _SIGS = {
     "jb_tune_attn_decode": (None, [i32, i32]),
     "jb_attn_decode_split": (i32, [i32, vp, i64, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "jb_attn_decode_split_parts": (i32, [i32, i32, i32]),
+    # attn_func, q, ldq, kcache, vcache_w, cache_cap, res, ldr, bias, x_out, ldo, n_batch, d_head, width, block_ctx, t_dev, max_len, stream
+    "jb_attn_decode_wide": (i32, [i32, vp, i64, vp, vp, i32, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
+    "jb_attn_decode_wide_supported": (i32, [i32, i32, i32, i32, i32]),
     "jb_tune_attn_decode_split": (None, [i32, i32]),
     "jb_tune_attn_decode_split_min_keys": (None, [i32]),
     "jb_tune_gemm_lds": (None, [i32]),

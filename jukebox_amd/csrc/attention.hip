@@ -281,6 +281,128 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     }
 }
 
+// Wide-value variant for single-head layers (the upsamplers): the cache row of a key holds v' = v·Wp (W channels), the
+// value already carried through attn.c_proj, so sum_k p_k v'_k IS the projected attention output and this kernel writes
+// the residual stream itself -- the attn.c_proj launch (4.7 us of the 28.6 us layer, a full kernel boundary plus a cold
+// weight stream) is gone.  Grid (sample, slice): slice sl owns output channels [sl*d, (sl+1)*d) and reads the K rows
+// (d channels) plus that slice of the v' rows, the same bytes per workgroup as the kernel above; the W/d slices of a
+// sample recompute identical probabilities.
+template <int ND32>
+__global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f16* __restrict__ q, int64_t ldq,
+                                                               const f16* __restrict__ kc, const f16* __restrict__ vw, int cap,
+                                                               const f16* __restrict__ res, int64_t ldr,
+                                                               const float* __restrict__ bias, f16* __restrict__ out,
+                                                               int64_t ldo, int W, int bc, const int* __restrict__ t_dev) {
+    constexpr int d = ND32 * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nw = blockDim.x >> 6;
+    float* s_ml = smem;                      // [nw][2]
+    float* s_pw = smem + 2 * nw;             // [nw][16]
+    float* s_o = s_pw + 16 * nw;             // [nw][d]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int n = blockIdx.x, sl = blockIdx.y;
+    const f16* qrow = q + (int64_t)n * ldq;
+    f16x8 qf[ND32];
+#pragma unroll
+    for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+    // epilogue operands of this thread's output channel (blockDim.x >= d): requested with the query, used at the end
+    const int och = sl * d + min((int)threadIdx.x, d - 1);
+    const float bias_e = bias[och];
+    const f16 res_e = res[(int64_t)n * ldr + och];
+    jb_issue_fence();
+    const int t = *t_dev;
+    const KeySet ks = decode_key_set(func, t, bc, cap);
+    f16* o = out + (int64_t)n * ldo;
+    if (ks.count == 0) {      // zero rows -> attention output 0 -> c_proj gives its bias
+        if (threadIdx.x < d) o[och] = (f16)jb_round<f16>((float)res_e + jb_round<f16>(jb_round<f16>(bias_e)));
+        return;
+    }
+    const float scale = 1.0f / sqrtf(sqrtf((float)d));
+    const float scale2 = scale * scale;
+    const f16* kbase = kc + ((int64_t)n * cap) * d;
+    const f16* vbase = vw + ((int64_t)n * cap) * W + sl * d;
+    const int c0 = min(lane * 8, d - 8);
+
+    float m_w = -INFINITY, l_w = 0.f;
+    float of[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) of[e] = 0.f;
+    float* pw = s_pw + 16 * wave;
+
+    const int ntiles = (ks.count + 15) >> 4;
+    for (int tt = wave; tt < ntiles; tt += nw) {
+        const int kbase_i = tt * 16;
+        const int ki = min(kbase_i + c, ks.count - 1);
+        const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * d + g * 8;
+        f16x8 kf[ND32];
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) kf[dt] = ld_frag<f16>(kr + dt * 32);
+        f16x8 vv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int vi = min(kbase_i + k, ks.count - 1);
+            vv[k] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * W + c0);
+        }
+        jb_issue_fence_before_use(qf[0]);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) sc = jb_mfma(kf[dt], qf[dt], sc);
+        float pv[4], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = kbase_i + g * 4 + r < ks.count;
+            pv[r] = ok ? jb_round<f16>(jb_round<f16>(sc[r]) * scale2) : -INFINITY;
+            mx = fmaxf(mx, pv[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_w, mx);
+        const float alpha = expf(m_w - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pv[r] = (pv[r] == -INFINITY) ? 0.f : expf(pv[r] - m_new);
+            ps += pv[r];
+        }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l_w = l_w * alpha + ps;
+        m_w = m_new;
+        if (c == 0) *reinterpret_cast<f32x4*>(pw + g * 4) = f32x4{pv[0], pv[1], pv[2], pv[3]};
+        f32x4 p4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p4[i] = *reinterpret_cast<const f32x4*>(pw + i * 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) of[e] *= alpha;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float pr = jb_round<f16>(p4[k >> 2][k & 3]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) of[e] += pr * (float)vv[k][e];
+        }
+    }
+    if (lane == 0) { s_ml[2 * wave] = m_w; s_ml[2 * wave + 1] = l_w; }
+    if (lane * 8 < d) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_o[wave * d + lane * 8 + e] = of[e];
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);
+    float lsum = 0.f;
+    for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] * expf(s_ml[2 * w] - m);
+    const float inv = 1.0f / lsum;
+    if (threadIdx.x < d) {
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += s_o[w * d + threadIdx.x] * expf(s_ml[2 * w] - m);
+        // attn.c_proj's epilogue (bias, round) and the residual add of the block, as jb_gemv does them
+        const float cp = jb_round<f16>(a * inv + jb_round<f16>(bias_e));
+        o[och] = (f16)jb_round<f16>((float)res_e + cp);
+    }
+}
+
 // Key-split variant of the kernel above (the decode step's default in fp16): grid (sample, head, split).  One CU pulls
 // ~100 GB/s, so a single workgroup reading a whole 128-key K and V set (245 KB at d = 480) spends 2-3 us on its own L1
 // fill -- longer than the rest of the chip needs for everything.  Here split s of n_parts takes the 16-key tiles
@@ -460,6 +582,41 @@ extern "C" int jb_attn_decode_split(int attn_func, const void* q, int64_t ldq, c
         default: JB_LAUNCH_DECS(16); break;
     }
 #undef JB_LAUNCH_DECS
+    JB_CHECK_LAUNCH();
+    return JB_OK;
+}
+
+extern "C" int jb_attn_decode_wide_supported(int attn_func, int d_head, int width, int block_ctx, int max_len) {
+    (void)max_len;
+    const bool func_ok = attn_func == 0 || attn_func == 7 || ((attn_func == 1 || attn_func == 2 || attn_func == 3) && block_ctx > 0);
+    return func_ok && split_d_ok(d_head) && d_head <= 512 && width > 0 && width % d_head == 0 && width % 8 == 0;
+}
+
+extern "C" int jb_attn_decode_wide(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache_w,
+                                   int cache_cap, const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo,
+                                   int n_batch, int d_head, int width, int block_ctx, const int* t_dev, int max_len,
+                                   void* stream) {
+    JB_REQUIRE(q && kcache && vcache_w && res && bias && x_out && t_dev, "null pointer");
+    JB_REQUIRE(n_batch > 0 && max_len > 0, "bad dims");
+    JB_REQUIRE(jb_attn_decode_wide_supported(attn_func, d_head, width, block_ctx, max_len) && ldq % 8 == 0,
+               "wide-value attention: self-attention pattern, d_head = 32 x {1,2,4,8,15,16}, width a multiple of d_head");
+    const int nw = 8;
+    const size_t lds = (size_t)(2 * nw + 16 * nw + nw * d_head) * sizeof(float);
+    dim3 grid(n_batch, width / d_head);
+    hipStream_t s = (hipStream_t)stream;
+#define JB_LAUNCH_DECW(ND)                                                                                          \
+    attn_decode_wide_kernel<ND><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,          \
+                                                         (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, bias, \
+                                                         (f16*)x_out, ldo, width, block_ctx, t_dev)
+    switch (d_head / 32) {
+        case 1: JB_LAUNCH_DECW(1); break;
+        case 2: JB_LAUNCH_DECW(2); break;
+        case 4: JB_LAUNCH_DECW(4); break;
+        case 8: JB_LAUNCH_DECW(8); break;
+        case 15: JB_LAUNCH_DECW(15); break;
+        default: JB_LAUNCH_DECW(16); break;
+    }
+#undef JB_LAUNCH_DECW
     JB_CHECK_LAUNCH();
     return JB_OK;
 }

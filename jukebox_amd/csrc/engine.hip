@@ -4,7 +4,8 @@
 // ConditionalAutoregressive2D.sample / primed_sample (jukebox/prior/autoregressive.py:222-236,289-347):
 //   decode step  = L x [LN0+c_attn(+k/v append) | attention (key-split) | c_proj(+merge)+res | LN1+c_fc+gelu | c_proj+res]
 //                  -> logits -> sample + embed(t+1) + (t += 1)            (5 L + 2 launches, one hipGraph);
-//                  the last c_proj also writes `x.float() + cond` for the logits head, the sampler embeds the next position
+//                  the last c_proj also writes `x.float() + cond` for the logits head, the sampler embeds the next position;
+//                  wide-value layers (single head, jb_layer.vcache_w) have no attn.c_proj launch: 4 launches per layer
 //   prefill      = the same per layer on a chunk of positions with the tiled GEMM and the MFMA attention.
 // The position t lives in device memory (*t_dev) so that the captured graph is replayable for every step.
 #include <vector>
@@ -17,6 +18,9 @@ struct JbEngine {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t capture_stream = nullptr;   // the legacy default stream cannot be captured: record on a private one
+    // wide-value layers append k and v' (not v) in the decode step: until the next window's prefill starts again at
+    // position 0, the v rows of decoded positions are stale and a prefill that would attend to them is refused
+    bool v_rows_stale = false;
 };
 
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
@@ -51,6 +55,13 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
                        (L.w_fc_f && L.b_fc_f && L.c1_fc &&
                         jb_gemv_ln_fold_supported(cfg->dtype, cfg->width, cfg->n_mlp, cfg->n_batch)),
                    "folded LayerNorm image of mlp.c_fc is incomplete or unsupported for this shape");
+        const bool any_wide = L.w_attn_fw || L.b_attn_fw || L.c1_attn_w || L.vcache_w;
+        JB_REQUIRE(!any_wide ||
+                       (L.w_attn_fw && L.b_attn_fw && L.c1_attn_w && L.vcache_w &&
+                        cfg->dtype == JB_F16 && cfg->n_head == 1 &&
+                        jb_attn_decode_wide_supported(L.attn_func, cfg->n_state, cfg->width, cfg->block_ctx, cfg->seq_len) &&
+                        jb_gemv_ln_fold_supported(cfg->dtype, cfg->width, 2 * cfg->n_state + cfg->width, cfg->n_batch)),
+                   "wide-value layer: all four fields, fp16, one head, shapes accepted by jb_attn_decode_wide / the folded c_attn");
     }
     JB_REQUIRE((cfg->att_parts == nullptr) == (cfg->att_ml == nullptr), "att_parts and att_ml come together");
     JB_REQUIRE(cfg->bins <= 0 || !cfg->x_out_packed || cfg->ticket, "ticket counter missing");
@@ -74,10 +85,14 @@ extern "C" int jb_engine_destroy(void* handle) {
     return JB_OK;
 }
 
+static bool layer_wide(const jb_engine_cfg& c, const jb_layer& L);
+
 extern "C" int jb_engine_launches_per_step(void* handle) {
     if (!handle) return 0;
-    const jb_engine_cfg& c = ((JbEngine*)handle)->cfg;
-    return 5 * c.n_layers + 2;
+    const JbEngine* e = (const JbEngine*)handle;
+    int n = 5 * e->cfg.n_layers + 2;
+    for (const jb_layer& L : e->layers) n -= layer_wide(e->cfg, L) ? 1 : 0;
+    return n;
 }
 
 #define JB_TRY(call)                \
@@ -114,6 +129,28 @@ static int layer_split_parts(const jb_engine_cfg& c, const jb_layer& L) {
     return jb_attn_decode_split_parts(c.dtype, c.n_state / c.n_head, layer_max_keys(c, L));
 }
 
+// Wide-value layer (jb_layer.vcache_w): the decode attention writes the residual stream, no attn.c_proj launch.  Layers
+// whose key sets are long enough for the key split keep the split (+ merging c_proj) form.
+static bool layer_wide(const jb_engine_cfg& c, const jb_layer& L) {
+    return L.vcache_w && L.w_attn_fw && layer_split_parts(c, L) == 0;
+}
+
+// ln_0 + attn.c_attn of the decode step with the k / v (or k / v') rows appended at *t_dev.
+static void fill_c_attn(jb_gemv_args& g, const jb_engine_cfg& c, const jb_layer& L) {
+    const int S = c.n_state;
+    g = {};
+    fill_ln_proj(g, c, L, 0);
+    g.x = c.x_a; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
+    if (L.attn_func == JB_ATTN_CROSS) { g.J = S; return; }        // query only; k/v come from the encoder (set_encoder_kv)
+    g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
+    if (layer_wide(c, L)) {
+        g.W = L.w_attn_fw; g.bias = L.b_attn_fw; g.ln_fold_c1 = L.c1_attn_w; g.ln_gamma = g.ln_beta = nullptr;
+        g.J = 2 * S + c.width; g.vcache = nullptr; g.vcache_wide = L.vcache_w; g.wide = c.width;
+    } else {
+        g.J = 3 * S; g.vcache = L.vcache;
+    }
+}
+
 static int enqueue_embed(JbEngine* e, int t0, hipStream_t s) {
     const jb_engine_cfg& c = e->cfg;
     return jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
@@ -127,23 +164,19 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
     for (int l = 0; l < c.n_layers; ++l) {
         const jb_layer& L = e->layers[l];
-        jb_gemv_args g = {};
+        jb_gemv_args g;
         // a7/a8/a9: ln_0 + c_attn, k/v appended at *t_dev
-        fill_ln_proj(g, c, L, 0);
-        g.x = c.x_a; g.out = c.q; g.ldo = S; g.act = JB_ACT_NONE;
-        if (L.attn_func == JB_ATTN_CROSS) {
-            g.J = S;                         // query only; k/v come from the encoder (set_encoder_kv)
-        } else {
-            g.J = 3 * S;
-            g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
-        }
+        fill_c_attn(g, c, L);
         JB_TRY(jb_gemv(&g, s));
         // attention, then attn.c_proj + residual: x_b = x_a + a
         const int parts = layer_split_parts(c, L);
         g = {};
         g.dtype = c.dtype; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
         g.out = c.x_b; g.ldo = W; g.res = c.x_a; g.ldr = W;
-        if (parts > 0) {
+        if (layer_wide(c, L)) {
+            JB_TRY(jb_attn_decode_wide(L.attn_func, c.q, S, L.kcache, L.vcache_w, L.cache_cap, c.x_a, W, L.b_proj, c.x_b, W, N,
+                                       S, W, c.block_ctx, c.t_dev, c.seq_len, s));
+        } else if (parts > 0) {
             JB_TRY(jb_attn_decode_split(L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att_parts, c.att_ml, N, H, d,
                                         c.block_ctx, c.t_dev, layer_max_keys(c, L), parts, s));
             g.x_parts = c.att_parts; g.x_ml = c.att_ml; g.n_parts = parts; g.n_head = H; g.d_head = d;
@@ -152,7 +185,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
                                   c.block_ctx, c.t_dev, c.seq_len, s));
             g.x = c.att;
         }
-        JB_TRY(jb_gemv(&g, s));
+        if (!layer_wide(c, L)) JB_TRY(jb_gemv(&g, s));
         // ln_1 + mlp.c_fc + quick_gelu
         g = {};
         fill_ln_proj(g, c, L, 1);
@@ -187,6 +220,7 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
     set_int_kernel<<<1, 1, 0, s>>>(e->cfg.t_dev, t0);
     JB_CHECK_LAUNCH();
     if (n_steps == 0) return JB_OK;
+    for (const jb_layer& L : e->layers) e->v_rows_stale = e->v_rows_stale || layer_wide(e->cfg, L);
     JB_TRY(enqueue_embed(e, t0, s));         // later positions are embedded by the sampler of the step before
     if (!use_graph) {
         for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
@@ -247,6 +281,9 @@ extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
     JB_REQUIRE(t0 >= 0 && n_t > 0 && t0 + n_t <= c.seq_len, "chunk outside the sequence");
     JB_REQUIRE(c.chunk_cap > 0 && c.c_xa && c.c_xb && c.c_h && c.c_q && c.c_att && c.c_mlp, "prefill buffers missing");
     JB_REQUIRE(!c.preds || c.c_xf, "c_xf required when preds is set");
+    if (t0 == 0) e->v_rows_stale = false;
+    JB_REQUIRE(!e->v_rows_stale, "prefill at t0 > 0 after decode steps: wide-value layers did not append v rows (prefill the "
+                                 "window from position 0, or build the engine without wide-value layers)");
     hipStream_t s = (hipStream_t)stream;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
     for (int off = 0; off < n_t; off += c.chunk_cap) {
@@ -273,6 +310,19 @@ extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
                 g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.cache_t0 = p0;
             }
             JB_TRY(jb_gemm(&g, s));
+            if (L.vcache_w && p0 < L.cache_cap) {
+                // wide-value layer: v' = v·Wp for the decode steps, from the v rows just cached.  One flat GEMM per sample
+                // (its rows are contiguous in both caches): 4x fewer FLOPs than carrying Wv·Wp as extra c_attn columns
+                // (measured: +104 ms per 4096 x 16-token window that way).
+                const int Cn = (C < L.cache_cap - p0) ? C : L.cache_cap - p0;
+                for (int n = 0; n < N; ++n) {
+                    const int64_t row = (int64_t)n * L.cache_cap + p0;
+                    jb_gemm_args gv;
+                    base(gv, (const f16*)L.vcache + row * S, S, S, L.w_proj, nullptr, W, (f16*)L.vcache_w + row * W, W);
+                    gv.n_seq = 1; gv.t_in = gv.t_out = Cn; gv.in_seq_stride = gv.out_seq_stride = Cn;
+                    JB_TRY(jb_gemm(&gv, s));
+                }
+            }
             JB_TRY(jb_attn_prefill(c.dtype, L.attn_func, c.c_q, L.kcache, L.vcache, L.cache_cap, c.c_att, N, H, d,
                                    c.block_ctx, p0, C, s));
             if (c.rec_out && l == c.rec_layer)
@@ -329,10 +379,8 @@ extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, voi
         for (int i = 0; i < reps; ++i)
             for (int l = 0; l < c.n_layers; ++l) {
                 const jb_layer& L = e->layers[l];
-                jb_gemv_args g = {};
-                fill_ln_proj(g, c, L, 0);
-                g.x = c.x_a; g.J = 3 * S; g.out = c.q; g.ldo = S;
-                g.qkv_split = 1; g.S = S; g.kcache = L.kcache; g.vcache = L.vcache; g.cache_cap = L.cache_cap; g.t_dev = c.t_dev;
+                jb_gemv_args g;
+                fill_c_attn(g, c, L);
                 JB_TRY(jb_gemv(&g, s));
                 g = {};
                 fill_ln_proj(g, c, L, 1);
@@ -352,7 +400,13 @@ extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, voi
     (void)hipEventDestroy(e1);
     const double launches = 2.0 * c.n_layers * n_steps;
     const double esz = c.dtype == JB_F16 ? 2.0 : 4.0;
-    const double b_attn = (double)W * 3 * S * esz + (double)N * W * esz + (double)N * 3 * S * esz;
+    // ALGORITHMIC bytes: a wide-value layer's c_attn streams W x (2S + W) weights, but the work it stands for is the
+    // reference's c_attn (W x 3S) plus the attn.c_proj it absorbed (S x W) -- only those are counted
+    double b_attn = 0.0;
+    for (const jb_layer& L : e->layers) {
+        const double J = L.attn_func == JB_ATTN_CROSS ? S : (layer_wide(c, L) ? 4.0 * S : 3.0 * S);
+        b_attn += ((double)W * J * esz + (double)N * W * esz + (double)N * J * esz) / c.n_layers;
+    }
     const double b_fc = (double)W * M * esz + (double)N * W * esz + (double)N * M * esz;
     out[0] = (double)ms * 1e3 / launches;
     out[1] = launches;

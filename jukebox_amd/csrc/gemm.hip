@@ -67,12 +67,25 @@ struct EpiParams {
     int J, act; float res_scale;
     int qkv_split, S;
     void* kcache; void* vcache; int cache_cap;
+    // column layout of a q/k/v split: q [0,S) | k [S,2S) | v [2S,2S+v_cols) (v_cols = S or 0) | v' [.., ..+v2w) -- v' is the
+    // value already carried through attn.c_proj (single-head models, see jb_attn_decode_wide), cache rows of v2w elements
+    void* vcache2; int v2w, v_cols;
     int vec_out;        // 4 consecutive columns may be stored as one vector
     // decode step, last layer: a second fp32 copy out2[row][j] = value + add2[row*add2_n + t*add2_t + j] (t = *t_dev) --
     // `x.float() + cond` before the logits head (autoregressive.py:226-227), fused into mlp.c_proj's epilogue
     float* out2; int64_t ldo2;
     const float* add2; int64_t add2_n, add2_t;
 };
+
+// Column j of a q/k/v(/v') projection goes to the query row or to row `cache_row` of the matching cache.
+template <typename T>
+__device__ __forceinline__ void qkv_store(const EpiParams& p, float x, int64_t orow, int j, int64_t cache_row) {
+    if (j < p.S) { ((T*)p.out)[orow * p.ldo + j] = (T)x; return; }
+    if (cache_row < 0) return;
+    if (j < 2 * p.S) ((T*)p.kcache)[cache_row * p.S + (j - p.S)] = (T)x;
+    else if (j < 2 * p.S + p.v_cols) ((T*)p.vcache)[cache_row * p.S + (j - 2 * p.S)] = (T)x;
+    else ((T*)p.vcache2)[cache_row * p.v2w + (j - 2 * p.S - p.v_cols)] = (T)x;
+}
 
 // vals[r] is the accumulator of column jb + r of output row `orow`; cache_row < 0 disables the k/v write.
 template <typename T>
@@ -115,15 +128,7 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& p, f32x4 acc, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (!ok[r]) continue;
-            int j = jb + r;
-            int part = j / p.S;
-            int jj = j - part * p.S;
-            if (part == 0) {
-                ((T*)p.out)[orow * p.ldo + jj] = (T)v[r];
-            } else if (cache_row >= 0) {
-                T* c = (T*)(part == 1 ? p.kcache : p.vcache);
-                c[cache_row * p.S + jj] = (T)v[r];
-            }
+            qkv_store<T>(p, v[r], orow, jb + r, cache_row);
         }
     }
 }
@@ -140,9 +145,7 @@ __device__ __forceinline__ void epilogue_store1(const EpiParams& p, float x, int
     if (!p.qkv_split) {
         ((T*)p.out)[orow * p.ldo + j] = (T)x;
     } else {
-        const int part = j / p.S, jj = j - part * p.S;
-        if (part == 0) ((T*)p.out)[orow * p.ldo + jj] = (T)x;
-        else if (cache_row >= 0) ((T*)(part == 1 ? p.kcache : p.vcache))[cache_row * p.S + jj] = (T)x;
+        qkv_store<T>(p, x, orow, j, cache_row);
     }
 }
 
@@ -379,6 +382,7 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     p.epi.J = a->J; p.epi.act = a->act; p.epi.res_scale = a->res_scale;
     p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
     p.epi.cache_cap = a->cache_cap;
+    p.epi.vcache2 = nullptr; p.epi.v2w = 0; p.epi.v_cols = a->S;
     p.epi.vec_out = !a->qkv_split && (a->ldo % 4 == 0) && aligned_to(a->out, 4 * esz);
     p.epi.out2 = nullptr; p.epi.ldo2 = 0; p.epi.add2 = nullptr; p.epi.add2_n = p.epi.add2_t = 0;
     dim3 grid((unsigned)((p.m_total + 255) / 256), (unsigned)((p.njt + 3) / 4));
@@ -1074,7 +1078,9 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     JB_REQUIRE(a->dtype == JB_F32 || a->dtype == JB_F16, "bad dtype");
     JB_REQUIRE(a->n_rows >= 1 && a->n_rows <= 64, "n_rows must be 1..64");
     JB_REQUIRE(a->K > 0 && a->J > 0, "empty problem");
-    JB_REQUIRE(!a->qkv_split || (a->S > 0 && a->J == 3 * a->S && a->kcache && a->vcache && a->t_dev), "bad qkv split");
+    JB_REQUIRE(a->wide >= 0 && (a->wide == 0 || (a->qkv_split && a->vcache_wide)), "wide v' columns need qkv_split and vcache_wide");
+    JB_REQUIRE(!a->qkv_split || (a->S > 0 && a->kcache && a->t_dev && (a->vcache || a->wide > 0) &&
+                                 a->J == 2 * a->S + (a->vcache ? a->S : 0) + a->wide), "bad qkv split");
     JB_REQUIRE(!a->out2 || (a->ldo2 >= a->J && (!a->add2 || a->t_dev)), "bad second output (out2 / add2 need ldo2 >= J and t_dev)");
     JB_REQUIRE(!a->out2 || (!a->ln_gamma && !a->ln_fold_c1 && !a->x_parts), "out2 is available on the plain projection only");
     if (a->x_parts) {
@@ -1111,6 +1117,7 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     p.epi.J = a->J; p.epi.act = a->act; p.epi.res_scale = 1.0f;
     p.epi.qkv_split = a->qkv_split; p.epi.S = a->S; p.epi.kcache = a->kcache; p.epi.vcache = a->vcache;
     p.epi.cache_cap = a->cache_cap;
+    p.epi.vcache2 = a->vcache_wide; p.epi.v2w = a->wide; p.epi.v_cols = a->vcache ? a->S : 0;
     p.epi.vec_out = !a->qkv_split && (a->ldo % 4 == 0) && aligned_to(a->out, 4 * esz);
     p.epi.out2 = a->out2; p.epi.ldo2 = a->ldo2; p.epi.add2 = a->out2 ? a->add2 : nullptr;
     p.epi.add2_n = a->add2_n_stride; p.epi.add2_t = a->add2_t_stride;

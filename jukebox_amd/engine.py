@@ -44,7 +44,7 @@ class PackedPrior:
 
     def __init__(self, sd, prefix, *, seq_len, bins, width, depth, heads, attn_order, blocks=None, m_attn=0.25, m_mlp=1.0,
                  prime_len=None, y_cond=False, add_cond_after=True, fp16=True, encoder_dims=0, only_encode=False,
-                 fold_ln=None, device="cuda"):
+                 fold_ln=None, wide_v=None, device="cuda"):
         L.lib()
         self.device = torch.device(device)
         self.T, self.bins, self.W = seq_len, bins, width
@@ -63,6 +63,12 @@ class PackedPrior:
         if fold_ln is None:
             fold_ln = bool(int(os.environ["JB_FOLD_LN"])) if "JB_FOLD_LN" in os.environ else fp16
         self.fold_ln = bool(fold_ln) and not only_encode
+        # Wide-value layers (jb_layer.vcache_w): single-head fp16 models cache v' = v·Wp, the value already carried through
+        # attn.c_proj, so the decode step's attention writes the residual stream and the attn.c_proj launch disappears
+        # (4 launches per layer instead of 5).  Needs the folded c_attn.  JB_WIDE_V=0/1 overrides.
+        if wide_v is None:
+            wide_v = bool(int(os.environ["JB_WIDE_V"])) if "JB_WIDE_V" in os.environ else True
+        self.wide_v = bool(wide_v) and self.fold_ln and fp16 and heads == 1
         dev, dt = self.device, self.dtype
         g = lambda name: sd[prefix + name].to(dev).contiguous()
         f32 = lambda name: g(name).float().contiguous()
@@ -82,7 +88,7 @@ class PackedPrior:
                        bs=[f32(p + n) for n in ("attn.c_attn.b", "attn.c_proj.b", "mlp.c_fc.b", "mlp.c_proj.b")],
                        lns=[f32(p + n) for n in ("ln_0.weight", "ln_0.bias", "ln_1.weight", "ln_1.bias")],
                        cap=self.prime_cap if func == 7 else (self.enc_len if func == 6 else self.T),
-                       f_attn=None, f_fc=None, enc=None, b_enc=None)
+                       f_attn=None, f_fc=None, enc=None, b_enc=None, wide=None)
             if func == 6:
                 # c_enc_kv (n_in, 2*n_state): key half and value half as separate packed matrices
                 wkv = g(p + "attn.c_enc_kv.w")
@@ -94,10 +100,27 @@ class PackedPrior:
                     lay["f_attn"] = H.FoldedLN(g(p + "attn.c_attn.w"), lay["bs"][0], lay["lns"][0], lay["lns"][1], dt)
                 if H.ln_fold_supported(dt, W, M, 1):
                     lay["f_fc"] = H.FoldedLN(g(p + "mlp.c_fc.w"), lay["bs"][2], lay["lns"][2], lay["lns"][3], dt)
-                for f in (lay["f_attn"], lay["f_fc"]):
-                    if f is not None:
+                if self.wide_v and func != 6 and lay["f_attn"] is not None and H.ln_fold_supported(dt, W, 2 * S + W, 1) and \
+                        L.lib().jb_attn_decode_wide_supported(func, S, W, self.block_ctx, seq_len):
+                    lay["wide"] = self._wide_images(g(p + "attn.c_attn.w"), g(p + "attn.c_proj.w"), lay["bs"][0],
+                                                    lay["lns"][0], lay["lns"][1])
+                for f in (lay["f_attn"], lay["f_fc"], lay["wide"] and lay["wide"]["fold"]):
+                    if f:
                         f.wf = None                  # the unpacked image is bind-time only
             self.layers.append(lay)
+
+    def _wide_images(self, w_attn, w_proj, b_attn, ln_g, ln_b):
+        """c_attn images of a wide-value layer.  With one head, attn.c_proj(sum_k p_k v_k) = sum_k p_k (v_k·Wp) + bp
+        (factored_attention.py:104-108,118-121 are linear in v), so the cache may hold v' = v·Wp = LN(x)·(Wv·Wp) + bv·Wp:
+        the decode image is the folded [Wq | Wk | Wv·Wp]; prefill keeps its own c_attn / attention / c_proj and fills v' from
+        the v rows with one more GEMM (jb_engine_prefill).  Wv and Wp are first rounded to the engine dtype, as the
+        reference uses them; the product is rounded once."""
+        S, dt = self.S, self.dtype
+        w16, wp16 = w_attn.to(dt), w_proj.to(dt)
+        vp = (w16[:, 2 * S:].double() @ wp16.double()).to(dt)                          # (W, W)
+        b_vp = (b_attn[2 * S:].double() @ wp16.double()).float()
+        w_dec = torch.cat([w16[:, :2 * S], vp], 1).contiguous()
+        return dict(fold=H.FoldedLN(w_dec, torch.cat([b_attn[:2 * S], b_vp]).contiguous(), ln_g, ln_b, dt))
 
     def weight_bytes(self):
         n = self.x_out.data.numel() * 4 if self.x_out is not None else 0
@@ -131,7 +154,7 @@ class PriorEngine:
         dev, dt = self.device, self.dtype
         N, T, S, W, M = self.N, self.T, self.S, self.W, self.M
         self.layers_c = (L.Layer * self.depth)()
-        self.kcaches, self.vcaches = [], []
+        self.kcaches, self.vcaches, self.vcaches_w = [], [], []
         for d, lay in enumerate(pk.layers):
             kc = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
             vc = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
@@ -153,6 +176,14 @@ class PriorEngine:
                     lc.w_fc_f, lc.b_fc_f, lc.c1_fc = f.pw.ptr, f.bias.data_ptr(), f.c1.data_ptr()
             if lay["func"] == 6:
                 lc.w_enc_k, lc.w_enc_v, lc.b_enc_kv = lay["enc"][0].ptr, lay["enc"][1].ptr, lay["b_enc"].data_ptr()
+            wd = lay["wide"]
+            if wd is not None and lc.w_attn_f and H.ln_fold_supported(dt, W, 2 * S + W, N):
+                vw = torch.zeros((N, lay["cap"], W), dtype=dt, device=dev)
+                self.vcaches_w.append(vw)
+                lc.w_attn_fw, lc.b_attn_fw, lc.c1_attn_w = wd["fold"].pw.ptr, wd["fold"].bias.data_ptr(), wd["fold"].c1.data_ptr()
+                lc.vcache_w = vw.data_ptr()
+            else:
+                self.vcaches_w.append(None)
 
         e = lambda *shape, dtype=dt: torch.zeros(shape, dtype=dtype, device=dev)
         Cc = self.chunk_cap
@@ -289,7 +320,8 @@ class PriorEngine:
         return float(L.lib().jb_engine_step_bytes(self.handle, int(t)))
 
     def cache_bytes(self):
-        return sum(k.numel() * k.element_size() * 2 for k in self.kcaches)
+        return sum(k.numel() * k.element_size() * 2 for k in self.kcaches) + \
+            sum(v.numel() * v.element_size() for v in self.vcaches_w if v is not None)
 
     def weight_bytes(self):
         return self.packed.weight_bytes()

@@ -164,19 +164,28 @@ def tap_view(pw, taps):
 
 
 def gemv(x, pw, bias=None, ln=None, res=None, act=L.ACT_NONE, out=None, eps=1e-5, ln_fold=None, parts=None, out2=None,
-         add2=None, t_dev=None):
+         add2=None, t_dev=None, qkv=None):
     """Decode-step skinny GEMM (see jb_gemv).  x: (n_rows<=64, K).  ln = (gamma, beta): normalise the rows in the
     kernel; ln_fold = FoldedLN: the folded form (pw / bias are taken from it); parts = (x_parts (N, P, K) f16,
     ml (N, H, P, 2) fp32): the operand is the merge of the key-split attention's partial states (x must be None);
-    out2 (N, J) fp32 [+ add2 (N, T, J) fp32 read at row *t_dev]: the second, fp32 output of the plain projection."""
+    out2 (N, J) fp32 [+ add2 (N, T, J) fp32 read at row *t_dev]: the second, fp32 output of the plain projection;
+    qkv = (S, kcache, vcache or None, vcache_wide or None): c_attn of the decode step -- columns q | k | v | v' with the
+    cache rows written at *t_dev; returns q (N, S)."""
     if ln_fold is not None:
         assert ln is None and bias is None and pw is None
         pw, bias = ln_fold.pw, ln_fold.bias
     _chk_cuda(x, bias, res, out, out2, add2)
     src = x if x is not None else parts[0]
     if out is None:
-        out = torch.empty((src.shape[0], pw.J), dtype=src.dtype, device=src.device)
+        out = torch.empty((src.shape[0], qkv[0] if qkv is not None else pw.J), dtype=src.dtype, device=src.device)
     a = L.GemvArgs()
+    if qkv is not None:
+        S, kc, vc, vw = qkv
+        _chk_cuda(kc, vc, vw, t_dev)
+        a.qkv_split, a.S, a.kcache, a.vcache, a.cache_cap = 1, S, kc.data_ptr(), L.ptr(vc), kc.shape[1]
+        if vw is not None:
+            a.vcache_wide, a.wide = vw.data_ptr(), vw.shape[2]
+        a.t_dev = L.ptr(t_dev)
     a.dtype = L.dtype_code(src.dtype)
     a.n_rows = src.shape[0]
     if x is not None:
@@ -211,6 +220,19 @@ def attn_decode(func, q, kcache, vcache, n_head, block_ctx, t_dev, max_len):
     L.check(L.lib().jb_attn_decode(L.dtype_code(q.dtype), func, q.data_ptr(), q.stride(0), kcache.data_ptr(),
                                    vcache.data_ptr(), kcache.shape[1], out.data_ptr(), out.stride(0), N, n_head,
                                    S // n_head, block_ctx or 0, t_dev.data_ptr(), max_len, L.stream()))
+    return out
+
+
+def attn_decode_wide(func, q, kcache, vcache_w, res, bias, block_ctx, t_dev, max_len):
+    """Wide-value decode attention of a single-head fp16 layer (jb_attn_decode_wide): q (N, S); kcache (N, cap, S);
+    vcache_w (N, cap, W) rows v' = v·Wp; returns x_out (N, W) = res + (sum_k p_k v'_k + bias)."""
+    _chk_cuda(q, kcache, vcache_w, res, bias, t_dev)
+    N, S = q.shape
+    W = vcache_w.shape[2]
+    out = torch.empty_like(res)
+    L.check(L.lib().jb_attn_decode_wide(func, q.data_ptr(), q.stride(0), kcache.data_ptr(), vcache_w.data_ptr(),
+                                        kcache.shape[1], res.data_ptr(), res.stride(0), bias.data_ptr(), out.data_ptr(),
+                                        out.stride(0), N, S, W, block_ctx or 0, t_dev.data_ptr(), max_len, L.stream()))
     return out
 
 

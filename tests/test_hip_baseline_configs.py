@@ -226,8 +226,9 @@ def test_config3_1b_lyrics_top_prior_full_depth():
 
 
 def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
-    """The timed configuration is fp16 with folded LayerNorm and the key-split attention, whose rounding points differ from
-    the reference-ordered fp16 path.  Gate: on the upsampler geometry (width 1920, depth 72, block_ctx 64), N = 16, with
+    """The timed configuration is fp16 with folded LayerNorm and wide-value layers (v' = v·Wp cached, no attn.c_proj launch),
+    whose rounding points differ from the reference-ordered fp16 path; the five-launch form and the key-split attention
+    are gated the same way.  Gate: on the upsampler geometry (width 1920, depth 72, block_ctx 64), N = 16, with
     OUTLIER channels in the residual stream and in the LayerNorm gains (what real checkpoints have and what stresses the
     sum-of-squares form of the folded variance), every engine teacher-forced on the fp32 engine's greedy stream:
       * the production engine's logits (and those of the engine with the key split forced on) are as close to fp32 as those of the reference-ordered fp16 engine (explicit
@@ -252,12 +253,13 @@ def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
 
     from jukebox_amd import _lib as L
 
-    def make(fp16, fold_ln, split):
+    def make(fp16, fold_ln, split, wide=None):
         # split: None = the default policy (this geometry's key sets are <= 128 keys: not split), True = force the key split
+        # wide: None = the default policy (single head + fp16 + folded LayerNorm: wide-value layers), False = five launches
         monkeypatch.setenv("JB_ATTN_SPLIT_OFF", "1" if split is False else "0")
         L.lib().jb_tune_attn_decode_split_min_keys(1 if split else 129)
         e = PriorEngine(sd, "", n_batch=N, seq_len=seq, bins=bins, width=W, depth=depth, heads=1, attn_order=2, blocks=128,
-                        y_cond=True, fp16=fp16, fold_ln=fold_ln, want_preds=True, chunk_cap=512)
+                        y_cond=True, fp16=fp16, fold_ln=fold_ln, want_preds=True, chunk_cap=512, wide_v=wide)
         e.set_cond(x_cond, yc)
         e.set_sampling(temp=1.0, top_k=1)
         e.tokens[:, :t0] = prefix
@@ -272,9 +274,11 @@ def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
     e32.close()
     del e32
     stats = {}
-    for name, fold_ln, split in (("production", True, None), ("key-split", True, True), ("reference-ordered", False, False)):
-        e16 = make(True, fold_ln, split)
+    for name, fold_ln, split, wide in (("production", True, None, None), ("five-launch", True, None, False),
+                                       ("key-split", True, True, False), ("reference-ordered", False, False, False)):
+        e16 = make(True, fold_ln, split, wide)
         assert e16.fold_ln == fold_ln and (e16.att_parts is not None) == bool(split)
+        assert e16.launches_per_step == (4 if name == "production" else 5) * depth + 2
         for i in range(n_steps):                   # teacher-forced: the fp16 engine always sees the fp32 stream's tokens
             e16.tokens[:, :t0 + i] = z32[:, :t0 + i]
             e16.decode(t0 + i, 1)
@@ -287,7 +291,7 @@ def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
     print("fp16 vs fp32 (max |dlogit|, mean |dlogit|, top-1 agreement), logit std %.3f:" % p32.std(), stats)
     L.lib().jb_tune_attn_decode_split_min_keys(129)
     mx_r, mean_r, agree_r = stats["reference-ordered"]
-    for name in ("production", "key-split"):
+    for name in ("production", "five-launch", "key-split"):
         mx_p, mean_p, agree_p = stats[name]
         assert mx_p <= 1.5 * mx_r + 1e-3 and mean_p <= 1.25 * mean_r + 1e-4, (name, stats)
         assert agree_p >= agree_r - 0.01 and agree_p >= 0.95, (name, stats)

@@ -131,10 +131,11 @@ def _random_sd(rng, width, depth, bins, seq, funcs_order, m_attn=0.25, scale=0.0
     return {k: np.asarray(v, np.float32) for k, v in sd.items()}
 
 
-@pytest.mark.parametrize("fp16", [False, True])
-def test_seeded_model_vs_oracle(PE, fp16):
+@pytest.mark.parametrize("fp16,wide_v", [(False, False), (True, False), (True, True)])
+def test_seeded_model_vs_oracle(PE, fp16, wide_v):
     """Production-shaped head (1 head x 480 channels, the upsampler geometry) at reduced depth/sequence:
-    primed (chunked prefill) + decode, N = 16, against the oracle on the same seeded weights."""
+    primed (chunked prefill) + decode, N = 16, against the oracle on the same seeded weights.  wide_v: the decode step
+    of the fp16 engine without the attn.c_proj launch (v' = v·Wp cached by prefill and by c_attn)."""
     rng = np.random.default_rng(123)
     width, depth, bins, seq, blocks = 1920, 3, 256, 512, 8
     sd = _random_sd(rng, width, depth, bins, seq, 2, scale=0.02)
@@ -145,8 +146,10 @@ def test_seeded_model_vs_oracle(PE, fp16):
     z_ref, p_ref = ora.primed_sample(N, prime, xc, None, fp16=fp16, top_k=1, get_preds=True, chunk_size=64,
                                      sample_tokens=n_total)
     eng = PE(to_dev(sd), "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=1, attn_order=2,
-             blocks=blocks, y_cond=False, fp16=fp16, want_preds=True, chunk_cap=64)
+             blocks=blocks, y_cond=False, fp16=fp16, want_preds=True, chunk_cap=64, wide_v=wide_v)
     eng.set_cond(torch.from_numpy(xc), None)
+    assert eng.launches_per_step == (4 if wide_v else 5) * depth + 2
+    assert all((v is not None) == wide_v for v in eng.vcaches_w)
     eng.set_sampling(temp=1.0, top_k=1)
     eng.tokens[:, :n_prime] = torch.from_numpy(prime).cuda()
     eng.prefill(0, n_prime)

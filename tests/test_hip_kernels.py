@@ -340,6 +340,91 @@ def test_attn_decode_upsampler_shape(H, func):
         assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max()), (func, t)
 
 
+@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("N,K,S,keep_v", [(16, 1920, 480, False), (5, 256, 64, False), (16, 256, 64, True), (3, 128, 32, False)])
+def test_gemv_qkv_wide_columns(H, N, K, S, keep_v, fold):
+    """c_attn of a wide-value layer in the decode step (jb_gemv_args.vcache_wide): columns q | k | [v |] v' with v' rows of
+    K = width elements appended to their own cache at *t_dev; explicit and folded LayerNorm."""
+    rng = np.random.default_rng(N + K + S)
+    f16 = torch.float16
+    cap, t = 9, 6
+    J = 2 * S + (S if keep_v else 0) + K
+    x = h16(rng.standard_normal((N, K)).astype(np.float32))
+    W = h16((rng.standard_normal((K, J)) / np.sqrt(K)).astype(np.float32))
+    b = (0.1 * rng.standard_normal(J)).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    if fold and not H.ln_fold_supported(f16, K, J, N):
+        pytest.skip("folded form not available for this shape")
+    kc = torch.zeros((N, cap, S), dtype=f16, device="cuda")
+    vc = torch.zeros((N, cap, S), dtype=f16, device="cuda") if keep_v else None
+    vw = torch.zeros((N, cap, K), dtype=f16, device="cuda")
+    t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+    if fold:
+        f = H.FoldedLN(dev(W), dev(b), dev(gam), dev(bet), f16)
+        q = H.gemv(dev(x, f16), None, ln_fold=f, qkv=(S, kc, vc, vw), t_dev=t_dev)
+    else:
+        q = H.gemv(dev(x, f16), H.pack_conv1d_w(dev(W), f16), bias=dev(b), ln=(dev(gam), dev(bet)), qkv=(S, kc, vc, vw), t_dev=t_dev)
+    torch.cuda.synchronize()
+    mu, var = x.mean(1, keepdims=True), x.var(1, keepdims=True)
+    xn = (x - mu) / np.sqrt(var + 1e-5) * gam + bet
+    want = xn @ W + b
+    tol = 6e-3 * max(1.0, np.abs(want).max())
+    assert tuple(q.shape) == (N, S)
+    assert np.abs(q.float().cpu().numpy() - want[:, :S]).max() < tol
+    assert np.abs(kc[:, t].float().cpu().numpy() - want[:, S:2 * S]).max() < tol
+    v0 = 2 * S
+    if keep_v:
+        assert np.abs(vc[:, t].float().cpu().numpy() - want[:, v0:v0 + S]).max() < tol
+        v0 += S
+    assert np.abs(vw[:, t].float().cpu().numpy() - want[:, v0:]).max() < tol
+    mask = np.ones(cap, bool); mask[t] = False
+    assert (kc[:, mask] == 0).all() and (vw[:, mask] == 0).all() and (vc is None or (vc[:, mask] == 0).all())
+
+
+@pytest.mark.parametrize("func", [0, 1, 2, 3, 7])
+@pytest.mark.parametrize("d,W_,bc,T", [(480, 1920, 128, 1024), (64, 256, 8, 96), (32, 32, 8, 96), (256, 1024, 128, 8192)])
+def test_attn_decode_wide(H, func, d, W_, bc, T):
+    """Wide-value decode attention (jb_attn_decode_wide): with v' = v·Wp cached, res + (sum_k p_k v'_k + bp) equals the
+    residual stream after jb_attn_decode + attn.c_proj (the five-launch form) up to the half rounding points, and equals
+    the fp32 evaluation on the same half operands within the half output bound.  Upsampler geometry (1 x 480, width 1920,
+    block length 128), block rows 0 and 63 of the transpose pattern, empty key sets (prev_block in block 0)."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(func * 100 + d + T)
+    N = 5
+    f16 = torch.float16
+    prime_r = 448 if T >= 960 else 24
+    cap = prime_r if func == 7 else T
+    assert L.lib().jb_attn_decode_wide_supported(func, d, W_, bc, T) == 1
+    assert L.lib().jb_attn_decode_wide_supported(6, d, W_, bc, T) == 0 and L.lib().jb_attn_decode_wide_supported(func, d + 8, W_, bc, T) == 0
+    K = h16(rng.standard_normal((N, cap, d)).astype(np.float32))
+    V = h16(rng.standard_normal((N, cap, d)).astype(np.float32))
+    Wp = h16((rng.standard_normal((d, W_)) / np.sqrt(d)).astype(np.float32))
+    bp = (0.1 * rng.standard_normal(W_)).astype(np.float32)
+    Vw = h16(V @ Wp)                                                       # the rows prefill / c_attn would have cached
+    res = h16(rng.standard_normal((N, W_)).astype(np.float32))
+    kc, vc, vw = dev(K, f16), dev(V, f16), dev(Vw, f16)
+    pw = H.pack_conv1d_w(dev(Wp), f16)
+    sc2 = (1.0 / math.sqrt(math.sqrt(d))) ** 2
+    ts = sorted({0, 1, bc - 1, bc, bc + 1, 2 * bc + 3, T // 2 + 5, T - bc - 1, T - 1})
+    for t in ts:
+        q = h16(rng.standard_normal((N, 1, d)).astype(np.float32))
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        got = H.attn_decode_wide(func, dev(q[:, 0], f16), kc, vw, dev(res, f16), dev(bp), bc, t_dev, T).float().cpu().numpy()
+        idx = decode_key_index(func, t, bc, prime_r if func == 7 else None)
+        if idx is None:
+            a = np.zeros((N, W_), np.float32)
+        else:
+            w = h16(h16(np.einsum("nd,nkd->nk", q[:, 0], K[:, idx])) * np.float32(sc2))
+            a = np.einsum("nk,nkw->nw", h16(O.softmax(w, -1)), Vw[:, idx])
+        want = h16(res + h16(a + h16(bp)))
+        scale = max(1.0, np.abs(want).max())
+        assert np.abs(got - want).max() < 4e-3 * scale, (func, t)
+        att = H.attn_decode(func, dev(q[:, 0], f16), kc, vc, 1, bc, t_dev, T)
+        five = H.gemv(att, pw, bias=dev(bp), res=dev(res, f16)).float().cpu().numpy()
+        assert np.abs(got - five).max() < 8e-3 * scale, (func, t)
+
+
 def _merge_parts(parts, ml):
     """numpy restatement of the log-sum-exp merge gemv_merge_kernel performs on jb_attn_decode_split's output."""
     N, P, S = parts.shape
