@@ -31,6 +31,18 @@ def attn_funcs(attn_order, depth):
     return [_ORDERS[attn_order](d) for d in range(depth)]
 
 
+def wide_value_weights(w_attn, w_proj, b_attn, S, dtype):
+    """c_attn of a wide-value layer: (W x (2S + W) weight, bias) producing q | k | v'.  With one head,
+    attn.c_proj(sum_k p_k v_k) = sum_k p_k (v_k·Wp) + bp (factored_attention.py:104-108,118-121 are linear in v), so the
+    cache may hold v' = v·Wp = LN(x)·(Wv·Wp) + bv·Wp and the attention output is already the projected one.  Wv and Wp are
+    first rounded to the engine dtype, as the reference uses them (`w.type_as(x)`, ops.py:99); the product is rounded once.
+    Prefill keeps its own c_attn / attention / c_proj and fills v' from the v rows it caches (jb_engine_prefill)."""
+    w16, wp16 = w_attn.to(dtype), w_proj.to(dtype)
+    vp = (w16[:, 2 * S:].double() @ wp16.double()).to(dtype)                           # (W, W)
+    b_vp = (b_attn[2 * S:].double() @ wp16.double()).float()
+    return torch.cat([w16[:, :2 * S], vp], 1).contiguous(), torch.cat([b_attn[:2 * S].float(), b_vp]).contiguous()
+
+
 class PackedPrior:
     """The weights of one ConditionalAutoregressive2D, re-laid once for the MFMA kernels (jb_pack_weight) in one engine
     dtype: per layer the four projections in fragment order, biases / LayerNorm parameters in fp32, the folded-LayerNorm
@@ -110,17 +122,9 @@ class PackedPrior:
             self.layers.append(lay)
 
     def _wide_images(self, w_attn, w_proj, b_attn, ln_g, ln_b):
-        """c_attn images of a wide-value layer.  With one head, attn.c_proj(sum_k p_k v_k) = sum_k p_k (v_k·Wp) + bp
-        (factored_attention.py:104-108,118-121 are linear in v), so the cache may hold v' = v·Wp = LN(x)·(Wv·Wp) + bv·Wp:
-        the decode image is the folded [Wq | Wk | Wv·Wp]; prefill keeps its own c_attn / attention / c_proj and fills v' from
-        the v rows with one more GEMM (jb_engine_prefill).  Wv and Wp are first rounded to the engine dtype, as the
-        reference uses them; the product is rounded once."""
-        S, dt = self.S, self.dtype
-        w16, wp16 = w_attn.to(dt), w_proj.to(dt)
-        vp = (w16[:, 2 * S:].double() @ wp16.double()).to(dt)                          # (W, W)
-        b_vp = (b_attn[2 * S:].double() @ wp16.double()).float()
-        w_dec = torch.cat([w16[:, :2 * S], vp], 1).contiguous()
-        return dict(fold=H.FoldedLN(w_dec, torch.cat([b_attn[:2 * S], b_vp]).contiguous(), ln_g, ln_b, dt))
+        """Folded decode image of a wide-value layer's c_attn (see wide_value_weights)."""
+        w_dec, b_dec = wide_value_weights(w_attn, w_proj, b_attn, self.S, self.dtype)
+        return dict(fold=H.FoldedLN(w_dec, b_dec, ln_g, ln_b, self.dtype))
 
     def weight_bytes(self):
         n = self.x_out.data.numel() * 4 if self.x_out is not None else 0

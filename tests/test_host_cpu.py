@@ -296,3 +296,61 @@ def test_save_html_matches_reference_outputs(tmp_path):
     d2 = str(tmp_path / "plain")
     save_html(d2, torch.from_numpy(g["x"]), zs, dict(info=info), None, Hyperparams(levels=3, sr=sr))
     assert not os.path.exists(f"{d2}/item_0/align.png") and "<script>" not in open(f"{d2}/item_0/index.html").read()
+
+
+@pytest.mark.parametrize("attn_order,prime_len", [(2, None), (0, None), (12, 6)])
+def test_wide_value_weights_reproduce_attention_plus_c_proj(attn_order, prime_len):
+    """The algebra behind the wide-value layers (jukebox_amd.engine.wide_value_weights, jb_attn_decode_wide): for a
+    single-head layer, caching v' = LN(x)·(Wv·Wp) + bv·Wp and returning sum_k p_k v'_k + bp equals the oracle's
+    FactoredAttention (c_attn, cached attention over the layer's pattern, c_proj) at every position of every pattern --
+    including the positions whose key set is empty (prev_block inside block 0: the output is c_proj's bias)."""
+    import math
+    from jukebox_amd.engine import wide_value_weights
+    from oracle import ops as O
+    from oracle.transformer import Transformer, decode_key_index
+    rng = np.random.default_rng(attn_order)
+    W, T, blocks, depth = 32, 24, 4, 16 if attn_order == 12 else 3
+    S = W // 4
+    sd = {}
+    for d in range(depth):
+        p = f"_attn_mods.{d}."
+        sd.update({p + "attn.c_attn.w": rng.standard_normal((W, 3 * S)) * 0.3, p + "attn.c_attn.b": rng.standard_normal(3 * S) * 0.1,
+                   p + "attn.c_proj.w": rng.standard_normal((S, W)) * 0.3, p + "attn.c_proj.b": rng.standard_normal(W) * 0.1,
+                   p + "mlp.c_fc.w": np.zeros((W, W)), p + "mlp.c_fc.b": np.zeros(W), p + "mlp.c_proj.w": np.zeros((W, W)),
+                   p + "mlp.c_proj.b": np.zeros(W)})
+        for ln in ("ln_0", "ln_1"):
+            sd.update({p + ln + ".weight": np.ones(W), p + ln + ".bias": np.zeros(W)})
+    sd = {k: np.asarray(v, np.float32) for k, v in sd.items()}
+    tr = Transformer(sd, "", W, T, 1, depth, attn_order=attn_order, blocks=blocks, prime_len=prime_len)
+    bc = T // blocks
+    N = 2
+    sc2 = (1.0 / math.sqrt(math.sqrt(S))) ** 2
+    seen = set()
+    for d in range(depth):
+        func = tr.funcs[d]
+        if func == 6 or func in seen:
+            continue
+        seen.add(func)
+        p = f"_attn_mods.{d}."
+        t = lambda name: torch.from_numpy(sd[p + name])
+        w_dec, b_dec = wide_value_weights(t("attn.c_attn.w"), t("attn.c_proj.w"), t("attn.c_attn.b"), S, torch.float32)
+        w_dec, b_dec, bp = w_dec.numpy(), b_dec.numpy(), sd[p + "attn.c_proj.b"]
+        assert w_dec.shape == (W, 2 * S + W) and b_dec.shape == (2 * S + W,)
+        cap = tr.prime_len_r if func == 7 else T
+        K, Vw = np.zeros((N, cap, S), np.float32), np.zeros((N, cap, W), np.float32)
+        empty_seen = False
+        for pos in range(T):
+            h = rng.standard_normal((N, 1, W)).astype(np.float32)
+            want = tr._attention(d, h, pos, False, None)[:, 0]
+            x = h[:, 0] @ w_dec + b_dec
+            if pos < cap:
+                K[:, pos], Vw[:, pos] = x[:, S:2 * S], x[:, 2 * S:]
+            idx = decode_key_index(func, pos, bc, tr.prime_len_r)
+            if idx is None:
+                got, empty_seen = np.broadcast_to(bp, (N, W)), True
+            else:
+                pr = O.softmax(np.einsum("nd,nkd->nk", x[:, :S], K[:, idx]) * np.float32(sc2), -1)
+                got = np.einsum("nk,nkw->nw", pr, Vw[:, idx]) + bp
+            assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max()), (func, pos)
+        assert empty_seen == (func == 3)
+    assert seen >= ({1, 2, 3} if attn_order == 2 else {0} if attn_order == 0 else {1, 2, 3, 7})
