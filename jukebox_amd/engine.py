@@ -159,6 +159,12 @@ class PriorEngine:
         N, T, S, W, M = self.N, self.T, self.S, self.W, self.M
         self.layers_c = (L.Layer * self.depth)()
         self.kcaches, self.vcaches, self.vcaches_w = [], [], []
+        # key-split decode attention (fp16 engines whose head size the split kernel takes) for layers with long key sets
+        split_off = os.environ.get("JB_ATTN_SPLIT_OFF", "0") == "1"
+        bc = max(self.block_ctx, 1)
+        max_keys = lambda lay: {0: T, 1: bc, 2: (T + bc - 1) // bc, 3: bc}.get(lay["func"], lay["cap"])
+        splits = lambda lay: (not self.only_encode and not split_off and N <= 32 and
+                              L.lib().jb_attn_decode_split_parts(self.code, S // self.H, max_keys(lay)) > 0)
         for d, lay in enumerate(pk.layers):
             kc = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
             vc = torch.zeros((N, lay["cap"], S), dtype=dt, device=dev)
@@ -181,7 +187,7 @@ class PriorEngine:
             if lay["func"] == 6:
                 lc.w_enc_k, lc.w_enc_v, lc.b_enc_kv = lay["enc"][0].ptr, lay["enc"][1].ptr, lay["b_enc"].data_ptr()
             wd = lay["wide"]
-            if wd is not None and lc.w_attn_f and H.ln_fold_supported(dt, W, 2 * S + W, N):
+            if wd is not None and lc.w_attn_f and H.ln_fold_supported(dt, W, 2 * S + W, N) and not splits(lay):
                 vw = torch.zeros((N, lay["cap"], W), dtype=dt, device=dev)
                 self.vcaches_w.append(vw)
                 lc.w_attn_fw, lc.b_attn_fw, lc.c1_attn_w = wd["fold"].pw.ptr, wd["fold"].bias.data_ptr(), wd["fold"].c1.data_ptr()
@@ -195,13 +201,9 @@ class PriorEngine:
                         xf=e(N, W, dtype=torch.float32), logits=e(N, max(self.bins, 1), dtype=torch.float32),
                         c_xa=e(N * Cc, W), c_xb=e(N * Cc, W), c_h=e(N * Cc, W), c_q=e(N * Cc, S), c_att=e(N * Cc, S),
                         c_mlp=e(N * Cc, M))
-        # key-split decode attention (fp16 engines whose head size the split kernel takes): partial softmax states
+        # partial softmax states of the key-split layers
         self.att_parts = self.att_ml = None
-        split_off = os.environ.get("JB_ATTN_SPLIT_OFF", "0") == "1"
-        bc = max(self.block_ctx, 1)
-        max_keys = lambda lay: {0: T, 1: bc, 2: (T + bc - 1) // bc, 3: bc}.get(lay["func"], lay["cap"])
-        if not self.only_encode and not split_off and N <= 32 and \
-                any(L.lib().jb_attn_decode_split_parts(self.code, S // self.H, max_keys(lay)) > 0 for lay in pk.layers):
+        if any(splits(lay) for lay in pk.layers):
             self.att_parts = e(N, 4, S)
             self.att_ml = e(N, self.H, 4, 2, dtype=torch.float32)
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)

@@ -1,7 +1,7 @@
 """Per-slot kernel durations of the decode step from a rocprofv3 kernel trace.
-Usage: python tools/slot_stats.py <dir with *_kernel_trace.csv> [n_layers]
+Usage: python tools/slot_stats.py <dir with *_kernel_trace.csv> [n_layers] [launches_per_layer]
 A step is n_layers x (c_attn, attention, c_proj, c_fc, c_proj2), logits, sample -- 5 L + 2 dispatches ending with
-sample_kernel; durations and the gap to the previous kernel's end are averaged per slot over the complete steps of the
+sample_kernel (launches_per_layer = 4 for wide-value engines: c_attn, attention, c_fc, c_proj2); durations and the gap to the previous kernel's end are averaged per slot over the complete steps of the
 trace (second half only: graph replay in tools/bench_engine.py)."""
 import csv
 import glob
@@ -10,7 +10,8 @@ from collections import defaultdict
 
 d = sys.argv[1]
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 72
-per_step = 5 * L + 2
+PL = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+per_step = PL * L + 2
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = []
 with open(f) as fh:
@@ -25,7 +26,7 @@ dur, gap, name = defaultdict(list), defaultdict(list), {}
 for s in steps:
     for k in range(per_step):
         st, en, nm = rows[s + k]
-        slot = ("layer", k % 5) if k < 5 * L else ("tail", k - 5 * L)
+        slot = ("layer", k % PL) if k < PL * L else ("tail", k - PL * L)
         dur[slot].append(en - st)
         gap[slot].append(st - rows[s + k - 1][1])
         name[slot] = nm[:80]
@@ -37,7 +38,7 @@ for slot in sorted(dur):
     print(f"{slot}: x{n:.0f}/step dur {a / 1e3:.2f} us  gap-before {g / 1e3:.2f} us  min {min(dur[slot]) / 1e3:.2f}  {name[slot]}")
 print(f"sum over a step: {tot / 1e6:.3f} ms")
 # per pattern (attn_order 2: layer l uses block / transpose / prev for l % 3 = 0 / 1 / 2) for the attention and c_proj slots
-for which in (1, 2):
+for which in ((1, 2) if PL == 5 else (1,)):
     for pat in range(3):
-        v = [rows[s + 5 * l + which][1] - rows[s + 5 * l + which][0] for s in steps for l in range(pat, L, 3)]
+        v = [rows[s + PL * l + which][1] - rows[s + PL * l + which][0] for s in steps for l in range(pat, L, 3)]
         print(f"slot {which} layers l%3=={pat}: {sum(v) / len(v) / 1e3:.2f} us")
