@@ -178,3 +178,26 @@ def test_sampling_is_reproducible_and_seeded(PE):
         outs.append(eng.tokens.cpu().numpy().copy())
     assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
     assert outs[0].min() >= 0 and outs[0].max() < 128
+
+
+def test_wide_value_engine_refuses_prefill_behind_decoded_positions(PE):
+    """Wide-value layers append k and v' (not v) in the decode step, so a prefill that would attend to decoded positions
+    (t0 > 0 after decode steps) is refused loudly; a new window (prefill from position 0) is fine again."""
+    from jukebox_amd._lib import JukeboxHipError
+    rng = np.random.default_rng(7)
+    width, depth, bins, seq, blocks, N = 1920, 3, 256, 512, 8, 4
+    eng = PE(to_dev(_random_sd(rng, width, depth, bins, seq, 2, scale=0.02)), "", n_batch=N, seq_len=seq, bins=bins,
+             width=width, depth=depth, heads=1, attn_order=2, blocks=blocks, y_cond=False, fp16=True, chunk_cap=64)
+    eng.set_cond(None, None)
+    assert eng.launches_per_step == 4 * depth + 2
+    eng.set_sampling(temp=1.0, top_k=1)
+    eng.tokens[:, :16] = torch.from_numpy(rng.integers(0, bins, (N, 16))).cuda()
+    eng.prefill(0, 8)
+    eng.prefill(8, 8)                      # chunked prefill of one window: allowed
+    eng.decode(16, 4)
+    with pytest.raises(JukeboxHipError):
+        eng.prefill(20, 4)
+    eng.prefill(0, 8)                      # next window
+    eng.decode(8, 2)
+    torch.cuda.synchronize()
+    assert int(eng.t_dev.item()) == 10
