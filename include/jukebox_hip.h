@@ -311,7 +311,8 @@ int jb_engine_set_encoder_kv(void* handle, void* stream);
 /* Prefill positions t0..t0+n_t-1 (tokens already in cfg.tokens): fills the k/v caches, leaves *t_dev = t0+n_t. */
 int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
 /* Run n_steps decode steps starting at position t0 (sets *t_dev = t0 and embeds position t0 first).  One step =
- * L x [c_attn | attention | attn.c_proj | mlp.c_fc | mlp.c_proj] | logits | sample + embed(t+1) + counter: 5 L + 2 launches.
+ * L x [c_attn | attention | attn.c_proj | mlp.c_fc | mlp.c_proj] | logits | sample + embed(t+1) + counter: 5 L + 2 launches
+ * (wide-value layers have no attn.c_proj launch: 4 per layer; jb_engine_launches_per_step reports the count).
  * use_graph != 0 captures one step into a hipGraph on first use and replays it. */
 int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
 /* Measurement aid: n_steps passes over all layers launching only the LayerNorm-fused projections (attn.c_attn and
