@@ -1,10 +1,12 @@
 """Summarise the two rocprofv3 --pmc passes over tools/pmc_target.py (FETCH_SIZE, WRITE_SIZE; one counter per pass) into
-profiles/r01_pmc_dominant_kernel.json.  Usage: python tools/pmc_summary.py <fetch_csv> <write_csv> <kernel substring> <out json>"""
+a json under profiles/.  Usage: python tools/pmc_summary.py <fetch_csv> <write_csv> <kernel substring> <out json> [--wide]
+(--wide: the target ran with --wide; the c_attn launch streams W x (2S + W) weights and is credited with W x 4S)."""
 import csv
 import json
 import sys
 
 fetch_csv, write_csv, key, out = sys.argv[1:5]
+wide = "--wide" in sys.argv
 
 
 def mean_kb(path, counter):
@@ -19,11 +21,12 @@ def mean_kb(path, counter):
 f_kb, n = mean_kb(fetch_csv, "FETCH_SIZE")
 w_kb, _ = mean_kb(write_csv, "WRITE_SIZE")
 N, W, S = 16, 1920, 480
-alg = int(0.5 * ((W * W + W * 3 * S) * 2 + 2 * N * W * 2 + N * (W + 3 * S) * 2))
+JC = 4 * S if wide else 3 * S
+alg = int(0.5 * ((W * W + W * JC) * 2 + 2 * N * W * 2 + N * (W + JC) * 2))
 traffic = int(round((2 * f_kb + w_kb) * 1024))
 json.dump({
-    "kernel": f"{key} (LayerNorm-folded projection), shapes K=1920 J=1440 / J=1920 alternating, 16 rows, cold weights",
-    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python tools/pmc_target.py (one pass per counter)",
+    "kernel": f"{key} (LayerNorm-folded projection), shapes K=1920 J={2 * S + W if wide else 3 * S} / J=1920 alternating, 16 rows, cold weights",
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python tools/pmc_target.py" + (" --wide" if wide else "") + " (one pass per counter)",
     "launches_per_counter": n,
     "FETCH_SIZE_KB_mean": f_kb,
     "WRITE_SIZE_KB_mean": w_kb,
