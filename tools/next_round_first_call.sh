@@ -4,6 +4,8 @@
 #      one run: profiles/README.md, r02_wide_* rows);
 #   2. the PMC passes on the dominant kernel in its wide-value shapes (roofline.traffic is null until this exists);
 #   3. the driver's bench command against a short wall budget (first full-length measurement of the wide-value tree).
+# Then (separate, ~1 minute): `git checkout wip/pipelined-launch -- tools/pipelined_launch_probe.hip`, build it with hipcc and run
+# it -- DESIGN.md section 8 item 1 says what its numbers decide.
 # Outputs land in gpurun_out/; copy what is to be judged into profiles/ (r03_*).
 export PYTHONPATH=$PWD TMPDIR=/tmp
 mkdir -p gpurun_out
