@@ -354,3 +354,55 @@ def test_wide_value_weights_reproduce_attention_plus_c_proj(attn_order, prime_le
             assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max()), (func, pos)
         assert empty_seen == (func == 3)
     assert seen >= ({1, 2, 3} if attn_order == 2 else {0} if attn_order == 0 else {1, 2, 3, 7})
+
+
+def test_engine_layer_policy_without_a_gpu(monkeypatch):
+    """Host logic of PriorEngine / jb_engine_create (no kernel runs: weight packing is stubbed, the native handle is built
+    from host descriptors): single-head fp16 engines with short key sets get wide-value layers (4 launches per layer);
+    layers whose key sets are long enough for the key split keep the five-launch form and get no v' cache; multi-head and
+    fp32 engines are untouched."""
+    from jukebox_amd import _lib as L
+    from jukebox_amd import engine as E
+    from jukebox_amd import hip_ops as H
+
+    def fake_pack(w, K, J, sk, sj, dtype, out=None, offset_elems=0):
+        code = L.dtype_code(dtype)
+        n = L.lib().jb_packed_weight_bytes(K, J, code) // (2 if code == L.F16 else 4)
+        return out if out is not None else torch.zeros(n, dtype=dtype)
+
+    monkeypatch.setattr(H, "pack_weight", fake_pack)
+    monkeypatch.setattr(H, "make_sample_params", lambda *a, device="cpu", **k: torch.zeros(8, dtype=torch.int64))
+    monkeypatch.delenv("JB_WIDE_V", raising=False)
+    monkeypatch.delenv("JB_FOLD_LN", raising=False)
+    monkeypatch.delenv("JB_ATTN_SPLIT_OFF", raising=False)
+
+    def state(W, depth, bins, T):
+        S = W // 4
+        sd = {"x_emb.weight": torch.randn(bins, W), "pos_emb.pos_emb": torch.randn(T, W), "start_token": torch.randn(1, W)}
+        sd["x_out.weight"] = sd["x_emb.weight"]
+        for d in range(depth):
+            p = f"transformer._attn_mods.{d}."
+            for nm, shape in (("attn.c_attn", (W, 3 * S)), ("attn.c_proj", (S, W)), ("mlp.c_fc", (W, W)), ("mlp.c_proj", (W, W))):
+                sd[p + nm + ".w"], sd[p + nm + ".b"] = torch.randn(*shape) * 0.02, torch.zeros(shape[1])
+            for ln in ("ln_0", "ln_1"):
+                sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(W), torch.zeros(W)
+        return sd
+
+    depth = 3
+    cases = [  # width, heads, attn_order, T, blocks, fp16, wide_v -> wide layers?, key-split buffers?
+        (1920, 1, 2, 512, 8, True, None, True, False),       # the upsampler geometry: key sets <= 64 keys
+        (1920, 1, 2, 512, 8, True, False, False, False),     # switched off by the caller
+        (1920, 1, 0, 512, None, True, None, False, True),    # dense single-head layers, 512 keys: key split, no v' cache
+        (256, 2, 2, 64, 8, True, None, False, False),        # two heads
+        (1920, 1, 2, 512, 8, False, None, False, False),     # fp32 parity engine
+    ]
+    for W, heads, order, T, blocks, fp16, wide_v, want_wide, want_split in cases:
+        eng = E.PriorEngine(state(W, depth, 64, T), "", n_batch=4, seq_len=T, bins=64, width=W, depth=depth, heads=heads,
+                            attn_order=order, blocks=blocks, y_cond=False, fp16=fp16, wide_v=wide_v, device="cpu")
+        assert [v is not None for v in eng.vcaches_w] == [want_wide] * depth
+        assert (eng.att_parts is not None) == want_split
+        eng.set_cond(None, None)
+        assert eng.launches_per_step == (4 if want_wide else 5) * depth + 2
+        if want_wide:
+            assert eng.cache_bytes() == depth * 4 * T * (2 * (W // 4) + W) * 2
+        eng.close()
