@@ -405,4 +405,11 @@ def test_engine_layer_policy_without_a_gpu(monkeypatch):
         assert eng.launches_per_step == (4 if want_wide else 5) * depth + 2
         if want_wide:
             assert eng.cache_bytes() == depth * 4 * T * (2 * (W // 4) + W) * 2
+            # an incomplete wide-value descriptor is refused by jb_engine_create, not silently ignored
+            keep = eng.layers_c[1].vcache_w
+            eng.layers_c[1].vcache_w = None
+            with pytest.raises(L.JukeboxHipError, match="wide-value layer"):
+                eng._create()
+            eng.layers_c[1].vcache_w = keep
+            eng._create()
         eng.close()
