@@ -41,6 +41,24 @@ def test_binding_loads_and_validates_arguments(built):
     assert lib.jb_gemv_ln_fold_supported(L.F16, 100, 64, 16) == 0 and lib.jb_gemv_ln_fold_supported(L.F32, 256, 64, 33) == 0
     a = L.GemvArgs()
     assert lib.jb_gemv(C.byref(a), None) == -1
+    # wide-value layers: host-side shape queries and the argument checks of the v' column group (no launch)
+    assert lib.jb_gemv_ln_fold_supported(L.F16, 1920, 2 * 480 + 1920, 16) == 1
+    assert lib.jb_attn_decode_wide_supported(1, 480, 1920, 64, 8192) == 1 and lib.jb_attn_decode_wide_supported(2, 256, 1024, 128, 8192) == 1
+    assert lib.jb_attn_decode_wide_supported(6, 480, 1920, 64, 8192) == 0        # cross-attention
+    assert lib.jb_attn_decode_wide_supported(1, 150, 4800, 64, 8192) == 0        # head size the MFMA kernel does not take
+    assert lib.jb_attn_decode_wide_supported(1, 480, 2000, 64, 8192) == 0        # width not a multiple of the head size
+    assert lib.jb_attn_decode_wide_supported(1, 480, 1920, 0, 8192) == 0         # block pattern without block_ctx
+    dummy = C.create_string_buffer(64)
+    ptr = C.addressof(dummy)
+    a = L.GemvArgs()
+    a.dtype, a.x, a.ldx, a.n_rows, a.W, a.K, a.out, a.ldo = L.F16, ptr, 1920, 16, ptr, 1920, ptr, 480
+    a.qkv_split, a.S, a.kcache, a.cache_cap, a.t_dev = 1, 480, ptr, 8, ptr
+    a.J, a.wide = 2 * 480 + 1920, 1920                                           # v' columns announced, no cache for them
+    assert lib.jb_gemv(C.byref(a), None) == -1 and b"vcache_wide" in lib.jb_last_error()
+    a.vcache_wide, a.J = ptr, 3 * 480 + 1920                                     # v columns counted, no v cache given
+    assert lib.jb_gemv(C.byref(a), None) == -1 and b"qkv split" in lib.jb_last_error()
+    assert lib.jb_attn_decode_wide(1, ptr, 480, ptr, ptr, 8, ptr, 1920, ptr, ptr, 1920, 16, 150, 4800, 64, ptr, 8192, None) == -1
+    assert b"wide-value attention" in lib.jb_last_error()
     with pytest.raises(L.JukeboxHipError):
         L.check(lib.jb_engine_decode(None, 0, 1, 0, None))
 
