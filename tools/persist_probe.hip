@@ -1,0 +1,530 @@
+// Micro-benchmark for a PERSISTENT decode step: the 4 x 72 dependent phases of one token step of the
+// level-0 upsampler (1920 wide, 72 wide-value layers, 16 rows) run inside ONE launch, every workgroup owning the same
+// output tile of the same projection in every layer, so that
+//   * the weight stream (or the old K / v' rows) of a workgroup's NEXT task is requested before the dependency edge resolves
+//     (those addresses never depend on this step's activations): the cold HBM round trip and the wave start leave the
+//     critical path;
+//   * an edge is: producer's write-through (sc1) stores drained -> one 4-byte sc1 flag per producer -> wave 0 of the consumer
+//     polls the flag row of the previous phase with ONE 16-byte sc1 load per lane (no atomics, no fan-in counter) ->
+//     s_barrier -> the waves read the activation block with sc1 loads (L1 bypass; no buffer_inv, no buffer_wbl2).
+// Phases per layer (tasks = workgroups that work in it; the others run ahead to their next task):
+//   A  ln_0 + c_attn -> q | k | v'   180 tiles of 16 columns, K = 1920 (11.06 MB of weights), input: D of the layer before
+//   B  wide attention                128 tasks (sample, 240-channel slice) on workgroups 0..127: old K / v' rows run ahead
+//   C  ln_1 + c_fc + gelu            120 tiles (7.37 MB) on workgroups 0..119, input: B
+//   D  mlp.c_proj + residual         120 tiles (7.37 MB) on workgroups 0..119, input: C
+// 180 workgroups x 512 threads, <= 128 VGPRs: two such launches (two levels of the sampler) can be co-resident.
+// Wave 0 is the sync wave of its workgroup (polls, reduces the partial tiles, stores, publishes; vector loads return in
+// order, so a wave with weight fragments in flight would see its poll result late); waves 1..7 share the 60 k-tiles.  In the
+// attention tasks all 8 waves take a 16-key tile.
+// The arithmetic is a stand-in (MFMAs on the real fragment layout, results discarded); the DATA FLOW is checked: every
+// consumer checksums what it read against the value pattern of (phase, step), so a stale or early read is counted.
+// Modes:  persist SV=0 (sc1 + flags), SV=1 (plain stores + agent release fence / acquire fence + plain loads),
+//         PF=1 / 0 (run-ahead requests on / off);  chain = the same bodies as one kernel per phase in a hipGraph.
+// Every poll is bounded (2 s on the constant 100 MHz clock): a timeout raises `abort`, everybody leaves, the run is
+// reported as aborted -- no hung GPU.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/persist_probe tools/persist_probe.hip      Run: tools/persist_probe [steps]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
+constexpr int NROW = 16, WID = 1920, SST = 480, JA = 2 * SST + WID;      // 2880 columns of the wide c_attn
+constexpr int NKT = WID / 32;                                             // 60 k-tiles
+constexpr int NW = 8, THREADS = NW * 64;
+constexpr int NL = 72, PH = 4 * NL, FROW = 256;
+constexpr int SLW = 240, NSL = WID / SLW;                                 // attention: 8 slices of 240 channels
+constexpr int TA = JA / 16, TB = NROW * NSL, TC = WID / 16, TD = WID / 16;   // 180 / 128 / 120 / 120 tasks
+constexpr int G = TA;                                                     // 180 workgroups
+constexpr size_t WA_EL = (size_t)TA * NKT * 512, WC_EL = (size_t)TC * NKT * 512;   // f16 elements per layer
+constexpr int KEYS = 64;                                                  // keys the model attention reads (4 tiles)
+constexpr size_t KC_EL = (size_t)KEYS * SST, VC_EL = (size_t)KEYS * WID;  // per (layer, sample): K rows, v' rows
+
+struct Args {
+    const f16* wA; const f16* wC; const f16* wD; const f16* kc; const f16* vc;
+    f16* X0; f16* Q; f16* X1; f16* H;
+    unsigned* flags; unsigned* epoch_dev; unsigned* err; unsigned* abort_flag; float* sink; long long* stamps;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void issue_fence() { asm volatile("" ::: "memory"); }
+
+__device__ __forceinline__ int tagv(int p, unsigned step) { return (int)((p + 5u * step + 11u) % 11u); }
+__device__ __forceinline__ float val_at(int i, int p, unsigned step) { return (float)(((i + p) & 7) + tagv(p, step)); }
+
+// Every bulk load is a buffer load: descriptor and the task / tile / k-tile part of the address in SGPRs (soff, in elements),
+// ONE lane-dependent VGPR offset (el) per access pattern.  With flat pointers the compiler hoists one 64-bit address per
+// unrolled load out of the layer loop (31 for an attention tile) and spills them.
+template <int SV> __device__ __forceinline__ f16x8 ld_act(const f16* base, int el, int soff = 0) {       // 8 halves of an activation row
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc(base), el * 2, soff * 2, SV == 0 ? 16 : 0));
+}
+template <int SV> __device__ __forceinline__ f16x4 ld_act4(const f16* base, int el, int soff = 0) {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rsrc(base), el * 2, soff * 2, SV == 0 ? 16 : 0));
+}
+
+// ---- wave 0: wait until the n_dep producers of `row` have published `epoch` ----
+template <int SV> __device__ __forceinline__ bool wait_flags(const Args& a, const unsigned* row, int n_dep, unsigned epoch, int lane) {
+    if (n_dep <= 0) return true;
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 0;; ++spins) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc(row), lane * 16, 0, 16);
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ok = ok && (lane * 4 + r >= n_dep || v[r] == epoch);
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 63) == 63 && (wall_clock64() - t0 > 200000000ll || ld_u32(a.abort_flag))) {
+            if (lane == 0) st_u32(a.abort_flag, 1u);
+            return false;
+        }
+    }
+    if constexpr (SV == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+template <int SV> __device__ __forceinline__ void publish(unsigned* flag, unsigned epoch, int lane) {   // the storing wave only
+    if constexpr (SV == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (SV != 2) { if (lane == 0) st_u32(flag, epoch); }
+}
+
+struct Task { const f16* w; const f16* x; int ldx; f16* out; int ldo; int jt; int p; int n_dep; float expect; int nmf; };
+
+__device__ __forceinline__ Task gemv_task(const Args& a, int kind, int l, int jt, unsigned step) {
+    Task t;
+    t.jt = jt; t.p = 4 * l + kind;
+    const float blk = 107520.0f;       // sum of ((i + p) & 7) over 16 x 1920 consecutive indices
+    if (kind == 0) {
+        t.w = a.wA + (size_t)l * WA_EL; t.x = a.X0; t.ldx = WID; t.out = a.Q; t.ldo = JA; t.n_dep = l == 0 ? 0 : TD; t.nmf = 3;
+        const int pp = l == 0 ? PH - 1 : t.p - 1;                      // layer 0 reads what the previous step's last D left
+        t.expect = blk + 30720.0f * (float)tagv(pp, l == 0 ? step - 1 : step);
+    } else if (kind == 2) {
+        t.w = a.wC + (size_t)l * WC_EL; t.x = a.X1; t.ldx = WID; t.out = a.H; t.ldo = WID; t.n_dep = TB; t.nmf = 3;
+        t.expect = blk + 30720.0f * (float)tagv(t.p - 1, step);
+    } else {
+        t.w = a.wD + (size_t)l * WC_EL; t.x = a.H; t.ldx = WID; t.out = a.X0; t.ldo = WID; t.n_dep = TC; t.nmf = 2;
+        t.expect = blk + 30720.0f * (float)tagv(t.p - 1, step);
+    }
+    t.w += (size_t)jt * NKT * 512;
+    return t;
+}
+
+// k-tiles of a wave: wave 0 (the sync wave) none, waves 1..7 share the 60 k-tiles (8 or 9 each; NF = 9 fragments, clamped)
+constexpr int NF = 9;
+__device__ __forceinline__ int kt_first(int wave) { return ((wave - 1) * NKT) / (NW - 1); }
+
+__device__ __forceinline__ void load_w_wave(f16x8 (&wf)[NF], const f16* w, int wave, int lane) {
+    const int kt0 = kt_first(wave);
+    const __amdgpu_buffer_rsrc_t rs = rsrc(w);
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+        wf[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, min(kt0 + i, NKT - 1) * 1024, 2));   // nt
+}
+
+struct AttnRegs { f16x8 kf[15]; f16x4 vv[16]; };
+// old K rows (all 480 channels, MFMA A-operand layout) and the slice of the old v' rows of this wave's 16-key tile
+__device__ __forceinline__ void load_kv(AttnRegs& r, const Args& a, int l, int task, int wave, int lane) {
+    const int n = task / NSL, sl = task % NSL, g = lane >> 4, c = lane & 15;
+    const f16* kb = a.kc + ((size_t)l * NROW + n) * KC_EL;
+    const f16* vb = a.vc + ((size_t)l * NROW + n) * VC_EL + sl * SLW;
+    const int tile = wave < KEYS / 16 ? wave : KEYS / 16 - 1;
+    const __amdgpu_buffer_rsrc_t rk = rsrc(kb), rv = rsrc(vb);
+    const int kvo = (c * SST + g * 8) * 2, vvo = min(lane * 4, SLW - 4) * 2;
+#pragma unroll
+    for (int dt = 0; dt < 15; ++dt)
+        r.kf[dt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, kvo, (tile * 16 * SST + dt * 32) * 2, 0));
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        r.vv[k] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rv, vvo, (tile * 16 + k) * WID * 2, 0));
+}
+
+struct Lds {
+    f32x4 acc[NW][64]; float sum[NW][16];
+    f16 q[SST + 8]; f16 fk[SST + 8]; f16 fv[SLW + 8];
+    float o[NW][SLW]; float ml[NW][2]; float chk; int stop;
+};
+
+// ---- one projection task; on entry wf holds this wave's weight fragments when RUNAHEAD ----
+template <int SV, bool RUNAHEAD>
+__device__ __forceinline__ void gemv_compute(Lds& s, const Task& t, f16x8 (&wf)[NF], int wave, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const int kt0 = kt_first(wave), kt1 = kt_first(wave + 1);
+    if (!RUNAHEAD) load_w_wave(wf, t.w, wave, lane);
+    f16x8 xf[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        xf[i] = ld_act<SV>(t.x, c * t.ldx + g * 8, min(kt0 + i, NKT - 1) * 32);
+    }
+    issue_fence();
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        if (kt0 + i >= kt1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[i][e] = (f16)0;
+        }
+    }
+    f16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (f16)1.0f;
+    f32x4 acc = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[i], acc, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, xf[i], a1, 0, 0, 0);
+        if (t.nmf == 3) a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[i], xf[i], a2, 0, 0, 0);
+    }
+    s.acc[wave][lane] = acc + a2 * 1e-30f;
+    if (g == 0) s.sum[wave][c] = a1[0];
+}
+
+// wave 0 after the partial tiles are in LDS: reduce, check what was read, store the tile, publish
+template <int SV> __device__ __forceinline__ void gemv_epilogue(const Args& a, Lds& s, const Task& t, unsigned epoch, int lane) {
+    f32x4 v = {0, 0, 0, 0};
+    float rs = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { v += s.acc[w][lane]; rs += s.sum[w][lane & 15]; }
+    float tot = lane < 16 ? rs : 0.f;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0 && tot != t.expect) atomicAdd(a.err, 1u);
+    const int row = lane & 15, col = t.jt * 16 + (lane >> 4) * 4, i0 = row * t.ldo + col;
+    const float bump = (v[0] + v[1] + v[2] + v[3] == 123.456f) ? 1.f : 0.f;
+    f16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (f16)(val_at(i0 + r, t.p, epoch - 1) + bump);
+    if constexpr (SV == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrc(t.out), i0 * 2, 0, 16);
+    else *reinterpret_cast<f16x4*>(t.out + i0) = o;
+    publish<SV>(a.flags + (size_t)t.p * FROW + t.jt, epoch, lane);
+}
+
+// ---- wide attention task (sample n, slice sl): wave 0 stages q and the fresh k / v' row in LDS, every wave one key tile ----
+template <int SV> __device__ __forceinline__ void attn_stage_inputs(const Args& a, Lds& s, int task, int lane) {
+    const int n = task / NSL, sl = task % NSL;
+    const f16* qrow = a.Q + (size_t)n * JA;
+    if (lane < 60) {
+        const f16x8 q8 = ld_act<SV>(qrow, lane * 8), k8 = ld_act<SV>(qrow, SST + lane * 8);
+        const f16x4 v4 = ld_act4<SV>(qrow, 2 * SST + sl * SLW + lane * 4);
+        *reinterpret_cast<f16x8*>(s.q + lane * 8) = q8;
+        *reinterpret_cast<f16x8*>(s.fk + lane * 8) = k8;
+        *reinterpret_cast<f16x4*>(s.fv + lane * 4) = v4;
+    }
+}
+__device__ __forceinline__ void attn_compute(Lds& s, AttnRegs& r, int wave, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const bool busy = wave < KEYS / 16;
+    float of[4] = {0.f, 0.f, 0.f, 0.f};
+    if (busy) {
+        // the fresh key is the last key of the last tile: its K fragments and v' row come from LDS
+        const bool last = wave == KEYS / 16 - 1;
+        f32x4 sc = {0, 0, 0, 0};
+        if (last) {          // wave-uniform: only this wave reads the fresh K fragments
+#pragma unroll
+            for (int dt = 0; dt < 15; ++dt) {
+                if (dt % 5 == 0) issue_fence();          // LDS reads in batches of 5: they are hoisted as far as this only
+                const f16x8 qf = *reinterpret_cast<const f16x8*>(s.q + dt * 32 + g * 8);
+                const f16x8 fk = *reinterpret_cast<const f16x8*>(s.fk + dt * 32 + g * 8);
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c == 15 ? fk : r.kf[dt], qf, sc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < 15; ++dt) {
+                if (dt % 5 == 0) issue_fence();
+                const f16x8 qf = *reinterpret_cast<const f16x8*>(s.q + dt * 32 + g * 8);
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.kf[dt], qf, sc, 0, 0, 0);
+            }
+        }
+        const f16x4 fv = *reinterpret_cast<const f16x4*>(s.fv + min(lane * 4, SLW - 4));
+        if (last) r.vv[15] = fv;
+        float pv[4], mx = -1e30f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pv[q] = sc[q] * 0.045f; mx = fmaxf(mx, pv[q]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float ps = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pv[q] = __expf(pv[q] - mx); ps += pv[q]; }
+        ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float pr = __shfl(pv[k & 3], (k >> 2) * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) of[e] += pr * (float)r.vv[k][e];
+        }
+        if (lane == 0) { s.ml[wave][0] = mx; s.ml[wave][1] = ps; }
+    } else if (lane == 0) { s.ml[wave][0] = -1e30f; s.ml[wave][1] = 0.f; }
+    if (lane < 60) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s.o[wave][lane * 4 + e] = of[e];
+    }
+    if (wave == 1) {          // what wave 0 staged, checksummed by another wave (q | fresh k | fresh v' slice)
+        float chk = 0.f;
+        if (lane < 60) {
+            const f16x8 q8 = *reinterpret_cast<const f16x8*>(s.q + lane * 8), k8 = *reinterpret_cast<const f16x8*>(s.fk + lane * 8);
+            const f16x4 v4 = *reinterpret_cast<const f16x4*>(s.fv + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) chk += (float)q8[e] + (float)k8[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) chk += (float)v4[e];
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) chk += __shfl_xor(chk, o);
+        if (lane == 0) s.chk = chk;
+    }
+}
+template <int SV> __device__ __forceinline__ void attn_epilogue(const Args& a, Lds& s, int l, int task, unsigned epoch, int lane) {
+    const int p = 4 * l + 1, n = task / NSL, sl = task % NSL;
+    // q row + fresh k row: 2 x 480 consecutive indices, fresh v' slice: 240 -> sums of ((i + p) & 7) are 1680, 1680, 840
+    const float expect = 4200.f + 1200.f * (float)tagv(p - 1, epoch - 1);
+    if (lane == 0 && s.chk != expect) atomicAdd(a.err, 1u);
+    if (lane < 60) {
+        float m = -1e30f, den = 0.f, acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NW; ++w) m = fmaxf(m, s.ml[w][0]);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float f = __expf(s.ml[w][0] - m);
+            den += s.ml[w][1] * f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc4[e] += s.o[w][lane * 4 + e] * f;
+        }
+        const int i0 = n * WID + sl * SLW + lane * 4;
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)(val_at(i0 + e, p, epoch - 1) + (acc4[e] / den == 123.456f ? 1.f : 0.f));
+        if constexpr (SV == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrc(a.X1), i0 * 2, 0, 16);
+        else *reinterpret_cast<f16x4*>(a.X1 + i0) = o;
+    }
+    publish<SV>(a.flags + (size_t)p * FROW + task, epoch, lane);
+}
+
+// The two wave programs of a workgroup execute the same sequence of barriers (two per task: "inputs visible" and "partial
+// results in LDS"), written as two straight-line loops so that the register allocator sees each wave role's live ranges
+// exactly (one loop with `if (wave == 0)` islands keeps the run-ahead registers of BOTH roles alive around the whole loop).
+// has_b: workgroups 0..127 (attention tasks)   has_cd: workgroups 0..119 (c_fc / mlp.c_proj tiles)
+
+// wave 0: poll, publish the verdict, barrier; false = abort
+template <int SV> __device__ __forceinline__ bool sync_edge(const Args& a, Lds& s, int p, int n_dep, unsigned epoch, int lane) {
+    const bool ok = wait_flags<SV>(a, a.flags + (size_t)(p - 1) * FROW, n_dep, epoch, lane);
+    if (lane == 0) s.stop = ok ? 0 : 1;
+    if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[p] = wall_clock64();
+    __syncthreads();
+    return ok;
+}
+
+template <int SV, int PF, bool has_b, bool has_cd>
+__device__ __forceinline__ void sync_wave_loop(const Args& a, Lds& s, unsigned epoch, int lane) {
+    constexpr bool RA = PF != 0;
+    const int wg = blockIdx.x;
+    const unsigned step = epoch - 1;
+    AttnRegs ar;
+    for (int l = 0; l < NL; ++l) {
+        const Task tA = gemv_task(a, 0, l, wg, step);
+        if (!sync_edge<SV>(a, s, tA.p, tA.n_dep, epoch, lane)) return;
+        __syncthreads();
+        gemv_epilogue<SV>(a, s, tA, epoch, lane);
+        if (has_b) {
+            if (RA) load_kv(ar, a, l, wg, 0, lane);
+            issue_fence();
+            const bool ok = wait_flags<SV>(a, a.flags + (size_t)(4 * l) * FROW, TA, epoch, lane);
+            if (ok) attn_stage_inputs<SV>(a, s, wg, lane);
+            if (lane == 0) s.stop = ok ? 0 : 1;
+            if (a.stamps && wg == 0 && lane == 0) a.stamps[4 * l + 1] = wall_clock64();
+            __syncthreads();
+            if (!ok) return;
+            if (!RA) load_kv(ar, a, l, wg, 0, lane);
+            attn_compute(s, ar, 0, lane);
+            __syncthreads();
+            attn_epilogue<SV>(a, s, l, wg, epoch, lane);
+        }
+        if (has_cd) {
+            const Task tC = gemv_task(a, 2, l, wg, step);
+            if (!sync_edge<SV>(a, s, tC.p, tC.n_dep, epoch, lane)) return;
+            __syncthreads();
+            gemv_epilogue<SV>(a, s, tC, epoch, lane);
+            const Task tD = gemv_task(a, 3, l, wg, step);
+            if (!sync_edge<SV>(a, s, tD.p, tD.n_dep, epoch, lane)) return;
+            __syncthreads();
+            gemv_epilogue<SV>(a, s, tD, epoch, lane);
+        }
+    }
+}
+
+template <int SV, int PF, bool has_b, bool has_cd>
+__device__ __forceinline__ void compute_wave_loop(const Args& a, Lds& s, unsigned epoch, int wave, int lane) {
+    constexpr bool RA = PF != 0;
+    const int wg = blockIdx.x;
+    const unsigned step = epoch - 1;
+    f16x8 wf[NF];
+    AttnRegs ar;
+    if (RA) load_w_wave(wf, a.wA + (size_t)wg * NKT * 512, wave, lane);
+    for (int l = 0; l < NL; ++l) {
+        const f16* wN = a.wA + (size_t)(l + 1 < NL ? l + 1 : l) * WA_EL + (size_t)wg * NKT * 512;      // next A (layer l + 1)
+        // ---- A ----
+        __syncthreads();
+        if (s.stop) return;
+        gemv_compute<SV, RA>(s, gemv_task(a, 0, l, wg, step), wf, wave, lane);
+        issue_fence();
+        if (RA) { if (has_b) load_kv(ar, a, l, wg, wave, lane); else load_w_wave(wf, wN, wave, lane); }
+        issue_fence();
+        __syncthreads();
+        if (has_b) {
+            // ---- B ----
+            __syncthreads();
+            if (s.stop) return;
+            if (!RA) load_kv(ar, a, l, wg, wave, lane);
+            attn_compute(s, ar, wave, lane);
+            issue_fence();
+            if (RA) load_w_wave(wf, has_cd ? a.wC + (size_t)l * WC_EL + (size_t)wg * NKT * 512 : wN, wave, lane);
+            issue_fence();
+            __syncthreads();
+        }
+        if (has_cd) {
+            // ---- C ----
+            __syncthreads();
+            if (s.stop) return;
+            gemv_compute<SV, RA>(s, gemv_task(a, 2, l, wg, step), wf, wave, lane);
+            issue_fence();
+            if (RA) load_w_wave(wf, a.wD + (size_t)l * WC_EL + (size_t)wg * NKT * 512, wave, lane);
+            issue_fence();
+            __syncthreads();
+            // ---- D ----
+            __syncthreads();
+            if (s.stop) return;
+            gemv_compute<SV, RA>(s, gemv_task(a, 3, l, wg, step), wf, wave, lane);
+            issue_fence();
+            if (RA) load_w_wave(wf, wN, wave, lane);
+            issue_fence();
+            __syncthreads();
+        }
+    }
+}
+
+template <int SV, int PF, bool has_b, bool has_cd>
+__device__ __forceinline__ void role_loop(const Args& a, Lds& s, unsigned epoch, int wave, int lane) {
+    if (wave == 0) sync_wave_loop<SV, PF, has_b, has_cd>(a, s, epoch, lane);
+    else compute_wave_loop<SV, PF, has_b, has_cd>(a, s, epoch, wave, lane);
+}
+
+template <int SV, int PF>
+__global__ __launch_bounds__(THREADS, 4) void persist_kernel(Args a) {
+    __shared__ Lds s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = blockIdx.x;
+    const unsigned epoch = ld_u32(a.epoch_dev) + 1;
+    if (wg < TC) role_loop<SV, PF, true, true>(a, s, epoch, wave, lane);
+    else if (wg < TB) role_loop<SV, PF, true, false>(a, s, epoch, wave, lane);
+    else role_loop<SV, PF, false, false>(a, s, epoch, wave, lane);
+    // the last D task of workgroup 0 closes the step (every workgroup has read the epoch before that task can finish)
+    if (wg == 0 && threadIdx.x == 0 && !ld_u32(a.abort_flag)) st_u32(a.epoch_dev, epoch);
+}
+
+// The same bodies as one kernel per phase (today's structure): no flags, plain loads / stores, kernel boundaries.
+__global__ __launch_bounds__(THREADS, 4) void chain_kernel(Args a, int p) {
+    __shared__ Lds s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned epoch = ld_u32(a.epoch_dev) + 1;
+    const int l = p >> 2, kind = p & 3, task = blockIdx.x;
+    if (kind == 1) {
+        AttnRegs ar;
+        load_kv(ar, a, l, task, wave, lane);
+        if (wave == 0) attn_stage_inputs<2>(a, s, task, lane);
+        __syncthreads();
+        attn_compute(s, ar, wave, lane);
+        __syncthreads();
+        if (wave == 0) attn_epilogue<2>(a, s, l, task, epoch, lane);
+        return;
+    }
+    f16x8 wf[NF];
+    const Task t = gemv_task(a, kind, l, task, epoch - 1);
+    if (wave != 0) gemv_compute<2, false>(s, t, wf, wave, lane);
+    __syncthreads();
+    if (wave == 0) gemv_epilogue<2>(a, s, t, epoch, lane);
+}
+__global__ void close_step_kernel(unsigned* epoch_dev) { *epoch_dev += 1; }
+
+int main(int argc, char** argv) {
+    const int R = argc > 1 ? atoi(argv[1]) : 30;
+    Args a{};
+    f16 *wA, *wC, *wD, *kc, *vc;
+    const size_t kc_el = (size_t)NL * NROW * KC_EL, vc_el = (size_t)NL * NROW * VC_EL;
+    CK(hipMalloc(&wA, WA_EL * NL * 2)); CK(hipMalloc(&wC, WC_EL * NL * 2)); CK(hipMalloc(&wD, WC_EL * NL * 2));
+    CK(hipMalloc(&kc, kc_el * 2)); CK(hipMalloc(&vc, vc_el * 2));
+    CK(hipMemset(wA, 0, WA_EL * NL * 2)); CK(hipMemset(wC, 0, WC_EL * NL * 2)); CK(hipMemset(wD, 0, WC_EL * NL * 2));
+    CK(hipMemset(kc, 0, kc_el * 2)); CK(hipMemset(vc, 0, vc_el * 2));
+    CK(hipMalloc(&a.X0, NROW * WID * 2)); CK(hipMalloc(&a.Q, NROW * JA * 2)); CK(hipMalloc(&a.X1, NROW * WID * 2)); CK(hipMalloc(&a.H, NROW * WID * 2));
+    CK(hipMalloc(&a.flags, (size_t)PH * FROW * 4)); CK(hipMalloc(&a.epoch_dev, 4)); CK(hipMalloc(&a.err, 4)); CK(hipMalloc(&a.abort_flag, 4));
+    CK(hipMalloc(&a.sink, 4)); CK(hipMalloc(&a.stamps, PH * 8));
+    a.wA = wA; a.wC = wC; a.wD = wD; a.kc = kc; a.vc = vc;
+    printf("persistent decode-step probe: %d layers x 4 phases, %d workgroups x %d threads, weights %.2f GB + k/v' rows %.2f GB per step, %d steps per mode\n",
+           NL, G, THREADS, (WA_EL + 2 * WC_EL) * NL * 2 / 1e9, (kc_el + vc_el) * 2 / 1e9, R);
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // X0 as step "-1" (epoch 0) left it: the pattern of phase PH-1 at step 0xffffffff
+    std::vector<f16> h0(NROW * WID);
+    auto reset = [&]() -> int {
+        for (int i = 0; i < NROW * WID; ++i) h0[i] = (f16)(float)(((i + PH - 1) & 7) + (int)((PH - 1 + 5u * 0xffffffffu + 11u) % 11u));
+        CK(hipMemcpy(a.X0, h0.data(), NROW * WID * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(a.flags, 0, (size_t)PH * FROW * 4)); CK(hipMemset(a.epoch_dev, 0, 4)); CK(hipMemset(a.err, 0, 4)); CK(hipMemset(a.abort_flag, 0, 4));
+        CK(hipMemset(a.stamps, 0, PH * 8));
+        CK(hipDeviceSynchronize());
+        return 0;
+    };
+    struct Mode { int kind, sv, pf; const char* name; };
+    const Mode modes[] = {{1, 0, 0, "chain: one kernel per phase, hipGraph (today's structure)"},
+                          {0, 0, 1, "persistent, sc1 + flag row, run-ahead weights / k / v'"},
+                          {0, 0, 0, "persistent, sc1 + flag row, everything after the edge"},
+                          {0, 1, 1, "persistent, release / acquire fences + plain accesses, run-ahead"}};
+    for (const Mode& m : modes) {
+        if (reset()) return 1;
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (m.kind == 1) {
+            for (int p = 0; p < PH; ++p) {
+                const int k = p & 3, n = k == 0 ? TA : (k == 1 ? TB : TC);
+                chain_kernel<<<n, THREADS, 0, st>>>(a, p);
+            }
+            close_step_kernel<<<1, 1, 0, st>>>(a.epoch_dev);
+        } else if (m.sv == 0 && m.pf == 1) persist_kernel<0, 1><<<G, THREADS, 0, st>>>(a);
+        else if (m.sv == 0) persist_kernel<0, 0><<<G, THREADS, 0, st>>>(a);
+        else persist_kernel<1, 1><<<G, THREADS, 0, st>>>(a);
+        CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
+        unsigned ab = 0; CK(hipMemcpy(&ab, a.abort_flag, 4, hipMemcpyDeviceToHost));
+        float ms = 0.f;
+        if (!ab) {
+            CK(hipEventRecord(e0, st));
+            for (int r = 0; r < R; ++r) CK(hipGraphLaunch(ge, st));
+            CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        unsigned errs = 0, ep = 0;
+        CK(hipMemcpy(&errs, a.err, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ab, a.abort_flag, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&ep, a.epoch_dev, 4, hipMemcpyDeviceToHost));
+        printf("%-66s %8.3f ms/step  %6.2f us/phase  (steps done %u, checksum errors %u, aborted %u)\n", m.name, ms / R,
+               ms * 1e3 / ((double)R * PH), ep, errs, ab);
+        if (m.kind == 0) {      // where the time goes: wave 0 of workgroup 0 stamps "inputs ready" of every phase
+            std::vector<long long> sp(PH);
+            CK(hipMemcpy(sp.data(), a.stamps, PH * 8, hipMemcpyDeviceToHost));
+            double d[4] = {0, 0, 0, 0}; int cnt[4] = {0, 0, 0, 0};
+            for (int p = 8; p + 1 < PH; ++p) if (sp[p] && sp[p + 1]) { d[p & 3] += (sp[p + 1] - sp[p]) * 0.01; cnt[p & 3]++; }
+            printf("    ready(next phase) - ready(this phase), last step, us:  A %.2f   B %.2f   C %.2f   D %.2f\n", cnt[0] ? d[0] / cnt[0] : 0,
+                   cnt[1] ? d[1] / cnt[1] : 0, cnt[2] ? d[2] / cnt[2] : 0, cnt[3] ? d[3] / cnt[3] : 0);
+        }
+        fflush(stdout);
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        if (ab) printf("    (a poll timed out: results of this mode are void)\n");
+    }
+    return 0;
+}

@@ -1,0 +1,215 @@
+// Micro-benchmark for SOFTWARE-PIPELINED LAUNCHES of a dependent kernel chain.
+//
+// The decode step is a chain of ~290 kernels; each costs ~6 us of which ~3.5 us do not depend on the producer (launch
+// boundary, wave start, the cold round trip of a weight stream whose addresses are known at capture time).  Here the
+// kernels of the chain alternate between NS streams of one captured graph, so kernel j+1 is dispatched while kernel j runs:
+// it requests its weights, then ONE lane per workgroup polls a flag that kernel j's last workgroup (atomic ticket)
+// publishes with release semantics, and only then reads the activation block.  Every phase models one decode projection:
+// each of G workgroups streams its own 60 KB of a weight matrix that is cold (K distinct matrices, 2 GB in total), reads
+// the whole 16 x 1920 f16 activation block written by ALL workgroups of the previous phase, and writes its slice of the
+// next one.  Visibility across the 8 XCD L2s is checked every phase with a checksum (stale data changes the sum).
+//
+//   NS = 1, no wait : one kernel per phase in stream order -- today's structure (the flag is still published: + ~0.2 us)
+//   NS = 1, wait    : the same with the poll (always satisfied): cost of the flag machinery alone
+//   NS = 2 / 3, wait: pipelined, kernel j+1 (and j+2) resident while j runs
+//   V0: plain loads/stores, agent-scope release (buffer_wbl2 sc1) before the ticket, acquire (buffer_inv sc1) after the poll
+//   V1: activations moved with relaxed agent-scope 8-byte atomics (sc1), no L2 write-back / invalidate
+// Spin loops are bounded: after 2^22 polls a workgroup raises the abort flag, every later poll returns at once and the
+// run is reported as aborted (no hung GPU).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/pipelined_launch_probe tools/pipelined_launch_probe.hip
+// Run:   tools/pipelined_launch_probe [graph launches, default 40]
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+constexpr int N_EL = 16 * 1920;            // halfs per activation block
+constexpr int N_W8 = N_EL / 4;             // 8-byte words
+constexpr int THREADS = 512;
+constexpr int K = 288;                     // kernels per graph (even: the double buffer of phase j is static)
+constexpr int PAD = 32;                    // flags / tickets 128 B apart
+typedef unsigned long long u64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Args {
+    __half* act; const u32x4* wts; size_t w_phase_u4; unsigned* flags; unsigned* tickets; unsigned* err; unsigned* abort_flag;
+    float* sink; int G;
+};
+
+__device__ inline float expected_sum(unsigned p) { return 107520.0f + 30720.0f * (float)(p & 3); }
+__device__ inline __half value_at(int i, unsigned p) { return __float2half((float)(((i + p) & 7) + (p & 3))); }
+
+template <int V> __device__ inline u64 ld8(const u64* p) {
+    if constexpr (V == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <int V> __device__ inline void st8(u64* p, u64 v) {
+    if constexpr (V == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ inline unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_kernel(Args a, int j) {
+    __shared__ float red[THREADS / 64];
+    __shared__ unsigned s_i;
+    const int tid = threadIdx.x, wg = blockIdx.x;
+    // 1. the weight stream does not depend on the producer: request it first (8 x 16 B per thread = 64 KB per workgroup)
+    const size_t per_wg = a.w_phase_u4 / a.G;
+    const u32x4* w = a.wts + (size_t)j * a.w_phase_u4 + (size_t)wg * per_wg;
+    u32x4 wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const size_t k = (size_t)tid + (size_t)u * THREADS;
+        wv[u] = __builtin_nontemporal_load(w + (k < per_wg ? k : per_wg - 1));
+    }
+    asm volatile("" ::: "memory");
+    // 2. how often has this slot run (its own flag), then wait for the producer slot to have run once more
+    if (tid == 0) {
+        const unsigned i = ld_flag(a.flags + j * PAD);
+        if constexpr (WAIT) {
+            const int prev = j == 0 ? K - 1 : j - 1;
+            const unsigned need = j == 0 ? i : i + 1;
+            unsigned spins = 0;
+            while (ld_flag(a.flags + prev * PAD) < need) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22) || ld_flag(a.abort_flag)) {
+                    __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        s_i = i;
+    }
+    __syncthreads();
+    if constexpr (V == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // buffer_inv sc1
+    const unsigned i = s_i, p = i * (unsigned)K + (unsigned)j;
+    const __half* src = a.act + (size_t)(j & 1) * N_EL;
+    __half* dst = a.act + (size_t)((j + 1) & 1) * N_EL;
+    // 3. the whole activation block, checksummed
+    float s = 0.f;
+    const u64* s8 = reinterpret_cast<const u64*>(src);
+    u64 r[N_W8 / THREADS];
+#pragma unroll
+    for (int u = 0; u < N_W8 / THREADS; ++u) r[u] = ld8<V>(s8 + tid + u * THREADS);
+#pragma unroll
+    for (int u = 0; u < N_W8 / THREADS; ++u) {
+        union { u64 q; __half h[4]; } cv; cv.q = r[u];
+        s += __half2float(cv.h[0]) + __half2float(cv.h[1]) + __half2float(cv.h[2]) + __half2float(cv.h[3]);
+    }
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int k = 0; k < THREADS / 64; ++k) tot += red[k];
+    if (tid == 0 && tot != expected_sum(p)) atomicAdd(a.err, 1u);
+    // 4. my slice of the next block
+    const int per = N_EL / a.G, w8 = per / 4;
+    if (tid < w8) {
+        union { u64 q; __half h[4]; } cv;
+        const int i0 = wg * per + tid * 4;
+        for (int k = 0; k < 4; ++k) cv.h[k] = value_at(i0 + k, p + 1);
+        st8<V>(reinterpret_cast<u64*>(dst) + (i0 >> 2), cv.q);
+    }
+    float wacc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wacc += __uint_as_float(wv[u].x ^ wv[u].y ^ wv[u].z ^ wv[u].w);
+    if (wacc + tot * 1e-30f == 123.456f) a.sink[0] = wacc;
+    // 5. publish: every workgroup's stores are visible device-wide before its ticket; the last ticket raises the flag
+    if constexpr (V == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // s_waitcnt + buffer_wbl2 sc1
+    else { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(a.tickets + j * PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)a.G - 1) {
+            __hip_atomic_store(a.tickets + j * PAD, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.flags + j * PAD, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int V, bool WAIT> static void launch(const Args& a, int j, hipStream_t s) {
+    phase_kernel<V, WAIT><<<a.G, THREADS, 0, s>>>(a, j);
+}
+
+int main(int argc, char** argv) {
+    const int R = argc > 1 ? atoi(argv[1]) : 40;
+    std::vector<__half> h(N_EL);
+    for (int i = 0; i < N_EL; ++i) h[i] = __float2half((float)((i & 7)));
+    __half* act; unsigned *flags, *tickets, *err, *abortf; float* sink; u32x4* wts;
+    const size_t W_MAX_PHASE = 11059200;                         // 1920 x 2880 f16
+    CK(hipMalloc(&act, 2 * N_EL * 2)); CK(hipMalloc(&flags, K * PAD * 4)); CK(hipMalloc(&tickets, K * PAD * 4));
+    CK(hipMalloc(&err, 4)); CK(hipMalloc(&abortf, 4)); CK(hipMalloc(&sink, 4));
+    CK(hipMalloc(&wts, W_MAX_PHASE * K)); CK(hipMemset(wts, 1, W_MAX_PHASE * K));
+    int lo = 0, hi = 0;
+    CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t st[3];
+    for (int k = 0; k < 3; ++k) {                                // distinct priority classes: distinct hardware queues
+        int pr = hi + k; if (pr > lo) pr = lo;
+        CK(hipStreamCreateWithPriority(&st[k], hipStreamNonBlocking, pr));
+    }
+    hipEvent_t e0, e1, fork, join[3];
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    for (int k = 0; k < 3; ++k) CK(hipEventCreateWithFlags(&join[k], hipEventDisableTiming));
+    struct Shape { int G; size_t wbytes; const char* what; };
+    const Shape shapes[3] = {{120, 7372800, "c_fc / mlp.c_proj (1920x1920)"}, {192, 11059200, "wide c_attn (1920x2880)"},
+                             {120, 0, "no weights"}};
+    struct Mode { int ns; bool wait; bool graph; const char* name; };
+    const Mode modes[6] = {{1, false, true, "graph 1 stream, no wait"}, {1, true, true, "graph 1 stream, wait"},
+                           {2, true, true, "graph 2 streams, wait"}, {3, true, true, "graph 3 streams, wait"},
+                           {2, true, false, "eager 2 streams, wait"}, {1, false, false, "eager 1 stream, no wait"}};
+    for (const Shape& sh : shapes) for (int v = 0; v < 2; ++v) for (const Mode& m : modes) {
+        Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G};
+        if (a.w_phase_u4 == 0) a.w_phase_u4 = (size_t)sh.G;      // one dummy vector per workgroup
+        CK(hipMemcpy(act, h.data(), N_EL * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(flags, 0, K * PAD * 4)); CK(hipMemset(tickets, 0, K * PAD * 4)); CK(hipMemset(err, 0, 4)); CK(hipMemset(abortf, 0, 4));
+        CK(hipDeviceSynchronize());
+        auto enqueue = [&](bool capture) -> int {
+            if (capture && m.ns > 1) {
+                CK(hipEventRecord(fork, st[0]));
+                for (int k = 1; k < m.ns; ++k) CK(hipStreamWaitEvent(st[k], fork, 0));
+            }
+            for (int j = 0; j < K; ++j) {
+                hipStream_t s = st[j % m.ns];
+                if (v == 0) { if (m.wait) launch<0, true>(a, j, s); else launch<0, false>(a, j, s); }
+                else { if (m.wait) launch<1, true>(a, j, s); else launch<1, false>(a, j, s); }
+            }
+            if (capture && m.ns > 1)
+                for (int k = 1; k < m.ns; ++k) { CK(hipEventRecord(join[k], st[k])); CK(hipStreamWaitEvent(st[0], join[k], 0)); }
+            return 0;
+        };
+        float ms = 0.f;
+        if (m.graph) {
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(st[0], hipStreamCaptureModeThreadLocal));
+            if (enqueue(true)) return 1;
+            CK(hipStreamEndCapture(st[0], &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(ge, st[0])); CK(hipStreamSynchronize(st[0]));          // warm-up
+            CK(hipEventRecord(e0, st[0]));
+            for (int r = 0; r < R; ++r) CK(hipGraphLaunch(ge, st[0]));
+            CK(hipEventRecord(e1, st[0])); CK(hipStreamSynchronize(st[0]));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        } else {
+            // eager: with several streams the flags are the ONLY dependency between streams; a repetition starts when the
+            // previous one has finished on every stream (the host joins them)
+            if (enqueue(false)) return 1;
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, st[0]));
+            for (int r = 0; r < R; ++r) {
+                if (enqueue(false)) return 1;
+                for (int k = 1; k < m.ns; ++k) { CK(hipEventRecord(join[k], st[k])); CK(hipStreamWaitEvent(st[0], join[k], 0)); }
+            }
+            CK(hipEventRecord(e1, st[0])); CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        unsigned errs = 0, ab = 0;
+        CK(hipMemcpy(&errs, err, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ab, abortf, 4, hipMemcpyDeviceToHost));
+        printf("%-30s G=%3d V%d %-26s %6.2f us/phase  (checksum errors %u, aborted %u)\n", sh.what, sh.G, v, m.name,
+               ms * 1e3 / ((double)R * K), errs, ab);
+        fflush(stdout);
+        if (ab) { printf("aborted: a poll timed out -- stopping\n"); return 2; }
+    }
+    return 0;
+}
