@@ -51,7 +51,12 @@ constexpr size_t KC_EL = (size_t)KEYS * SST, VC_EL = (size_t)KEYS * WID;  // per
 struct Args {
     const f16* wA; const f16* wC; const f16* wD; const f16* kc; const f16* vc;
     f16* X0; f16* Q; f16* X1; f16* H;
-    unsigned* flags; unsigned* epoch_dev; unsigned* err; unsigned* abort_flag; float* sink; long long* stamps;
+    unsigned* flags; unsigned* epoch_dev; unsigned* err; unsigned* abort_flag; float* sink; long long* stamps; long long* pub;
+    unsigned* progress;      // chain + prefetcher: epoch * 512 + phase of the newest chain kernel that has started
+    unsigned* xcd_rank;      // [8] prefetcher workgroups registered per XCD (reset by the chain's first kernel)
+    unsigned* census;        // [8][2]: chain workgroups of phase 0 seen on XCD x, of which block % 8 == x
+    int hot;                 // chain: every layer reads layer 0's weights / k / v' rows (upper bound of what ANY prefetching can give)
+    int w_nt;                // chain: weight loads non-temporal (today) or default policy (so that prefetched lines are kept)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p) {
@@ -100,11 +105,12 @@ template <int SV> __device__ __forceinline__ void publish(unsigned* flag, unsign
     if constexpr (SV != 2) { if (lane == 0) st_u32(flag, epoch); }
 }
 
-struct Task { const f16* w; const f16* x; int ldx; f16* out; int ldo; int jt; int p; int n_dep; float expect; int nmf; };
+struct Task { const f16* w; const f16* x; int ldx; f16* out; int ldo; int jt; int p; int n_dep; float expect; int nmf; long long* st; };
 
 __device__ __forceinline__ Task gemv_task(const Args& a, int kind, int l, int jt, unsigned step) {
     Task t;
     t.jt = jt; t.p = 4 * l + kind;
+    t.st = (a.stamps && jt == 0) ? a.stamps + (size_t)t.p * 8 : nullptr;
     const float blk = 107520.0f;       // sum of ((i + p) & 7) over 16 x 1920 consecutive indices
     if (kind == 0) {
         t.w = a.wA + (size_t)l * WA_EL; t.x = a.X0; t.ldx = WID; t.out = a.Q; t.ldo = JA; t.n_dep = l == 0 ? 0 : TD; t.nmf = 3;
@@ -125,12 +131,13 @@ __device__ __forceinline__ Task gemv_task(const Args& a, int kind, int l, int jt
 constexpr int NF = 9;
 __device__ __forceinline__ int kt_first(int wave) { return ((wave - 1) * NKT) / (NW - 1); }
 
+template <int AUX = 2>       // 2 = nt
 __device__ __forceinline__ void load_w_wave(f16x8 (&wf)[NF], const f16* w, int wave, int lane) {
     const int kt0 = kt_first(wave);
     const __amdgpu_buffer_rsrc_t rs = rsrc(w);
 #pragma unroll
     for (int i = 0; i < NF; ++i)
-        wf[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, min(kt0 + i, NKT - 1) * 1024, 2));   // nt
+        wf[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, min(kt0 + i, NKT - 1) * 1024, AUX));
 }
 
 struct AttnRegs { f16x8 kf[15]; f16x4 vv[16]; };
@@ -161,13 +168,15 @@ template <int SV, bool RUNAHEAD>
 __device__ __forceinline__ void gemv_compute(Lds& s, const Task& t, f16x8 (&wf)[NF], int wave, int lane) {
     const int g = lane >> 4, c = lane & 15;
     const int kt0 = kt_first(wave), kt1 = kt_first(wave + 1);
-    if (!RUNAHEAD) load_w_wave(wf, t.w, wave, lane);
+    if (!RUNAHEAD) { if (SV == 3) load_w_wave<0>(wf, t.w, wave, lane); else load_w_wave(wf, t.w, wave, lane); }
     f16x8 xf[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
         xf[i] = ld_act<SV>(t.x, c * t.ldx + g * 8, min(kt0 + i, NKT - 1) * 32);
     }
     issue_fence();
+    if (t.st && wave == 1 && lane == 0) t.st[1] = wall_clock64();                 // released, requests issued
+    if (t.st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (wave == 1 && lane == 0) t.st[2] = wall_clock64(); }   // operands landed
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
         if (kt0 + i >= kt1) {
@@ -187,14 +196,16 @@ __device__ __forceinline__ void gemv_compute(Lds& s, const Task& t, f16x8 (&wf)[
     }
     s.acc[wave][lane] = acc + a2 * 1e-30f;
     if (g == 0) s.sum[wave][c] = a1[0];
+    if (t.st && wave == 1 && lane == 0) t.st[3] = wall_clock64();                 // partial tile written
 }
 
 // wave 0 after the partial tiles are in LDS: reduce, check what was read, store the tile, publish
 template <int SV> __device__ __forceinline__ void gemv_epilogue(const Args& a, Lds& s, const Task& t, unsigned epoch, int lane) {
+    if (t.st && lane == 0) t.st[4] = wall_clock64();                              // sync wave past barrier 2
     f32x4 v = {0, 0, 0, 0};
     float rs = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { v += s.acc[w][lane]; rs += s.sum[w][lane & 15]; }
+    for (int w = 1; w < NW; ++w) { v += s.acc[w][lane]; rs += s.sum[w][lane & 15]; }      // wave 0 carries no k-tiles
     float tot = lane < 16 ? rs : 0.f;
 #pragma unroll
     for (int o = 32; o; o >>= 1) tot += __shfl_xor(tot, o);
@@ -206,7 +217,9 @@ template <int SV> __device__ __forceinline__ void gemv_epilogue(const Args& a, L
     for (int r = 0; r < 4; ++r) o[r] = (f16)(val_at(i0 + r, t.p, epoch - 1) + bump);
     if constexpr (SV == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrc(t.out), i0 * 2, 0, 16);
     else *reinterpret_cast<f16x4*>(t.out + i0) = o;
+    if (t.st && lane == 0) t.st[5] = wall_clock64();                              // stores issued
     publish<SV>(a.flags + (size_t)t.p * FROW + t.jt, epoch, lane);
+    if (lane == 0) { if (t.st) t.st[6] = wall_clock64(); if (a.pub) a.pub[(size_t)t.p * FROW + t.jt] = wall_clock64(); }
 }
 
 // ---- wide attention task (sample n, slice sl): wave 0 stages q and the fresh k / v' row in LDS, every wave one key tile ----
@@ -306,6 +319,7 @@ template <int SV> __device__ __forceinline__ void attn_epilogue(const Args& a, L
         else *reinterpret_cast<f16x4*>(a.X1 + i0) = o;
     }
     publish<SV>(a.flags + (size_t)p * FROW + task, epoch, lane);
+    if (lane == 0 && a.pub) a.pub[(size_t)p * FROW + task] = wall_clock64();
 }
 
 // The two wave programs of a workgroup execute the same sequence of barriers (two per task: "inputs visible" and "partial
@@ -317,7 +331,7 @@ template <int SV> __device__ __forceinline__ void attn_epilogue(const Args& a, L
 template <int SV> __device__ __forceinline__ bool sync_edge(const Args& a, Lds& s, int p, int n_dep, unsigned epoch, int lane) {
     const bool ok = wait_flags<SV>(a, a.flags + (size_t)(p - 1) * FROW, n_dep, epoch, lane);
     if (lane == 0) s.stop = ok ? 0 : 1;
-    if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[p] = wall_clock64();
+    if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[p * 8] = wall_clock64();
     __syncthreads();
     return ok;
 }
@@ -339,7 +353,7 @@ __device__ __forceinline__ void sync_wave_loop(const Args& a, Lds& s, unsigned e
             const bool ok = wait_flags<SV>(a, a.flags + (size_t)(4 * l) * FROW, TA, epoch, lane);
             if (ok) attn_stage_inputs<SV>(a, s, wg, lane);
             if (lane == 0) s.stop = ok ? 0 : 1;
-            if (a.stamps && wg == 0 && lane == 0) a.stamps[4 * l + 1] = wall_clock64();
+            if (a.stamps && wg == 0 && lane == 0) a.stamps[(4 * l + 1) * 8] = wall_clock64();
             __syncthreads();
             if (!ok) return;
             if (!RA) load_kv(ar, a, l, wg, 0, lane);
@@ -434,10 +448,19 @@ __global__ __launch_bounds__(THREADS, 4) void chain_kernel(Args a, int p) {
     __shared__ Lds s;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned epoch = ld_u32(a.epoch_dev) + 1;
-    const int l = p >> 2, kind = p & 3, task = blockIdx.x;
+    const int kind = p & 3, task = blockIdx.x;
+    int l = p >> 2;
+    if (a.progress && task == 0 && threadIdx.x == 0) {
+        st_u32(a.progress, epoch * 512u + (unsigned)p);
+    }
+    if (a.census && p == 4 && threadIdx.x == 0) {
+        const unsigned x = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;
+        atomicAdd(a.census + 2 * x, 1u);
+        if ((task & 7) == (int)x) atomicAdd(a.census + 2 * x + 1, 1u);
+    }
     if (kind == 1) {
         AttnRegs ar;
-        load_kv(ar, a, l, task, wave, lane);
+        load_kv(ar, a, a.hot ? 0 : l, task, wave, lane);
         if (wave == 0) attn_stage_inputs<2>(a, s, task, lane);
         __syncthreads();
         attn_compute(s, ar, wave, lane);
@@ -446,10 +469,75 @@ __global__ __launch_bounds__(THREADS, 4) void chain_kernel(Args a, int p) {
         return;
     }
     f16x8 wf[NF];
-    const Task t = gemv_task(a, kind, l, task, epoch - 1);
-    if (wave != 0) gemv_compute<2, false>(s, t, wf, wave, lane);
+    Task t = gemv_task(a, kind, l, task, epoch - 1);
+    if (a.hot) t.w = gemv_task(a, kind, 0, task, epoch - 1).w;
+    if (wave != 0) { if (a.w_nt) gemv_compute<2, false>(s, t, wf, wave, lane); else gemv_compute<3, false>(s, t, wf, wave, lane); }
     __syncthreads();
     if (wave == 0) gemv_epilogue<2>(a, s, t, epoch, lane);
+}
+
+// Side-stream prefetcher for the launch chain: one wave per workgroup, 256 workgroups.  While the chain executes phase p it
+// pulls the weights (and the old K / v' rows) of phase p + lead into the L2 of the XCD whose workgroups will consume them
+// (a fresh grid places block b on XCD b % 8: observed, not guaranteed -- a miss costs speed only).  Never waited for by the
+// chain; paced by the progress word the chain kernels publish; leaves when the step is over or nothing moves for 20 ms.
+__global__ __launch_bounds__(512) void prefetch_kernel(Args a, int lead) {
+    // 256 workgroups x 8 waves: per phase every wave issues ONE batch of <= 8 KiB; wave 0 paces the workgroup.
+    __shared__ unsigned s_pr;
+    const int lane = threadIdx.x & 63, pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);       // the XCD this workgroup really runs on
+    const int slot = ((blockIdx.x >> 3) & 31) * 8 + pw;                         // 256 wave slots per XCD when block b sits on XCD b % 8
+    const unsigned epoch = ld_u32(a.epoch_dev) + 1;
+    const long long t_start = wall_clock64();
+    for (int q = 0; q < PH; ++q) {
+        const unsigned want = epoch * 512u + (unsigned)(q > lead ? q - lead : 0);
+        if (pw == 0) {
+            unsigned pr;
+            for (;;) {
+                pr = ld_u32(a.progress);
+                if (pr >= want) break;
+                if (ld_u32(a.epoch_dev) + 1 != epoch || wall_clock64() - t_start > 2000000ll) { pr = 0xffffffffu; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (lane == 0) s_pr = pr;
+        }
+        __syncthreads();
+        const unsigned pr = s_pr;
+        __syncthreads();
+        if (pr == 0xffffffffu) return;
+        if (pr >= epoch * 512u + (unsigned)q) {                   // the chain is already there: too late for this phase
+            if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(a.census + 16, 1u);
+            continue;
+        }
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(a.census + 17, 1u);
+        const int l = q >> 2, kind = q & 3;
+        u32x4 v[8];
+        if (kind == 1) {
+            // attention tasks of this XCD (task % 8 == x): per task 60 KiB of K rows (60 items) + 64 v' slice rows (32 items)
+            const int n_task = (TB - x + 7) / 8, M = n_task * 92;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = min(slot + 256 * u, M - 1), task = x + 8 * (m / 92), i = m % 92;
+                const int n = task / NSL, sl = task % NSL;
+                if (i < 60)
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.kc + (size_t)l * NROW * KC_EL), lane * 16, (n * (int)KC_EL) * 2 + i * 1024, 0);
+                else
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.vc + (size_t)l * NROW * VC_EL), (min(lane, 59) % 30) * 16 + (lane >= 30) * WID * 2,
+                                                                 (n * (int)VC_EL + sl * SLW + (i - 60) * 2 * WID) * 2, 0);
+            }
+        } else {
+            const f16* w = kind == 0 ? a.wA + (size_t)l * WA_EL : (kind == 2 ? a.wC : a.wD) + (size_t)l * WC_EL;
+            const int nt = kind == 0 ? TA : TC;
+            const int n_tile = (nt - x + 7) / 8, M = n_tile * NKT;
+            const __amdgpu_buffer_rsrc_t rs = rsrc(w);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = min(slot + 256 * u, M - 1), jt = x + 8 * (m / NKT), kt = m % NKT;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (jt * NKT + kt) * 1024, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" :: "v"(v[u]));
+    }
 }
 __global__ void close_step_kernel(unsigned* epoch_dev) { *epoch_dev += 1; }
 
@@ -464,7 +552,12 @@ int main(int argc, char** argv) {
     CK(hipMemset(kc, 0, kc_el * 2)); CK(hipMemset(vc, 0, vc_el * 2));
     CK(hipMalloc(&a.X0, NROW * WID * 2)); CK(hipMalloc(&a.Q, NROW * JA * 2)); CK(hipMalloc(&a.X1, NROW * WID * 2)); CK(hipMalloc(&a.H, NROW * WID * 2));
     CK(hipMalloc(&a.flags, (size_t)PH * FROW * 4)); CK(hipMalloc(&a.epoch_dev, 4)); CK(hipMalloc(&a.err, 4)); CK(hipMalloc(&a.abort_flag, 4));
-    CK(hipMalloc(&a.sink, 4)); CK(hipMalloc(&a.stamps, PH * 8));
+    CK(hipMalloc(&a.sink, 4)); CK(hipMalloc(&a.stamps, PH * 64)); CK(hipMalloc(&a.pub, (size_t)PH * FROW * 8));
+    unsigned *progress, *xcd_rank, *census;
+    CK(hipMalloc(&progress, 4)); CK(hipMalloc(&xcd_rank, 8 * 32 * 4)); CK(hipMalloc(&census, 128));
+    CK(hipMemset(progress, 0, 4)); CK(hipMemset(xcd_rank, 0, 8 * 32 * 4)); CK(hipMemset(census, 0, 128));
+    a.w_nt = 1;
+    hipStream_t st2; CK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
     a.wA = wA; a.wC = wC; a.wD = wD; a.kc = kc; a.vc = vc;
     printf("persistent decode-step probe: %d layers x 4 phases, %d workgroups x %d threads, weights %.2f GB + k/v' rows %.2f GB per step, %d steps per mode\n",
            NL, G, THREADS, (WA_EL + 2 * WC_EL) * NL * 2 / 1e9, (kc_el + vc_el) * 2 / 1e9, R);
@@ -476,20 +569,30 @@ int main(int argc, char** argv) {
         for (int i = 0; i < NROW * WID; ++i) h0[i] = (f16)(float)(((i + PH - 1) & 7) + (int)((PH - 1 + 5u * 0xffffffffu + 11u) % 11u));
         CK(hipMemcpy(a.X0, h0.data(), NROW * WID * 2, hipMemcpyHostToDevice));
         CK(hipMemset(a.flags, 0, (size_t)PH * FROW * 4)); CK(hipMemset(a.epoch_dev, 0, 4)); CK(hipMemset(a.err, 0, 4)); CK(hipMemset(a.abort_flag, 0, 4));
-        CK(hipMemset(a.stamps, 0, PH * 8));
+        CK(hipMemset(a.stamps, 0, PH * 64)); CK(hipMemset(a.pub, 0, (size_t)PH * FROW * 8));
         CK(hipDeviceSynchronize());
         return 0;
     };
     struct Mode { int kind, sv, pf; const char* name; };
-    const Mode modes[] = {{1, 0, 0, "chain: one kernel per phase, hipGraph (today's structure)"},
+    // kind 1: chain;  kind 2: chain + side-stream prefetcher (sv = lead in phases, pf = 1: chain weight loads non-temporal)
+    const Mode modes[] = {{1, 0, 1, "chain: one kernel per phase, hipGraph (today's structure)"},
+                          {1, 0, 0, "chain, default-policy weight loads (no prefetcher)"},
+                          {3, 0, 0, "chain, HOT weights and k / v' rows (every layer reads layer 0's), default policy"},
+                          {2, 1, 0, "chain + L2 prefetcher, lead 1, default-policy loads"},
+                          {2, 2, 0, "chain + L2 prefetcher, lead 2, default-policy loads"},
+                          {2, 3, 0, "chain + L2 prefetcher, lead 3, default-policy loads"},
+                          {2, 2, 1, "chain + L2 prefetcher, lead 2, non-temporal loads"},
                           {0, 0, 1, "persistent, sc1 + flag row, run-ahead weights / k / v'"},
                           {0, 0, 0, "persistent, sc1 + flag row, everything after the edge"},
                           {0, 1, 1, "persistent, release / acquire fences + plain accesses, run-ahead"}};
     for (const Mode& m : modes) {
         if (reset()) return 1;
+        CK(hipMemset(census, 0, 128)); CK(hipDeviceSynchronize());
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        if (m.kind == 1) {
+        a.progress = m.kind == 2 ? progress : nullptr; a.census = m.kind == 2 ? census : nullptr;
+        a.xcd_rank = xcd_rank; a.w_nt = m.kind == 0 ? 1 : m.pf; a.hot = m.kind == 3;
+        if (m.kind >= 1) {
             for (int p = 0; p < PH; ++p) {
                 const int k = p & 3, n = k == 0 ? TA : (k == 1 ? TB : TC);
                 chain_kernel<<<n, THREADS, 0, st>>>(a, p);
@@ -499,14 +602,14 @@ int main(int argc, char** argv) {
         else if (m.sv == 0) persist_kernel<0, 0><<<G, THREADS, 0, st>>>(a);
         else persist_kernel<1, 1><<<G, THREADS, 0, st>>>(a);
         CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, st));
-        CK(hipStreamSynchronize(st));
+        for (int r = 0; r < 3; ++r) { CK(hipGraphLaunch(ge, st)); if (m.kind == 2) prefetch_kernel<<<256, 512, 0, st2>>>(a, m.sv); }
+        CK(hipStreamSynchronize(st)); CK(hipStreamSynchronize(st2));
         unsigned ab = 0; CK(hipMemcpy(&ab, a.abort_flag, 4, hipMemcpyDeviceToHost));
         float ms = 0.f;
         if (!ab) {
             CK(hipEventRecord(e0, st));
-            for (int r = 0; r < R; ++r) CK(hipGraphLaunch(ge, st));
-            CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+            for (int r = 0; r < R; ++r) { CK(hipGraphLaunch(ge, st)); if (m.kind == 2) prefetch_kernel<<<256, 512, 0, st2>>>(a, m.sv); }
+            CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st)); CK(hipStreamSynchronize(st2));
             CK(hipEventElapsedTime(&ms, e0, e1));
         }
         unsigned errs = 0, ep = 0;
@@ -514,13 +617,33 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(&ep, a.epoch_dev, 4, hipMemcpyDeviceToHost));
         printf("%-66s %8.3f ms/step  %6.2f us/phase  (steps done %u, checksum errors %u, aborted %u)\n", m.name, ms / R,
                ms * 1e3 / ((double)R * PH), ep, errs, ab);
-        if (m.kind == 0) {      // where the time goes: wave 0 of workgroup 0 stamps "inputs ready" of every phase
-            std::vector<long long> sp(PH);
-            CK(hipMemcpy(sp.data(), a.stamps, PH * 8, hipMemcpyDeviceToHost));
-            double d[4] = {0, 0, 0, 0}; int cnt[4] = {0, 0, 0, 0};
-            for (int p = 8; p + 1 < PH; ++p) if (sp[p] && sp[p + 1]) { d[p & 3] += (sp[p + 1] - sp[p]) * 0.01; cnt[p & 3]++; }
-            printf("    ready(next phase) - ready(this phase), last step, us:  A %.2f   B %.2f   C %.2f   D %.2f\n", cnt[0] ? d[0] / cnt[0] : 0,
-                   cnt[1] ? d[1] / cnt[1] : 0, cnt[2] ? d[2] / cnt[2] : 0, cnt[3] ? d[3] / cnt[3] : 0);
+        if (a.census) {
+            unsigned cz[32]; CK(hipMemcpy(cz, census, 128, hipMemcpyDeviceToHost));
+            printf("    chain workgroups per XCD (of which block %% 8 == XCD): ");
+            for (int x = 0; x < 8; ++x) printf("%u(%u) ", cz[2 * x], cz[2 * x + 1]);
+            printf("  prefetcher: %u phases served, %u skipped as too late\n", cz[17], cz[16]);
+        }
+        if (m.kind == 0) {      // where the time goes, last step: stamps of workgroup 0, publish times of every producer
+            std::vector<long long> sp(PH * 8), pb((size_t)PH * FROW);
+            CK(hipMemcpy(sp.data(), a.stamps, PH * 64, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(pb.data(), a.pub, (size_t)PH * FROW * 8, hipMemcpyDeviceToHost));
+            const char* nm[4] = {"A", "B", "C", "D"};
+            for (int k = 0; k < 4; ++k) {
+                double seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, spread = 0, prop = 0, whole = 0; int cnt = 0;
+                for (int p = 8 + k; p + 1 < PH; p += 4) {
+                    const long long* t = &sp[(size_t)p * 8];
+                    const int nprod = k == 0 ? TA : (k == 1 ? TB : TC);
+                    long long lo = 1ll << 62, hi = 0;
+                    for (int j = 0; j < nprod; ++j) { const long long v = pb[(size_t)p * FROW + j]; if (v) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; } }
+                    if (!t[0] || !sp[(size_t)(p + 1) * 8] || !hi) continue;
+                    for (int i = 1; i <= 6; ++i) seg[i] += t[i] ? (t[i] - t[0]) * 0.01 : 0;
+                    spread += (hi - lo) * 0.01; prop += (sp[(size_t)(p + 1) * 8] - hi) * 0.01; whole += (sp[(size_t)(p + 1) * 8] - t[0]) * 0.01; cnt++;
+                }
+                if (!cnt) continue;
+                printf("    %s: ready -> released %.2f -> operands landed %.2f -> partials %.2f -> sync wave %.2f -> stores issued %.2f -> published %.2f | "
+                       "first..last publish %.2f, last publish -> next phase ready %.2f, whole %.2f us\n", nm[k], seg[1] / cnt, seg[2] / cnt, seg[3] / cnt,
+                       seg[4] / cnt, seg[5] / cnt, seg[6] / cnt, spread / cnt, prop / cnt, whole / cnt);
+            }
         }
         fflush(stdout);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));

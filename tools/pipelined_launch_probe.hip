@@ -14,6 +14,12 @@
 //   NS = 2 / 3, wait: pipelined, kernel j+1 (and j+2) resident while j runs
 //   V0: plain loads/stores, agent-scope release (buffer_wbl2 sc1) before the ticket, acquire (buffer_inv sc1) after the poll
 //   V1: activations moved with relaxed agent-scope 8-byte atomics (sc1), no L2 write-back / invalidate
+//   V2: V1 with a flag ROW per slot (one word per producer workgroup, no ticket atomics), polled by wave 0 with one
+//       16-byte sc1 load per lane (round 3)
+//   V3: V1 with the completion count sharded per XCD: every workgroup adds 1 (non-returning atomic) to the counter of the XCD
+//       it runs on, the consumer's lanes 0..7 read the 8 counters with one sc1 load and compare their sum with (i + 1) * G
+//   "2 graphs": the even and the odd kernels of the chain as two single-stream graphs replayed on two streams (a 2-stream
+//       capture in ONE graph replays at 22 us per kernel: round 3, profiles/r03_pipelined_launch_probe.log)
 // Spin loops are bounded: after 2^22 polls a workgroup raises the abort flag, every later poll returns at once and the
 // run is reported as aborted (no hung GPU).
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/pipelined_launch_probe tools/pipelined_launch_probe.hip
@@ -35,18 +41,21 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct Args {
     __half* act; const u32x4* wts; size_t w_phase_u4; unsigned* flags; unsigned* tickets; unsigned* err; unsigned* abort_flag;
-    float* sink; int G;
+    float* sink; int G; unsigned* rows;      // rows: [K][256] per-producer flags (V2)
 };
+__device__ inline __amdgpu_buffer_rsrc_t rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, 0x7fffffff, 0x00020000);
+}
 
 __device__ inline float expected_sum(unsigned p) { return 107520.0f + 30720.0f * (float)(p & 3); }
 __device__ inline __half value_at(int i, unsigned p) { return __float2half((float)(((i + p) & 7) + (p & 3))); }
 
 template <int V> __device__ inline u64 ld8(const u64* p) {
-    if constexpr (V == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (V >= 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
 }
 template <int V> __device__ inline void st8(u64* p, u64 v) {
-    if constexpr (V == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (V >= 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
 __device__ inline unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -66,7 +75,51 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
     }
     asm volatile("" ::: "memory");
     // 2. how often has this slot run (its own flag), then wait for the producer slot to have run once more
-    if (tid == 0) {
+    if constexpr (V == 3) {
+        if (tid < 64) {
+            // counters never reset: slot j has run i times when its 8 counters sum to i * G
+            auto total = [&](int slot) {
+                unsigned c = tid < 8 ? ld_flag(a.rows + (size_t)slot * 256 + tid * 16) : 0u;
+                for (int o = 4; o; o >>= 1) c += __shfl_xor(c, o);
+                return __shfl(c, 0);
+            };
+            const unsigned i = total(j) / (unsigned)a.G;
+            if constexpr (WAIT) {
+                const int prev = j == 0 ? K - 1 : j - 1;
+                const unsigned need = (j == 0 ? i : i + 1) * (unsigned)a.G;
+                for (unsigned spins = 0;; ++spins) {
+                    if (total(prev) >= need) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins > (1u << 20) || ((spins & 255) == 255 && ld_flag(a.abort_flag))) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            if (tid == 0) s_i = i;
+        }
+    } else if constexpr (V == 2) {
+        if (tid < 64) {
+            // how often has this slot run: its own row entry of workgroup 0; the producer slot must have run once more
+            const unsigned i = ld_flag(a.rows + (size_t)j * 256 + wg);
+            if constexpr (WAIT) {
+                const int prev = j == 0 ? K - 1 : j - 1;
+                const unsigned need = j == 0 ? i : i + 1;
+                for (unsigned spins = 0;; ++spins) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.rows + (size_t)prev * 256), tid * 16, 0, 16);
+                    bool ok = true;
+                    for (int r = 0; r < 4; ++r) ok = ok && (tid * 4 + r >= a.G || v[r] >= need);
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins > (1u << 20) || ((spins & 255) == 255 && ld_flag(a.abort_flag))) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            if (tid == 0) s_i = i;
+        }
+    } else if (tid == 0) {
         const unsigned i = ld_flag(a.flags + j * PAD);
         if constexpr (WAIT) {
             const int prev = j == 0 ? K - 1 : j - 1;
@@ -118,9 +171,16 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
     if (wacc + tot * 1e-30f == 123.456f) a.sink[0] = wacc;
     // 5. publish: every workgroup's stores are visible device-wide before its ticket; the last ticket raises the flag
     if constexpr (V == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // s_waitcnt + buffer_wbl2 sc1
-    else { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
-    if (tid == 0) {
+    if constexpr (V == 3) {
+        if (tid == 0) {
+            const unsigned x = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;
+            __hip_atomic_fetch_add(a.rows + (size_t)j * 256 + x * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if constexpr (V == 2) {
+        if (tid == 0) __hip_atomic_store(a.rows + (size_t)j * 256 + wg, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(a.tickets + j * PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == (unsigned)a.G - 1) {
             __hip_atomic_store(a.tickets + j * PAD, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -155,35 +215,34 @@ int main(int argc, char** argv) {
     struct Shape { int G; size_t wbytes; const char* what; };
     const Shape shapes[3] = {{120, 7372800, "c_fc / mlp.c_proj (1920x1920)"}, {192, 11059200, "wide c_attn (1920x2880)"},
                              {120, 0, "no weights"}};
-    struct Mode { int ns; bool wait; bool graph; const char* name; };
-    const Mode modes[6] = {{1, false, true, "graph 1 stream, no wait"}, {1, true, true, "graph 1 stream, wait"},
-                           {2, true, true, "graph 2 streams, wait"}, {3, true, true, "graph 3 streams, wait"},
-                           {2, true, false, "eager 2 streams, wait"}, {1, false, false, "eager 1 stream, no wait"}};
-    for (const Shape& sh : shapes) for (int v = 0; v < 2; ++v) for (const Mode& m : modes) {
-        Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G};
+    unsigned* rows; CK(hipMalloc(&rows, (size_t)K * 256 * 4));
+    // kind 0: one graph (all streams captured into it)   1: eager   2: one single-stream graph per stream, replayed side by side
+    struct Mode { int ns; bool wait; int kind; const char* name; };
+    const Mode modes[] = {{1, false, 0, "graph 1 stream, no wait"}, {1, true, 0, "graph 1 stream, wait"},
+                          {2, true, 1, "eager 2 streams, wait"},
+                          {2, true, 2, "2 graphs on 2 streams, wait"}, {3, true, 2, "3 graphs on 3 streams, wait"}};
+    for (const Shape& sh : shapes) for (int v = 1; v <= 3; ++v) for (const Mode& m : modes) {
+        Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G, rows};
         if (a.w_phase_u4 == 0) a.w_phase_u4 = (size_t)sh.G;      // one dummy vector per workgroup
         CK(hipMemcpy(act, h.data(), N_EL * 2, hipMemcpyHostToDevice));
         CK(hipMemset(flags, 0, K * PAD * 4)); CK(hipMemset(tickets, 0, K * PAD * 4)); CK(hipMemset(err, 0, 4)); CK(hipMemset(abortf, 0, 4));
+        CK(hipMemset(rows, 0, (size_t)K * 256 * 4));
         CK(hipDeviceSynchronize());
-        auto enqueue = [&](bool capture) -> int {
-            if (capture && m.ns > 1) {
+        auto launch_j = [&](int j, hipStream_t s) {
+            if (v == 1) { if (m.wait) launch<1, true>(a, j, s); else launch<1, false>(a, j, s); }
+            else if (v == 2) { if (m.wait) launch<2, true>(a, j, s); else launch<2, false>(a, j, s); }
+            else { if (m.wait) launch<3, true>(a, j, s); else launch<3, false>(a, j, s); }
+        };
+        float ms = 0.f;
+        if (m.kind == 0) {
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(st[0], hipStreamCaptureModeThreadLocal));
+            if (m.ns > 1) {
                 CK(hipEventRecord(fork, st[0]));
                 for (int k = 1; k < m.ns; ++k) CK(hipStreamWaitEvent(st[k], fork, 0));
             }
-            for (int j = 0; j < K; ++j) {
-                hipStream_t s = st[j % m.ns];
-                if (v == 0) { if (m.wait) launch<0, true>(a, j, s); else launch<0, false>(a, j, s); }
-                else { if (m.wait) launch<1, true>(a, j, s); else launch<1, false>(a, j, s); }
-            }
-            if (capture && m.ns > 1)
-                for (int k = 1; k < m.ns; ++k) { CK(hipEventRecord(join[k], st[k])); CK(hipStreamWaitEvent(st[0], join[k], 0)); }
-            return 0;
-        };
-        float ms = 0.f;
-        if (m.graph) {
-            hipGraph_t g; hipGraphExec_t ge;
-            CK(hipStreamBeginCapture(st[0], hipStreamCaptureModeThreadLocal));
-            if (enqueue(true)) return 1;
+            for (int j = 0; j < K; ++j) launch_j(j, st[j % m.ns]);
+            for (int k = 1; k < m.ns; ++k) { CK(hipEventRecord(join[k], st[k])); CK(hipStreamWaitEvent(st[0], join[k], 0)); }
             CK(hipStreamEndCapture(st[0], &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             CK(hipGraphLaunch(ge, st[0])); CK(hipStreamSynchronize(st[0]));          // warm-up
             CK(hipEventRecord(e0, st[0]));
@@ -191,22 +250,34 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e1, st[0])); CK(hipStreamSynchronize(st[0]));
             CK(hipEventElapsedTime(&ms, e0, e1));
             CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
-        } else {
-            // eager: with several streams the flags are the ONLY dependency between streams; a repetition starts when the
-            // previous one has finished on every stream (the host joins them)
-            if (enqueue(false)) return 1;
+        } else if (m.kind == 1) {
+            // eager: the flags are the ONLY dependency between streams
+            for (int j = 0; j < K; ++j) launch_j(j, st[j % m.ns]);
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, st[0]));
-            for (int r = 0; r < R; ++r) {
-                if (enqueue(false)) return 1;
-                for (int k = 1; k < m.ns; ++k) { CK(hipEventRecord(join[k], st[k])); CK(hipStreamWaitEvent(st[0], join[k], 0)); }
-            }
+            for (int r = 0; r < R; ++r) for (int j = 0; j < K; ++j) launch_j(j, st[j % m.ns]);
+            for (int k = 1; k < m.ns; ++k) { CK(hipEventRecord(join[k], st[k])); CK(hipStreamWaitEvent(st[0], join[k], 0)); }
             CK(hipEventRecord(e1, st[0])); CK(hipDeviceSynchronize());
             CK(hipEventElapsedTime(&ms, e0, e1));
+        } else {
+            hipGraph_t g[3]; hipGraphExec_t ge[3];
+            for (int k = 0; k < m.ns; ++k) {
+                CK(hipStreamBeginCapture(st[k], hipStreamCaptureModeThreadLocal));
+                for (int j = k; j < K; j += m.ns) launch_j(j, st[k]);
+                CK(hipStreamEndCapture(st[k], &g[k])); CK(hipGraphInstantiate(&ge[k], g[k], nullptr, nullptr, 0));
+            }
+            for (int k = 0; k < m.ns; ++k) CK(hipGraphLaunch(ge[k], st[k]));
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, st[0]));
+            for (int r = 0; r < R; ++r) for (int k = 0; k < m.ns; ++k) CK(hipGraphLaunch(ge[k], st[k]));
+            for (int k = 1; k < m.ns; ++k) { CK(hipEventRecord(join[k], st[k])); CK(hipStreamWaitEvent(st[0], join[k], 0)); }
+            CK(hipEventRecord(e1, st[0])); CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            for (int k = 0; k < m.ns; ++k) { CK(hipGraphExecDestroy(ge[k])); CK(hipGraphDestroy(g[k])); }
         }
         unsigned errs = 0, ab = 0;
         CK(hipMemcpy(&errs, err, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ab, abortf, 4, hipMemcpyDeviceToHost));
-        printf("%-30s G=%3d V%d %-26s %6.2f us/phase  (checksum errors %u, aborted %u)\n", sh.what, sh.G, v, m.name,
+        printf("%-30s G=%3d V%d %-28s %6.2f us/phase  (checksum errors %u, aborted %u)\n", sh.what, sh.G, v, m.name,
                ms * 1e3 / ((double)R * K), errs, ab);
         fflush(stdout);
         if (ab) { printf("aborted: a poll timed out -- stopping\n"); return 2; }
