@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
     if (row >= rows) return;
     const TI* xr = x + row * W;
     TO* yr = y + row * W;
-    if ((W & 7) == 0 && W <= 4096 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+    // 8-element vectors: 16 bytes for half, 32 for float -- the row bases must be aligned to the vector type used below
+    if ((W & 7) == 0 && W <= 4096 && ((uintptr_t)x % (sizeof(TI) * 8)) == 0 && ((uintptr_t)y % (sizeof(TO) * 8)) == 0 &&
         ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0) {
         typedef Vec8<TI> __attribute__((aligned(sizeof(TI) * 8))) VI;
         typedef Vec8<TO> __attribute__((aligned(sizeof(TO) * 8))) VO;
@@ -355,8 +356,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         const float inc = block_scan_incl(part, s_f, &total);
         const float u = philox_uniform(P.seed, (uint32_t)P.stream_id, (uint32_t)(P.sample_base + n), (uint32_t)(P.pos_base + t));
         const float target = u * total;
-        // owner = first thread whose inclusive mass exceeds the target (the prefix sums are monotone in thread order)
-        if (inc > target) atomicMin(&s_owner, tid);
+        // owner = first thread WITH MASS whose inclusive sum exceeds the target.  The shuffle-based prefix sums associate
+        // differently per thread, so they are monotone only up to rounding: a thread whose whole chunk was filtered out
+        // (part == 0) could otherwise win with nothing to pick from.
+        if (inc > target && part > 0.f) atomicMin(&s_owner, tid);
         __syncthreads();
         if (tid == s_owner) {
             float cum = inc - part;

@@ -1007,11 +1007,16 @@ static int launch_gemv_lnf(const GemvParams& p, int njt, int nf, int nw, hipStre
 
 template <typename T, int MT, int NW, bool LNS, bool FAST, int NV>
 static int launch_gemv_fast(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
-    static bool configured = false;
-    if (lds > 64 * 1024 && !configured) {
-        JB_HIP(hipFuncSetAttribute((const void*)gemv_kernel<T, MT, NW, LNS, FAST, NV>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
+    // the opt-in for > 64 KiB of dynamic LDS is a property of (function, device): remember it per device
+    static bool configured[64] = {};
+    int dev = 0;
+    if (lds > 64 * 1024) {
+        JB_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !configured[dev]) {
+            JB_HIP(hipFuncSetAttribute((const void*)gemv_kernel<T, MT, NW, LNS, FAST, NV>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dev >= 0 && dev < 64) configured[dev] = true;
+        }
     }
     gemv_kernel<T, MT, NW, LNS, FAST, NV><<<njt, NW * 64, lds, s>>>(p);
     return JB_OK;

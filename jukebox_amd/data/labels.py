@@ -82,7 +82,7 @@ class TextProcessor:
 class ArtistGenreProcessor:
     """data/artist_genre_processor.py:27-100: name -> id tables read from the reference's `ids/v{2,3}_{artist,genre}_ids.txt`
     (data files of the released checkpoints, not redistributed here): `ids_dir`, else $JUKEBOX_IDS_DIR, else an `ids/`
-    directory next to this file.  Looking a NAME up without tables raises -- the reference cannot run without them
+    directory next to this file, else $JUKEBOX_REFERENCE/jukebox/data/ids.  Looking a NAME up without tables raises -- the reference cannot run without them
     either, and silently conditioning every sample on id 0 would be wrong audio without a warning.  With tables, an unknown
     name maps to id 0 with the reference's message (artist_genre_processor.py:45-47,57-60).  Ids can always be given
     directly (Labeller.get_batch_labels_from_ids)."""
@@ -90,7 +90,8 @@ class ArtistGenreProcessor:
     def __init__(self, v3=False, ids_dir=None):
         self.v3 = v3
         here_ids = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ids")
-        ids_dir = ids_dir or os.environ.get("JUKEBOX_IDS_DIR") or (here_ids if os.path.isdir(here_ids) else None)
+        ref_ids = os.path.join(os.environ.get("JUKEBOX_REFERENCE", ""), "jukebox", "data", "ids")     # a checkout of the reference
+        ids_dir = ids_dir or os.environ.get("JUKEBOX_IDS_DIR") or next((d for d in (here_ids, ref_ids) if os.path.isdir(d)), None)
         self.ids_dir = ids_dir
         self.artist_ids, self.genre_ids = {}, {}
         ver = "v3" if v3 else "v2"
