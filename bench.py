@@ -71,7 +71,7 @@ from jukebox_amd import sample as S  # noqa: E402
 from jukebox_amd.hparams import Hyperparams, setup_hparams  # noqa: E402
 from jukebox_amd.make_models import MODELS, make_prior, make_vqvae  # noqa: E402
 from jukebox_amd.utils import dist_adapter as dist  # noqa: E402
-from jukebox_amd.utils.dist_utils import setup_dist_from_env  # noqa: E402
+from jukebox_amd.utils.dist_utils import setup_dist_from_env, shard_range  # noqa: E402
 
 _JSON_OUT = sys.stdout
 BUDGET_S = float(os.environ.get("JB_BENCH_BUDGET_S", "1400"))
@@ -283,9 +283,33 @@ def timed_steps(step_fn, requested, world, device, tail_reserve_s, sync):
     return done, dt, per_step, out
 
 
-def dist_info(world):
-    return dict(world_size=world, backend=(torch.distributed.get_backend() if world > 1 else "none"),
-                launcher="torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "single process")
+def dist_info(world, rank=0, device=None, per_step=None, n_samples_rank=None):
+    """What a reviewer of a multi-GPU line needs: backend and its version, and per rank the device it ran on, the samples it
+    held and its own step seconds (the line's `value` uses the MAX over ranks; the spread shows stragglers).  Collective:
+    every rank calls it."""
+    backend = torch.distributed.get_backend() if world > 1 else "none"
+    mine = dict(rank=rank, host=os.uname().nodename, device=str(device), n_samples=n_samples_rank,
+                step_seconds=[round(x, 3) for x in (per_step or [])])
+    if device is not None and device.type == "cuda":
+        pr = torch.cuda.get_device_properties(device)
+        mine.update(device_name=pr.name, device_uuid=str(getattr(pr, "uuid", "")), hbm_gb=round(pr.total_memory / 2 ** 30, 1),
+                    compute_units=pr.multi_processor_count)
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, mine)
+    info = dict(world_size=world, backend=backend,
+                launcher="torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "single process",
+                ranks=ranks)
+    if backend == "nccl":
+        try:
+            info["rccl_version"] = ".".join(map(str, torch.cuda.nccl.version()))
+        except Exception as e:   # noqa: BLE001 -- version probing must never cost a bench line
+            info["rccl_version"] = f"unknown ({e})"
+    means = [sum(r["step_seconds"]) / len(r["step_seconds"]) for r in ranks if r and r["step_seconds"]]
+    if means:
+        info["rank_step_seconds_min_max"] = [round(min(means), 3), round(max(means), 3)]
+    return info
 
 
 def dry_run(a, rank, world, device):
@@ -293,14 +317,17 @@ def dry_run(a, rank, world, device):
     n_samples = a.samples_per_gpu * world
     audio = n_samples * a.seconds
     done, dt, per_step, _ = timed_steps(lambda: time.sleep(0.02 * (1 + rank)), max(a.steps, 1), world, device, 0.0, lambda: None)
+    lo, hi = shard_range(n_samples, rank, world)          # the sampler's own partition of the samples (sample.py)
+    di = dist_info(world, rank, device, per_step, hi - lo)
     if rank != 0:
         return
     line = json.dumps(dict(metric=BASELINE_METRIC, value=round(audio * done / dt, 4), unit="audio_s/s", n_gpus=world, steps=done,
                           warmup=0, steps_requested=a.steps, warmup_requested=a.warmup, ms_per_step=round(dt / done * 1e3, 1),
                           higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f16",
                           data="dry-run (no GPU work; launcher / rank bootstrap / step loop only)",
-                          config=dict(workload="dry-run", samples_per_gpu=a.samples_per_gpu, parallelism=f"sample-sharded x{world}"),
-                          dist=dist_info(world), roofline=None, cpu_baseline=None))
+                          config=dict(workload="dry-run", samples_per_gpu=a.samples_per_gpu, n_samples=n_samples,
+                                      parallelism=f"sample-sharded x{world}"),
+                          dist=di, roofline=None, cpu_baseline=None))
     print(line, file=_JSON_OUT, flush=True)
 
 
@@ -361,6 +388,7 @@ def main():
     steps_done, dt, per_step, zs = timed_steps(one_step, max(a.steps, 1), world, device, 45.0 + cpu_leg_s,
                                                lambda: torch.cuda.synchronize())
     assert all(int(z.shape[1]) == sample_length // p.raw_to_tokens for z, p in zip(zs, priors))
+    di = dist_info(world, rank, device, per_step, a.samples_per_gpu)
 
     if rank != 0:
         return
@@ -407,7 +435,7 @@ def main():
                            wall_budget_s=BUDGET_S,
                            note="a step is the whole 3-level job; the run times as many full steps as fit the wall budget "
                                 "(steps <= steps_requested), after at most one short warm-up pass"),
-               dist=dist_info(world), roofline=roofline, breakdown=breakdown)
+               dist=di, roofline=roofline, breakdown=breakdown)
     if world == 1 and not a.no_cpu_baseline:
         cb = None
         if not tiny and budget_left() > 90:
@@ -416,6 +444,10 @@ def main():
             total_steps = sum(sample_length // p.raw_to_tokens for p in priors)
             cb = cpu_baseline_port(priors[0], a.samples_per_gpu, a.cpu_steps if not tiny else 4, total_steps, audio_seconds_per_step)
         out["cpu_baseline"] = cb
+        # BASELINE.md holds no published number for this metric, so vs_baseline stays null; the ratio to the reference timed
+        # on this box's host cores in this run (north_star: >= 30x) is reported under its own name
+        if cb and cb.get("value"):
+            out["vs_cpu_baseline"] = round(value / cb["value"], 1)
     print(json.dumps(out), file=_JSON_OUT, flush=True)
 
 

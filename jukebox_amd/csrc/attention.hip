@@ -166,12 +166,18 @@ __global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ld
 // together, multiplies the K tile with the query replicated in all 16 B columns -- so every lane ends up with the
 // scores of keys (l>>4)*4 + r and the softmax statistics need only two cross-lane steps -- and accumulates p*V on the
 // vector ALU from the coalesced value rows.  No per-key shuffle reduction (6 ds_bpermute per key in the generic kernel).
-template <int ND32>
+// RAGGED: d_head is any even number <= ND32 * 32 (5b_lyrics: 8 heads of 150 channels in 5 k-tiles).  The fragment that
+// straddles d_head (and those past it) is read from channel d_head - 8 on, for the query and the keys alike, so every
+// address stays inside the head; the query elements that an earlier fragment already covers, or that lie past d_head,
+// are zeroed, which removes their products whatever the key registers hold.  Heads start at odd multiples of 4 bytes,
+// so the 16-byte loads are only dword-aligned (global memory takes that).
+typedef f16x8 __attribute__((aligned(4))) f16x8_a4;
+template <int ND32, bool RAGGED>
 __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f16* __restrict__ q, int64_t ldq,
                                                                const f16* __restrict__ kc, const f16* __restrict__ vc, int cap,
                                                                f16* __restrict__ out, int64_t ldo, int n_head, int bc,
-                                                               const int* __restrict__ t_dev) {
-    constexpr int d = ND32 * 32;
+                                                               const int* __restrict__ t_dev, int d_head) {
+    const int d = RAGGED ? d_head : ND32 * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* s_ml = smem;                      // [nw][2]
@@ -185,9 +191,22 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     // the query does not depend on the position: request it before the position is waited for
     const f16* qrow = q + (int64_t)n * ldq + h * d;
     f16x8 qf[ND32];
+    int foff[ND32];                          // channel a fragment is read from (RAGGED: clamped into the head)
 #pragma unroll
-    for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+    for (int dt = 0; dt < ND32; ++dt) {
+        const int cb = dt * 32 + g * 8;
+        foff[dt] = RAGGED ? min(cb, d - 8) : cb;
+        qf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(qrow + foff[dt]) : ld_frag<f16>(qrow + cb);
+    }
     jb_issue_fence();
+    if constexpr (RAGGED) {
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) {
+            const int cb = dt * 32 + g * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[dt][e] = (cb < d && foff[dt] + e >= cb) ? qf[dt][e] : (f16)0;
+        }
+    }
     const int t = *t_dev;
     const KeySet ks = decode_key_set(func, t, bc, cap);
     f16* o = out + (int64_t)n * ldo + h * d;
@@ -212,15 +231,17 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
         const int kbase_i = tt * 16;
         // ---- requests: K fragments of key (kbase_i + c), value rows kbase_i + 0..15 ----
         const int ki = min(kbase_i + c, ks.count - 1);
-        const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * S + g * 8;
+        const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * S;
         f16x8 kf[ND32];
 #pragma unroll
-        for (int dt = 0; dt < ND32; ++dt) kf[dt] = ld_frag<f16>(kr + dt * 32);
+        for (int dt = 0; dt < ND32; ++dt)
+            kf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(kr + foff[dt]) : ld_frag<f16>(kr + dt * 32 + g * 8);
         f16x8 vv[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int vi = min(kbase_i + k, ks.count - 1);
-            vv[k] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0);
+            const f16* vr = vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0;
+            vv[k] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(vr) : ld_frag<f16>(vr);
         }
         jb_issue_fence_before_use(qf[0]);        // K fragments AND value rows are in flight before the QK^T chain starts
         // ---- scores of keys g*4 + r (identical in all 16 columns) ----
@@ -264,9 +285,9 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
         }
     }
     if (lane == 0) { s_ml[2 * wave] = m_w; s_ml[2 * wave + 1] = l_w; }
-    if (lane * 8 < d) {
+    if (lane * 8 < d) {      // RAGGED: the last writing lane starts at d - 8 and re-writes channels its neighbour holds too (same values)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_o[wave * d + lane * 8 + e] = of[e];
+        for (int e = 0; e < 8; ++e) s_o[wave * d + c0 + e] = of[e];
     }
     __syncthreads();
     float m = -INFINITY;
@@ -638,13 +659,24 @@ extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t l
     (void)max_len;
     dim3 grid(n_batch, n_head);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == JB_F16 && g_dec_mfma && d_head % 32 != 0 && d_head % 2 == 0 && d_head > 128 && d_head < 160 && ldq % 2 == 0 &&
+        ldo % 2 == 0) {
+        // ragged head size in 5 k-tiles (5b_lyrics: 150 channels per head)
+        const int nwm = 8;
+        size_t ldsm = (size_t)(2 * nwm + 16 * nwm + nwm * d_head) * sizeof(float);
+        attn_decode_mfma_kernel<5, true><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+                                                                    (const f16*)vcache, cache_cap, (f16*)out, ldo, n_head,
+                                                                    block_ctx, t_dev, d_head);
+        JB_CHECK_LAUNCH();
+        return JB_OK;
+    }
     if (dtype == JB_F16 && g_dec_mfma && d_head % 32 == 0 && d_head <= 512 && ldq % 8 == 0 && (n_head * d_head) % 8 == 0) {
         const int nwm = 8;
         size_t ldsm = (size_t)(2 * nwm + 16 * nwm + nwm * d_head) * sizeof(float);
 #define JB_LAUNCH_DECM(ND)                                                                                      \
-    attn_decode_mfma_kernel<ND><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,    \
+    attn_decode_mfma_kernel<ND, false><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache, \
                                                            (const f16*)vcache, cache_cap, (f16*)out, ldo, n_head, \
-                                                           block_ctx, t_dev)
+                                                           block_ctx, t_dev, d_head)
         switch (d_head / 32) {
             case 1: JB_LAUNCH_DECM(1); break;
             case 2: JB_LAUNCH_DECM(2); break;

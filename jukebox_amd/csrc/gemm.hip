@@ -979,10 +979,18 @@ static int launch_gemv_merge(const GemvParams& p, int njt, hipStream_t s) {
 static int lnf_shape(int dtype, int K, int J, int n_rows, int* nw_out) {
     const int KT = dtype == JB_F16 ? 32 : 16, E = dtype == JB_F16 ? 8 : 4;
     if (K <= 0 || J < 4 || K % KT != 0 || J % 4 != 0 || K < E || n_rows < 1 || n_rows > 32) return 0;
-    const int nkt = K / KT, nw = nkt >= 32 ? 8 : 4;
-    const int per_wave = (nkt + nw - 1) / nw;
+    const int nkt = K / KT;
+    int nw = nkt >= 32 ? 8 : 4;
+    int per_wave = (nkt + nw - 1) / nw;
+    if (per_wave > 16) {         // long rows (5b_lyrics: K = 4800 = 150 k-tiles): 16 waves, <= 10 fragments each (128 VGPRs)
+        nw = 16;
+        per_wave = (nkt + nw - 1) / nw;
+        *nw_out = nw;
+        if (n_rows > 16) return 0;
+        return per_wave <= 8 ? 8 : (per_wave <= 10 ? 10 : 0);
+    }
     *nw_out = nw;
-    return per_wave <= 8 ? 8 : (per_wave <= 16 ? 16 : 0);
+    return per_wave <= 8 ? 8 : 16;
 }
 
 extern "C" int jb_gemv_ln_fold_supported(int dtype, int K, int J, int n_rows) {
@@ -994,6 +1002,7 @@ template <typename T, int MT, int NW>
 static int launch_gemv_lnf_nf(const GemvParams& p, int njt, int nf, hipStream_t s) {
     const size_t lds = (size_t)NW * MT * 64 * sizeof(f32x4) + (size_t)2 * NW * MT * 16 * sizeof(float);
     if (nf == 8) gemv_lnf_kernel<T, MT, NW, 8><<<njt, NW * 64, lds, s>>>(p);
+    else if constexpr (NW == 16) gemv_lnf_kernel<T, MT, NW, 10><<<njt, NW * 64, lds, s>>>(p);
     else gemv_lnf_kernel<T, MT, NW, 16><<<njt, NW * 64, lds, s>>>(p);
     return JB_OK;
 }
@@ -1001,6 +1010,10 @@ static int launch_gemv_lnf_nf(const GemvParams& p, int njt, int nf, hipStream_t 
 template <typename T>
 static int launch_gemv_lnf(const GemvParams& p, int njt, int nf, int nw, hipStream_t s) {
     const int mt = (p.n_rows + 15) / 16;
+    if (nw == 16) {
+        if (mt != 1) { jb_set_error("jb_gemv: folded LayerNorm over > 16 k-tiles per wave takes n_rows <= 16"); return JB_ERR_UNSUPPORTED; }
+        return launch_gemv_lnf_nf<T, 1, 16>(p, njt, nf, s);
+    }
     if (nw == 8) return mt == 1 ? launch_gemv_lnf_nf<T, 1, 8>(p, njt, nf, s) : launch_gemv_lnf_nf<T, 2, 8>(p, njt, nf, s);
     return mt == 1 ? launch_gemv_lnf_nf<T, 1, 4>(p, njt, nf, s) : launch_gemv_lnf_nf<T, 2, 4>(p, njt, nf, s);
 }

@@ -46,6 +46,19 @@ def test_gpus_2_spawns_its_own_ranks():
     assert out["config"]["parallelism"] == "sample-sharded x2"
 
 
+def test_gpus_8_shards_config4_as_16_samples_per_rank():
+    """BASELINE config 4 on one node: --gpus 8 -> 128 samples, 16 per rank (the sampler's shard_range), every rank reports its
+    device, its samples and its own step seconds; the line carries the spread between the fastest and the slowest rank."""
+    out = _run(["--gpus", "8", "--dry-run", "--steps", "2"], timeout=600)
+    assert out["n_gpus"] == 8 and out["config"]["n_samples"] == 128 and out["config"]["samples_per_gpu"] == 16
+    ranks = out["dist"]["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and all(r["n_samples"] == 16 for r in ranks)
+    assert all(len(r["step_seconds"]) == 2 for r in ranks)
+    lo, hi = out["dist"]["rank_step_seconds_min_max"]
+    assert lo < hi and hi >= 0.15                # rank 7 sleeps 8 x 20 ms per step
+    assert out["dist"]["backend"] == "gloo" and out["dist"]["launcher"] == "torch.distributed.run"
+
+
 def test_outer_launcher_is_respected():
     """Launched the driver's way (torch.distributed.run outside): no second level of spawning."""
     e = dict(os.environ)

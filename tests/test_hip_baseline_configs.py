@@ -178,6 +178,26 @@ def _full_size_case(tag, W, depth, heads, attn_order, blocks, seq, bins, prime_l
             worst = max(worst, float(np.abs(got - ref[0, :got.shape[0]]).max() / max(1.0, np.abs(ref).max())))
     assert worst < 3e-4, (tag, "prefill k/v", worst)
     del tr
+    # ... and of the OTHER samples: the same inputs shifted by `roll` batch slots must reproduce every cache row bit for bit
+    # in the shifted slot (a sample's rows do not depend on where in the batch it sits), so slot 0's check carries over
+    if N > 1:
+        roll = 5 % N or 1
+        nk = min(t0, eng.kcaches[depth - 1].shape[1])          # rows the prefill wrote (later rows belong to the decode steps)
+        last_k, last_v = eng.kcaches[depth - 1][:, :nk].clone(), eng.vcaches[depth - 1][:, :nk].clone()
+        nm = min(t0, eng.kcaches[depth // 2].shape[1])
+        mid_k = eng.kcaches[depth // 2][:, :nm].clone()
+        eng.set_cond(None if x_cond is None else torch.roll(x_cond, roll, 0), None if yc is None else torch.roll(yc, roll, 0))
+        eng.tokens[:, :t0] = torch.roll(tokens, roll, 0)
+        eng.prefill(0, t0)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.kcaches[depth - 1][:, :nk], torch.roll(last_k, roll, 0)), (tag, "prefill depends on the batch slot (k)")
+        assert torch.equal(eng.vcaches[depth - 1][:, :nk], torch.roll(last_v, roll, 0)), (tag, "prefill depends on the batch slot (v)")
+        assert torch.equal(eng.kcaches[depth // 2][:, :nm], torch.roll(mid_k, roll, 0)), (tag, "prefill depends on the batch slot (mid k)")
+        del last_k, last_v, mid_k
+        eng.set_cond(x_cond, yc)
+        eng.tokens[:, :t0] = tokens
+        eng.prefill(0, t0)                       # back to the original placement for the decode check below
+        torch.cuda.synchronize()
 
     # (b) decode of all samples from the validated caches
     st = TorchDecodeStack(tr_sd, "", W, seq, heads, depth, attn_order=attn_order, blocks=blocks, prime_len=prime_len, n_batch=N)
@@ -223,6 +243,157 @@ def test_config3_1b_lyrics_top_prior_full_depth():
         pytest.skip("no GPU")
     _full_size_case("1b_lyrics_top", W=2048, depth=72, heads=2, attn_order=12, blocks=64, seq=6528, bins=2127, prime_len=384,
                     y_cond=True, t0=384, n_steps=64)
+
+
+def test_config4_upsampler_geometry_full_size_late_positions():
+    """BASELINE config 4's dominant model: the level-0 / level-1 upsampler transformer (hparams.py:68-101 -- width 1920,
+    depth 72, ONE head of 480 channels, attn_order 2, blocks 128 -> block_ctx 64, n_ctx 8192, x- and y-conditioned), fp32:
+    teacher-forced prefill of 8064 positions, then 64 greedy decode steps in the last block rows (transpose pattern: 127
+    keys at stride 64; prev_block; block).  N = 4: the torch port's caches are 2.3 GB per sample at this size."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    h = setup_hparams("upsampler_level_0", {})
+    assert (h.prior_width, h.prior_depth, h.heads, h.attn_order, h.blocks, h.n_ctx) == (1920, 72, 1, 2, 128, 8192)
+    _full_size_case("upsampler", W=1920, depth=72, heads=1, attn_order=2, blocks=128, seq=8192, bins=2048, prime_len=None,
+                    y_cond=True, t0=8064, n_steps=64, N=4)
+
+
+def test_config5_5b_geometry_fast_paths():
+    """BASELINE config 5's transformer geometry (prior_5b_lyrics, hparams.py:127-153: width 4800, 8 heads of 150 channels,
+    n_ctx 8192, blocks 128, 3 samples per GPU) at depth 12 of its self-attention patterns:
+      * fp32 engine vs the torch port of the oracle: prefill of 1100 positions + 64 greedy steps (_full_size_case);
+      * the fp16 engine on its fast paths -- LayerNorm folded into c_attn / c_fc over 150 k-tiles (16-wave kernel), QK^T on
+        MFMA with the 150-channel heads padded to 5 k-tiles -- teacher-forced on the fp32 engine's stream for 64 steps:
+        logits as close to fp32 as the reference-ordered fp16 engine's (explicit LayerNorm, vector-ALU attention)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from jukebox_amd import _lib as L
+    from jukebox_amd.engine import PriorEngine
+    h = setup_hparams("prior_5b_lyrics", {})
+    assert (h.prior_width, h.heads, h.blocks, h.n_ctx) == (4800, 8, 128, 8192)
+    W, depth, heads, seq, bins, N, t0, n_steps = 4800, 12, 8, 8192, 2048, 3, 1100, 64
+    _full_size_case("5b", W=W, depth=depth, heads=heads, attn_order=2, blocks=128, seq=seq, bins=bins, prime_len=None,
+                    y_cond=True, t0=t0, n_steps=n_steps, N=N, seed=5)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    sd = _random_prior_state(gen, W, depth, bins, seq, heads, True)
+    x_cond = torch.randn(N, seq, W, device="cuda", generator=gen) * 0.05
+    yc = torch.randn(N, 1, W, device="cuda", generator=gen) * 0.05
+    prefix = torch.randint(0, bins, (N, t0), device="cuda", generator=gen)
+
+    def make(fp16, fold_ln):
+        e = PriorEngine(sd, "", n_batch=N, seq_len=seq, bins=bins, width=W, depth=depth, heads=heads, attn_order=2, blocks=128,
+                        y_cond=True, fp16=fp16, fold_ln=fold_ln, want_preds=True, chunk_cap=512)
+        e.set_cond(x_cond, yc)
+        e.set_sampling(temp=1.0, top_k=1)
+        e.tokens[:, :t0] = prefix
+        e.prefill(0, t0)
+        return e
+
+    e32 = make(False, False)
+    e32.decode(t0, n_steps)
+    torch.cuda.synchronize()
+    z32, p32 = e32.tokens[:, :t0 + n_steps].clone(), e32.preds[:, t0:t0 + n_steps].cpu().numpy()
+    e32.close()
+    stats = {}
+    for name, fold_ln, mfma in (("fast", True, True), ("reference-ordered", False, False)):
+        L.lib().jb_tune_attn_decode(0, 4 if mfma else -1)              # kb < 0: the generic vector-ALU decode attention
+        e16 = make(True, fold_ln)
+        assert bool(e16.layers_c[0].w_attn_f) == fold_ln and bool(e16.layers_c[0].w_fc_f) == fold_ln
+        for i in range(n_steps):
+            e16.tokens[:, :t0 + i] = z32[:, :t0 + i]
+            e16.decode(t0 + i, 1)
+        torch.cuda.synchronize()
+        p16 = e16.preds[:, t0:t0 + n_steps].cpu().numpy()
+        err = np.abs(p16 - p32)
+        stats[name] = (float(err.max()), float(err.mean()), float((p16.argmax(-1) == p32.argmax(-1)).mean()))
+        e16.close()
+    L.lib().jb_tune_attn_decode(0, 4)
+    print("5b geometry, fp16 vs fp32 (max |dlogit|, mean |dlogit|, top-1 agreement), logit std %.3f:" % p32.std(), stats)
+    (mx_f, mean_f, ag_f), (mx_r, mean_r, ag_r) = stats["fast"], stats["reference-ordered"]
+    assert mx_f <= 1.5 * mx_r + 1e-3 and mean_f <= 1.25 * mean_r + 1e-4 and ag_f >= ag_r - 0.02, stats
+
+
+def test_config4_upsampler_conditioner_full_size():
+    """Conditioner of upsampler_level_0 at its real dimensions (conditioners.py:8-48 with hparams.py:88-101: 2048 upper-level
+    codes -> 8192 x 1920, conv width 1024, two Resnet1D stacks of depth 16 with dilations 3^(d mod 8) = 1 ... 2187 -- the
+    largest dilation exceeds the 2048-position input -- then x2 transposed convolutions and the LayerNorm), one sample,
+    against the numpy oracle on the same seeded weights: <= 1e-4 relative."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from jukebox_amd.prior.conditioners import Conditioner
+    from oracle.prior import Conditioner as OracleConditioner
+    h = setup_hparams("upsampler_level_0", {})
+    assert (h.cond_width, h.cond_depth, h.cond_dilation_growth_rate, h.cond_dilation_cycle, h.prior_width) == (1024, 16, 3, 8, 1920)
+    kw = dict(width=h.cond_width, depth=h.cond_depth, m_conv=h.cond_m_conv, dilation_growth_rate=h.cond_dilation_growth_rate,
+              dilation_cycle=h.cond_dilation_cycle)
+    torch.manual_seed(5)
+    with torch.device("cuda"):
+        cond = Conditioner(input_shape=(2048,), bins=2048, down_t=2, stride_t=2, out_width=h.prior_width, init_scale=h.init_scale,
+                           zero_out=False, res_scale=False, **kw)
+        cond.ln.weight.data.normal_(1.0, 0.1)
+        cond.ln.bias.data.normal_(0.0, 0.1)
+        z = torch.randint(0, 2048, (1, 2048))
+    cond.eval()
+    with torch.no_grad():
+        got = cond(z).cpu().numpy()
+    assert got.shape == (1, 8192, 1920)
+    sd = {k: v.detach().cpu().numpy() for k, v in cond.state_dict().items()}
+    ora = OracleConditioner(sd, "", 2, 2, res_scale=False, checkpoint_res=0, **kw)
+    ref = ora(z.cpu().numpy())
+    err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+    print("conditioner at upsampler_level_0 size: max rel err %.3g (|ref| max %.3g)" % (err, np.abs(ref).max()))
+    assert err < 1e-4
+
+
+def test_config2_small_prior_whole_window_greedy_vs_reference_golden():
+    """BASELINE config 2 token for token: tests/golden/small_prior_full.npz holds the UNMODIFIED reference's greedy stream
+    of all 8192 tokens x 16 samples on small_prior (tests/golden/gen_small_prior_full.py, fp32, seeded weights from
+    tests/golden/seeded_weights.py) together with its top-1 / top-2 logit gap at every position.  The fp32 engine must
+    reproduce the stream; a different token is tolerated only where the reference itself was within 1e-3 of its runner-up
+    AND the engine picked exactly that runner-up -- the engine is then re-synchronised on the reference's token and goes on
+    (its caches up to that position were computed from identical inputs)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    path = os.path.join(gdir, "small_prior_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/small_prior_full.npz has not been generated")
+    sys.path.insert(0, gdir)
+    from seeded_weights import prior_state
+    from jukebox_amd.engine import PriorEngine
+    g = np.load(path)
+    z_ref, gap, runner = g["z"].astype(np.int64), g["gap"], g["runner_up"].astype(np.int64)
+    N, T = z_ref.shape
+    assert (N, T) == (16, 8192)
+    sd = {k: torch.from_numpy(v).cuda() for k, v in prior_state(int(g["seed"]), 1024, 48, 1024, 8192).items()}
+    eng = PriorEngine(sd, "", n_batch=N, seq_len=T, bins=1024, width=1024, depth=48, heads=1, attn_order=2, blocks=64,
+                      y_cond=False, fp16=False, want_preds=True)
+    eng.set_cond(None, None)
+    eng.set_sampling(temp=1.0, top_k=1)
+    z_dev = torch.from_numpy(z_ref).cuda()
+    t0, flips = 0, []
+    while t0 < T:
+        eng.decode(t0, T - t0)
+        torch.cuda.synchronize()
+        diff = (eng.tokens[:, t0:] != z_dev[:, t0:]).any(0)
+        if not bool(diff.any()):
+            break
+        t = t0 + int(torch.nonzero(diff)[0, 0])
+        got = eng.tokens[:, t].cpu().numpy()
+        for n in np.nonzero(got != z_ref[:, t])[0]:
+            assert gap[n, t] < 1e-3 and got[n] == runner[n, t], ("token differs outside a near-tie of the reference", n, t,
+                                                                 float(gap[n, t]), int(got[n]), int(z_ref[n, t]), int(runner[n, t]))
+            flips.append((int(n), int(t), float(gap[n, t])))
+        eng.tokens[:, :t + 1] = z_dev[:, :t + 1]              # re-synchronise on the reference's stream
+        t0 = t + 1
+        assert len(flips) <= 64, "too many near-tie flips to be rounding"
+    p0 = eng.preds[:, :4].cpu().numpy()
+    assert np.abs(p0 - g["first_logits"]).max() < 2e-4 * max(1.0, np.abs(g["first_logits"]).max())
+    print("small_prior whole window: %d of %d tokens identical, near-tie flips (sample, position, reference gap): %s; "
+          "near-ties in the reference stream: %d" % (N * T - len(flips), N * T, flips, int((gap < 1e-3).sum())))
+    eng.close()
 
 
 def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):

@@ -163,7 +163,25 @@ def test_seeded_model_vs_oracle(PE, fp16, wide_v):
         diverged = (z != z_ref).any(0)
         n_ok = int(np.argmax(diverged)) if diverged.any() else n_total
         assert n_ok > n_prime
-        assert np.abs(preds[:, :n_ok] - p_ref[:, :n_ok]).max() < 5e-2 * max(1.0, np.abs(p_ref).max())
+        bar = 5e-2 * max(1.0, np.abs(p_ref).max())
+        assert np.abs(preds[:, :n_ok] - p_ref[:, :n_ok]).max() < bar
+        # Teacher-forced on the ORACLE's fp16 stream: every decode step of every sample is compared with the oracle's
+        # fp16 emulation (the free run above stops counting at the first sample that takes another near-tie).
+        z_dev = torch.from_numpy(z_ref).cuda()
+        for i in range(n_prime, n_total):
+            eng.tokens[:, :i] = z_dev[:, :i]
+            eng.decode(i, 1)
+        torch.cuda.synchronize()
+        p_tf = eng.preds.cpu().numpy()[:, n_prime:n_total]
+        err = np.abs(p_tf - p_ref[:, n_prime:])
+        agree = float((p_tf.argmax(-1) == p_ref[:, n_prime:].argmax(-1)).mean())
+        print("fp16 %s engine, teacher-forced on the oracle's stream: max |dlogit| %.4f (bar %.4f), mean %.5f, top-1 agreement %.4f "
+              "over %d decode steps x %d samples" % ("wide-value" if wide_v else "five-launch", err.max(), bar, err.mean(), agree,
+                                                     n_total - n_prime, N))
+        # measured: max 0.06, mean 0.010 on logits that reach |215| (both engines); the free-run bar above is 10.8
+        assert err.max() < max(0.15, 1e-3 * np.abs(p_ref).max()), "fp16 logits drifted from the oracle's fp16 emulation"
+        assert err.mean() < 0.03
+        assert agree >= 0.99
 
 
 def test_sampling_is_reproducible_and_seeded(PE):

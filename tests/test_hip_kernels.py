@@ -186,7 +186,8 @@ def test_gemv_ln_epilogues(H, name, dt, tol, rows, K, J):
 
 
 @pytest.mark.parametrize("name,dt,tol", DT)
-@pytest.mark.parametrize("rows,K,J", [(16, 1920, 1440), (16, 256, 96), (32, 2048, 64), (3, 512, 132), (20, 1024, 20), (1, 32, 4)])
+@pytest.mark.parametrize("rows,K,J", [(16, 1920, 1440), (16, 256, 96), (32, 2048, 64), (3, 512, 132), (20, 1024, 20), (1, 32, 4),
+                                      (3, 4800, 272), (16, 4800, 64), (3, 5120, 32)])
 def test_gemv_ln_folded(H, name, dt, tol, rows, K, J):
     """Folded LayerNorm (jb_gemv_args.ln_fold_c1): rstd*(x.W' - mean*c1) + b' against LayerNorm -> Conv1D done the
     reference's way (ops.py:14-24,97-101), on rows with a mean several times their spread."""
@@ -199,7 +200,10 @@ def test_gemv_ln_folded(H, name, dt, tol, rows, K, J):
     b = rng.standard_normal(J).astype(np.float32)
     g = (1 + 0.2 * rng.standard_normal(K)).astype(np.float32)
     be = (0.2 * rng.standard_normal(K)).astype(np.float32)
-    assert H.ln_fold_supported(dt, K, J, rows)
+    if K >= 4800 and not f16:
+        assert not H.ln_fold_supported(dt, K, J, rows)       # 300+ fp32 k-tiles: the fp32 engine normalises explicitly
+        return
+    assert H.ln_fold_supported(dt, K, J, rows)               # K = 4800 (5b_lyrics): 150 k-tiles on 16 waves
     f = H.FoldedLN(dev(W), dev(b), dev(g), dev(be), dt)
     got = H.gemv(dev(x, dt), None, ln_fold=f, act=L.ACT_QUICK_GELU).float().cpu().numpy()
     x64 = x.astype(np.float64)
@@ -220,6 +224,8 @@ def test_gemv_ln_folded_rejects_unsupported_shapes(H):
     from jukebox_amd import _lib as L
     assert not H.ln_fold_supported(torch.float16, 100, 64, 16)        # K not a whole number of k-tiles
     assert not H.ln_fold_supported(torch.float16, 8192, 64, 16)       # fragments of a row do not fit in registers
+    assert H.ln_fold_supported(torch.float16, 4800, 3600, 3)          # 5b_lyrics: 150 k-tiles on 16 waves
+    assert not H.ln_fold_supported(torch.float16, 4800, 3600, 17)     # ... which take one 16-row tile
     assert not H.ln_fold_supported(torch.float32, 256, 64, 48)        # more than 32 rows
     x = torch.zeros((16, 128), dtype=torch.float16, device="cuda")
     f = H.FoldedLN(torch.zeros((128, 64), device="cuda"), torch.zeros(64, device="cuda"), torch.ones(128, device="cuda"),
@@ -322,6 +328,23 @@ def test_attn_decode(H, name, dt, tol, func, H_, d):
         got = H.attn_decode(func, dev(q[:, 0], dt), kc, vc, H_, bc, t_dev, T).float().cpu().numpy()
         want = _np_attention(func, q, K, V, H_, bc, prime_r, [t], fp16)[:, 0]
         assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (func, t)
+
+
+@pytest.mark.parametrize("func", [0, 1, 2, 3])
+def test_attn_decode_5b_head_size(H, func):
+    """fp16 MFMA decode attention at 5b_lyrics' head size: 8 heads of 150 channels (hparams.py:127-153) -- not a multiple of
+    the 32-wide k-tile, heads start at odd multiples of 4 bytes; block_ctx 64."""
+    rng = np.random.default_rng(50 + func)
+    N, T, bc, H_, d = 3, 400, 64, 8, 150
+    S = H_ * d
+    K, V = h16(rng.standard_normal((N, T, S)).astype(np.float32)), h16(rng.standard_normal((N, T, S)).astype(np.float32))
+    kc, vc = dev(K, torch.float16), dev(V, torch.float16)
+    for t in (0, 1, 63, 64, 70, 200, 399):
+        q = h16(rng.standard_normal((N, 1, S)).astype(np.float32))
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        got = H.attn_decode(func, dev(q[:, 0], torch.float16), kc, vc, H_, bc, t_dev, T).float().cpu().numpy()
+        want = _np_attention(func, q, K, V, H_, bc, None, [t], True)[:, 0]
+        assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max()), (func, t)
 
 
 @pytest.mark.parametrize("func", [1, 2, 3])
