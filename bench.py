@@ -452,4 +452,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        # leave the process group in order: a rank that simply exits while its peers are still inside a collective makes
+        # the backend's worker threads abort ("terminate called without an active exception")
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            try:
+                torch.distributed.barrier()
+                torch.distributed.destroy_process_group()
+            except Exception:   # noqa: BLE001 -- shutting down
+                pass

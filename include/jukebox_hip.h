@@ -299,6 +299,10 @@ typedef struct jb_engine_cfg {
     /* optional recording of one layer/head's attention probabilities during prefill (alignment): */
     int rec_layer, rec_head, rec_keys;                     /* rec_layer < 0: off */
     float* rec_out; int64_t rec_n_stride;                  /* [n][seq_len][rec_keys] */
+    /* row pitch of `att` in elements (0 = n_state).  With n_state not a whole number of k-tiles (5b_lyrics: 1200 = 37.5 x 32)
+     * a pitch rounded up to the k-tile, the padding zeroed once by the caller, lets the decode step's attn.c_proj run its
+     * branch-free path (the packed weight image is zero-padded to whole k-tiles anyway). */
+    int att_ld;
 } jb_engine_cfg;
 
 /* Transformer.forward(sample=True) + the token loop of ConditionalAutoregressive2D.sample/primed_sample

@@ -61,7 +61,8 @@ class EngineCfg(C.Structure):
                 ("chunk_cap", i32), ("c_xa", vp), ("c_xb", vp), ("c_h", vp), ("c_q", vp), ("c_att", vp),
                 ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
                 ("preds", vp), ("preds_n_stride", i64), ("sample_params", vp),
-                ("rec_layer", i32), ("rec_head", i32), ("rec_keys", i32), ("rec_out", vp), ("rec_n_stride", i64)]
+                ("rec_layer", i32), ("rec_head", i32), ("rec_keys", i32), ("rec_out", vp), ("rec_n_stride", i64),
+                ("att_ld", i32)]
 
 
 _SIGS = {

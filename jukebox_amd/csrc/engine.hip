@@ -66,6 +66,7 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
     JB_REQUIRE((cfg->att_parts == nullptr) == (cfg->att_ml == nullptr), "att_parts and att_ml come together");
     JB_REQUIRE(cfg->bins <= 0 || !cfg->x_out_packed || cfg->ticket, "ticket counter missing");
     JB_REQUIRE(cfg->width % 4 == 0, "width must be a multiple of 4");
+    JB_REQUIRE(cfg->att_ld == 0 || cfg->att_ld >= cfg->n_state, "att_ld must be 0 or >= n_state");
     JB_REQUIRE(!cfg->rec_out || (cfg->rec_layer >= 0 && cfg->rec_layer < cfg->n_layers && cfg->rec_keys > 0 &&
                                  cfg->rec_head >= 0 && cfg->rec_head < cfg->n_head), "bad attention recording request");
     JbEngine* e = new JbEngine();
@@ -171,6 +172,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
         // attention, then attn.c_proj + residual: x_b = x_a + a
         const int parts = layer_split_parts(c, L);
         g = {};
+        const int att_ld = c.att_ld ? c.att_ld : S;         // padded pitch (zeros): K covers the padding, the image has zero rows there
         g.dtype = c.dtype; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
         g.out = c.x_b; g.ldo = W; g.res = c.x_a; g.ldr = W;
         if (layer_wide(c, L)) {
@@ -181,9 +183,11 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
                                         c.block_ctx, c.t_dev, layer_max_keys(c, L), parts, s));
             g.x_parts = c.att_parts; g.x_ml = c.att_ml; g.n_parts = parts; g.n_head = H; g.d_head = d;
         } else {
-            JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, S, N, H, d,
+            JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, att_ld, N, H, d,
                                   c.block_ctx, c.t_dev, c.seq_len, s));
-            g.x = c.att;
+            g.x = c.att; g.ldx = att_ld;
+            const int KT = c.dtype == JB_F16 ? 32 : 16;
+            if (att_ld % KT == 0 && att_ld - S < KT) g.K = att_ld;
         }
         if (!layer_wide(c, L)) JB_TRY(jb_gemv(&g, s));
         // ln_1 + mlp.c_fc + quick_gelu

@@ -486,7 +486,7 @@ template <typename T, int MT, int NW, bool LNS, bool FAST, int NV>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     using V = typename Frag<T>::vec;
     constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
-    constexpr int WB = MT <= 2 ? 8 : 4;   // weight (and activation) fragments in flight per wave
+    constexpr int WB = NW == 16 ? 10 : (MT <= 2 ? 8 : 4);   // weight (and activation) fragments in flight per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     f32x4* s_acc = reinterpret_cast<f32x4*>(s_dyn);                 // [NW][MT][64]
     T* s_x = reinterpret_cast<T*>(s_dyn + NW * MT * 64 * sizeof(f32x4));   // [16*MT][pitch] (LNS only)
@@ -1063,8 +1063,13 @@ template <typename T>
 static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
     constexpr int E = Frag<T>::E;
     const int mt = (p.n_rows + 15) / 16;
-    // 8 waves when every wave still gets >= 4 k-tiles (more bytes in flight per CU), else 4
+    // 8 waves when every wave still gets >= 4 k-tiles (more bytes in flight per CU), else 4; long rows (5b_lyrics:
+    // K = 4800, 150 k-tiles) 16 waves of <= 10 k-tiles, all of them requested up front
     int nw = p.nkt >= 32 ? 8 : 4;
+    if (!ln && mt == 1 && p.fast && p.nkt > 128 && p.nkt <= 160) {
+        p.lds_pitch = 0;
+        return launch_gemv_fast<T, 1, 16, false, true, 0>(p, njt, (size_t)16 * 64 * sizeof(f32x4), s);
+    }
     if (ln && nw == 8) {   // keep the staged rows + partial tiles within the 160 KiB of LDS
         size_t pit = ((p.K + E - 1) / E) * E + E;
         size_t need = (size_t)8 * mt * 64 * sizeof(f32x4) + (size_t)p.n_rows * pit * sizeof(T) + 2 * pit * sizeof(float);

@@ -197,7 +197,10 @@ class PriorEngine:
 
         e = lambda *shape, dtype=dt: torch.zeros(shape, dtype=dtype, device=dev)
         Cc = self.chunk_cap
-        self.buf = dict(x_a=e(N, W), x_b=e(N, W), q=e(N, S), att=e(N, S), mlp=e(N, M),
+        # attention output rows padded to whole k-tiles (zeros): attn.c_proj's branch-free path for n_state = 1200 (5b_lyrics)
+        kt = 32 if self.dtype == torch.float16 else 16
+        self.att_ld = (S + kt - 1) // kt * kt
+        self.buf = dict(x_a=e(N, W), x_b=e(N, W), q=e(N, S), att=e(N, self.att_ld), mlp=e(N, M),
                         xf=e(N, W, dtype=torch.float32), logits=e(N, max(self.bins, 1), dtype=torch.float32),
                         c_xa=e(N * Cc, W), c_xb=e(N * Cc, W), c_h=e(N * Cc, W), c_q=e(N * Cc, S), c_att=e(N * Cc, S),
                         c_mlp=e(N * Cc, M))
@@ -272,6 +275,7 @@ class PriorEngine:
         if self.att_parts is not None:
             c.att_parts, c.att_ml = self.att_parts.data_ptr(), self.att_ml.data_ptr()
         c.ticket = self.ticket.data_ptr()
+        c.att_ld = self.att_ld
         c.chunk_cap = self.chunk_cap
         c.c_xf = b["c_xf"].data_ptr() if "c_xf" in b else None
         c.tokens, c.tok_stride, c.t_dev = self.tokens.data_ptr(), self.tokens.stride(0), self.t_dev.data_ptr()

@@ -37,7 +37,8 @@ def test_binding_loads_and_validates_arguments(built):
     assert rc == -1 and b"null" in lib.jb_last_error()
     # host-side shape query of the folded-LayerNorm projection (no launch)
     assert lib.jb_gemv_ln_fold_supported(L.F16, 1920, 1440, 16) == 1 and lib.jb_gemv_ln_fold_supported(L.F16, 2048, 2048, 32) == 1
-    assert lib.jb_gemv_ln_fold_supported(L.F16, 4800, 4800, 3) == 0       # 5b_lyrics width: rows normalised in-kernel instead
+    assert lib.jb_gemv_ln_fold_supported(L.F16, 4800, 4800, 3) == 1       # 5b_lyrics width: 150 k-tiles on the 16-wave kernel
+    assert lib.jb_gemv_ln_fold_supported(L.F16, 4800, 4800, 17) == 0 and lib.jb_gemv_ln_fold_supported(L.F32, 4800, 4800, 3) == 0
     assert lib.jb_gemv_ln_fold_supported(L.F16, 100, 64, 16) == 0 and lib.jb_gemv_ln_fold_supported(L.F32, 256, 64, 33) == 0
     a = L.GemvArgs()
     assert lib.jb_gemv(C.byref(a), None) == -1

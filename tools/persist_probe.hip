@@ -55,6 +55,8 @@ struct Args {
     unsigned* progress;      // chain + prefetcher: epoch * 512 + phase of the newest chain kernel that has started
     unsigned* xcd_rank;      // [8] prefetcher workgroups registered per XCD (reset by the chain's first kernel)
     unsigned* census;        // [8][2]: chain workgroups of phase 0 seen on XCD x, of which block % 8 == x
+    int pf_next;             // chain: after its own MFMAs every workgroup touches the weights of the projection 1 (D -> A) or 2
+                             // (A -> C, C -> D) kernels ahead, same tile index (same XCD); the loads are drained before it leaves
     int hot;                 // chain: every layer reads layer 0's weights / k / v' rows (upper bound of what ANY prefetching can give)
     int w_nt;                // chain: weight loads non-temporal (today) or default policy (so that prefetched lines are kept)
 };
@@ -472,8 +474,25 @@ __global__ __launch_bounds__(THREADS, 4) void chain_kernel(Args a, int p) {
     Task t = gemv_task(a, kind, l, task, epoch - 1);
     if (a.hot) t.w = gemv_task(a, kind, 0, task, epoch - 1).w;
     if (wave != 0) { if (a.w_nt) gemv_compute<2, false>(s, t, wf, wave, lane); else gemv_compute<3, false>(s, t, wf, wave, lane); }
+    f16x8 pf[NF];
+    const bool do_pf = a.pf_next && wave != 0 && (kind != 3 || l + 1 < NL);
+    if (do_pf) {
+        // A(l) -> C(l) (tiles 0..119 only), C(l) -> D(l), D(l) -> A(l+1) (+ tile jt + 120 for the first 60 workgroups)
+        const int nk = kind == 0 ? 2 : (kind == 2 ? 3 : 0), nl = kind == 3 ? l + 1 : l;
+        if (!(kind == 0 && task >= TC)) {
+            const Task tn = gemv_task(a, nk, nl, task, epoch - 1);
+            load_w_wave<0>(pf, tn.w, wave, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) pf[i] = wf[i];
+        }
+    }
     __syncthreads();
     if (wave == 0) gemv_epilogue<2>(a, s, t, epoch, lane);
+    if (do_pf) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) asm volatile("" :: "v"(pf[i]));
+    }
 }
 
 // Side-stream prefetcher for the launch chain: one wave per workgroup, 256 workgroups.  While the chain executes phase p it
@@ -578,6 +597,7 @@ int main(int argc, char** argv) {
     const Mode modes[] = {{1, 0, 1, "chain: one kernel per phase, hipGraph (today's structure)"},
                           {1, 0, 0, "chain, default-policy weight loads (no prefetcher)"},
                           {3, 0, 0, "chain, HOT weights and k / v' rows (every layer reads layer 0's), default policy"},
+                          {4, 0, 0, "chain, each kernel touches the NEXT projection's weights after its MFMAs, default policy"},
                           {2, 1, 0, "chain + L2 prefetcher, lead 1, default-policy loads"},
                           {2, 2, 0, "chain + L2 prefetcher, lead 2, default-policy loads"},
                           {2, 3, 0, "chain + L2 prefetcher, lead 3, default-policy loads"},
@@ -591,7 +611,7 @@ int main(int argc, char** argv) {
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         a.progress = m.kind == 2 ? progress : nullptr; a.census = m.kind == 2 ? census : nullptr;
-        a.xcd_rank = xcd_rank; a.w_nt = m.kind == 0 ? 1 : m.pf; a.hot = m.kind == 3;
+        a.xcd_rank = xcd_rank; a.w_nt = m.kind == 0 ? 1 : m.pf; a.hot = m.kind == 3; a.pf_next = m.kind == 4;
         if (m.kind >= 1) {
             for (int p = 0; p < PH; ++p) {
                 const int k = p & 3, n = k == 0 ? TA : (k == 1 ? TB : TC);
