@@ -303,6 +303,11 @@ typedef struct jb_engine_cfg {
      * a pitch rounded up to the k-tile, the padding zeroed once by the caller, lets the decode step's attn.c_proj run its
      * branch-free path (the packed weight image is zero-padded to whole k-tiles anyway). */
     int att_ld;
+    /* optional: (10 * launches_per_step + 1) * 32 zero-initialised words for software-pipelined launches
+     * (jb_engine_pipeline): per launch slot a completion count (32 words apart) and nine ticket counters; the last 32-word
+     * group starts with an error word (slot + 1 of a launch whose wait for its producer timed out; 0 = none; never reset by
+     * the library). */
+    unsigned* pipe_words;
 } jb_engine_cfg;
 
 /* Transformer.forward(sample=True) + the token loop of ConditionalAutoregressive2D.sample/primed_sample
@@ -319,6 +324,15 @@ int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
  * (wide-value layers have no attn.c_proj launch: 4 per layer; jb_engine_launches_per_step reports the count).
  * use_graph != 0 captures one step into a hipGraph on first use and replays it. */
 int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
+/* Software-pipelined launches of the decode step (graph replay only): the launches of a step alternate between the
+ * caller's stream and an internal stream of the same priority, so launch j+1 is dispatched -- and requests its weight
+ * stream, whose addresses never depend on activations -- while launch j still runs; what it reads from launch j it reads
+ * after polling j's completion word, through write-through stores / L1-bypassing loads.  Same kernels' arithmetic in the
+ * same order: tokens and logits are bit-identical to the plain chain.  enable != 0 returns JB_ERR_UNSUPPORTED unless every
+ * launch of this engine's step has a pipelined form (cfg.pipe_words given, fp16, <= 16 samples, every layer a wide-value
+ * layer of one 480-channel head, width and n_mlp of 33..64 k-tiles: the 1b upsamplers).  Replaces the same reference code
+ * as jb_engine_decode. */
+int jb_engine_pipeline(void* handle, int enable);
 /* Measurement aid: n_steps passes over all layers launching only the LayerNorm-fused projections (attn.c_attn and
  * mlp.c_fc -- the dominant kernel of the decode step) with their real arguments, back to back on `stream`, bracketed
  * by one HIP event pair.  Synchronises.  out[0] = average microseconds per launch, out[1] = launches timed,

@@ -62,7 +62,7 @@ class EngineCfg(C.Structure):
                 ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
                 ("preds", vp), ("preds_n_stride", i64), ("sample_params", vp),
                 ("rec_layer", i32), ("rec_head", i32), ("rec_keys", i32), ("rec_out", vp), ("rec_n_stride", i64),
-                ("att_ld", i32)]
+                ("att_ld", i32), ("pipe_words", vp)]
 
 
 _SIGS = {
@@ -106,6 +106,7 @@ _SIGS = {
     "jb_engine_decode": (i32, [vp, i32, i32, i32, vp]),
     "jb_engine_probe_projection": (i32, [vp, i32, i32, vp, C.POINTER(C.c_double)]),
     "jb_engine_launches_per_step": (i32, [vp]),
+    "jb_engine_pipeline": (i32, [vp, i32]),
     "jb_engine_step_bytes": (C.c_double, [vp, i32]),
 }
 EXPORTS = tuple(_SIGS)

@@ -308,12 +308,15 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
 // weight stream) is gone.  Grid (sample, slice): slice sl owns output channels [sl*d, (sl+1)*d) and reads the K rows
 // (d channels) plus that slice of the v' rows, the same bytes per workgroup as the kernel above; the W/d slices of a
 // sample recompute identical probabilities.
-template <int ND32>
+// PIPE: one launch of a software-pipelined chain (common.h, JbPipe): the query, the position and every cache row are read
+// write-through after the producer launch (c_attn, which appends this position's k / v' rows) has completed; the residual
+// rows are two launches old and the bias is constant: both are requested before the wait.
+template <int ND32, bool PIPE = false>
 __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f16* __restrict__ q, int64_t ldq,
                                                                const f16* __restrict__ kc, const f16* __restrict__ vw, int cap,
                                                                const f16* __restrict__ res, int64_t ldr,
                                                                const float* __restrict__ bias, f16* __restrict__ out,
-                                                               int64_t ldo, int W, int bc, const int* __restrict__ t_dev) {
+                                                               int64_t ldo, int W, int bc, const int* __restrict__ t_dev, JbPipe pipe) {
     constexpr int d = ND32 * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
@@ -325,48 +328,38 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     const int g = lane >> 4, c = lane & 15;
     const int n = blockIdx.x, sl = blockIdx.y;
     const f16* qrow = q + (int64_t)n * ldq;
+    unsigned pipe_own = 0;
+    if constexpr (PIPE) pipe_own = jb_pipe_own(pipe);
     f16x8 qf[ND32];
+    if constexpr (!PIPE) {
 #pragma unroll
-    for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+        for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+    }
     // epilogue operands of this thread's output channel (blockDim.x >= d): requested with the query, used at the end
     const int och = sl * d + min((int)threadIdx.x, d - 1);
     const float bias_e = bias[och];
     const f16 res_e = res[(int64_t)n * ldr + och];
     jb_issue_fence();
+    // PIPE: the position was written by the previous step's last launch, which this stream has already seen complete
+    // (an attention launch is never the first of a step): the key set is known before the wait.
     const int t = *t_dev;
     const KeySet ks = decode_key_set(func, t, bc, cap);
     f16* o = out + (int64_t)n * ldo;
-    if (ks.count == 0) {      // zero rows -> attention output 0 -> c_proj gives its bias
-        if (threadIdx.x < d) o[och] = (f16)jb_round<f16>((float)res_e + jb_round<f16>(jb_round<f16>(bias_e)));
-        return;
-    }
     const float scale = 1.0f / sqrtf(sqrtf((float)d));
     const float scale2 = scale * scale;
-    const f16* kbase = kc + ((int64_t)n * cap) * d;
-    const f16* vbase = vw + ((int64_t)n * cap) * W + sl * d;
+    const int64_t krow0 = (int64_t)n * cap;                      // first cache row of this sample
+    const f16* kbase = kc + krow0 * d;
+    const f16* vbase = vw + krow0 * W + sl * d;
     const int c0 = min(lane * 8, d - 8);
-
+    const int ntiles = (ks.count + 15) >> 4;
+    // One pass over 16-key tiles: requests (K fragments of key kbase_i + c, the 16 value rows), QK^T on MFMA, online softmax
+    // of the tile, p.V on the vector ALU.
     float m_w = -INFINITY, l_w = 0.f;
     float of[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) of[e] = 0.f;
     float* pw = s_pw + 16 * wave;
-
-    const int ntiles = (ks.count + 15) >> 4;
-    for (int tt = wave; tt < ntiles; tt += nw) {
-        const int kbase_i = tt * 16;
-        const int ki = min(kbase_i + c, ks.count - 1);
-        const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * d + g * 8;
-        f16x8 kf[ND32];
-#pragma unroll
-        for (int dt = 0; dt < ND32; ++dt) kf[dt] = ld_frag<f16>(kr + dt * 32);
-        f16x8 vv[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int vi = min(kbase_i + k, ks.count - 1);
-            vv[k] = ld_frag<f16>(vbase + (int64_t)(ks.start + vi * ks.stride) * W + c0);
-        }
-        jb_issue_fence_before_use(qf[0]);
+    auto tile_math = [&](const f16x8 (&kf)[ND32], const f16x8 (&vv)[16], int kbase_i) {
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < ND32; ++dt) sc = jb_mfma(kf[dt], qf[dt], sc);
@@ -403,6 +396,71 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
 #pragma unroll
             for (int e = 0; e < 8; ++e) of[e] += pr * (float)vv[k][e];
         }
+    };
+
+    if constexpr (PIPE) {
+        // One tile per wave (key sets of <= 16 * waves keys; jb_engine_pipeline checks it).  The cache rows of EARLIER
+        // positions were written in earlier steps: requested BEFORE the wait with plain loads (this launch's L1 is cold,
+        // L2 is coherent for write-through stores).  Position t itself is being written by the producer launch: where it is
+        // a key (the last one), its row is re-read write-through after the wait, straight into the same registers.
+        f16x8 kf[ND32], vv[16];
+        const int kbase_i = wave * 16;
+        const int ki = min(kbase_i + c, max(ks.count - 1, 0));
+        if (wave < ntiles) {
+            const int64_t kpos = ks.start + ki * ks.stride;
+#pragma unroll
+            for (int dt = 0; dt < ND32; ++dt) kf[dt] = ld_frag<f16>(kbase + kpos * d + g * 8 + dt * 32);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int64_t vpos = ks.start + min(kbase_i + k, ks.count - 1) * ks.stride;
+                vv[k] = ld_frag<f16>(vbase + vpos * W + c0);
+            }
+        }
+        jb_issue_fence();
+        jb_pipe_wait(pipe, pipe_own);
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) qf[dt] = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + dt * 32 + g * 8);
+        if (ks.count == 0) {      // zero rows -> attention output 0 -> c_proj gives its bias
+            if (threadIdx.x < d) jb_st_sc1(out, (int64_t)n * ldo + och, (f16)jb_round<f16>((float)res_e + jb_round<f16>(jb_round<f16>(bias_e))));
+            jb_pipe_publish(pipe, pipe_own);
+            return;
+        }
+        if (wave < ntiles) {
+            const int last_pos = ks.start + (ks.count - 1) * ks.stride;      // == t when the query's own position is a key
+            if (last_pos == t && wave == ntiles - 1) {                       // wave-uniform
+                const int64_t trow = krow0 + t;
+                if (ki == ks.count - 1) {
+#pragma unroll
+                    for (int dt = 0; dt < ND32; ++dt) kf[dt] = jb_ld_frag_sc1<f16>(kc, trow * d + g * 8 + dt * 32);
+                }
+                const f16x8 fv = jb_ld_frag_sc1<f16>(vw, trow * W + sl * d + c0);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) vv[k] = (kbase_i + k >= ks.count - 1) ? fv : vv[k];
+            }
+            jb_issue_fence_before_use(qf[0]);
+            tile_math(kf, vv, kbase_i);
+        }
+    } else {
+        if (ks.count == 0) {      // zero rows -> attention output 0 -> c_proj gives its bias
+            if (threadIdx.x < d) o[och] = (f16)jb_round<f16>((float)res_e + jb_round<f16>(jb_round<f16>(bias_e)));
+            return;
+        }
+        for (int tt = wave; tt < ntiles; tt += nw) {
+            const int kbase_i = tt * 16;
+            const int ki = min(kbase_i + c, ks.count - 1);
+            const int64_t kpos = ks.start + ki * ks.stride;
+            f16x8 kf[ND32];
+#pragma unroll
+            for (int dt = 0; dt < ND32; ++dt) kf[dt] = ld_frag<f16>(kbase + kpos * d + g * 8 + dt * 32);
+            f16x8 vv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int64_t vpos = ks.start + min(kbase_i + k, ks.count - 1) * ks.stride;
+                vv[k] = ld_frag<f16>(vbase + vpos * W + c0);
+            }
+            jb_issue_fence_before_use(qf[0]);
+            tile_math(kf, vv, kbase_i);
+        }
     }
     if (lane == 0) { s_ml[2 * wave] = m_w; s_ml[2 * wave + 1] = l_w; }
     if (lane * 8 < d) {
@@ -415,6 +473,22 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     float lsum = 0.f;
     for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] * expf(s_ml[2 * w] - m);
     const float inv = 1.0f / lsum;
+    if constexpr (PIPE) {
+        // every thread takes a channel (those past d a duplicate), four neighbours leave as one 8-byte write-through store
+        const int ch = min((int)threadIdx.x, d - 1);
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += s_o[w * d + ch] * expf(s_ml[2 * w] - m);
+        const float cp = jb_round<f16>(a * inv + jb_round<f16>(bias_e));
+        const float v1 = jb_round<f16>((float)res_e + cp);
+        const float a1 = __shfl_down(v1, 1, 64), a2 = __shfl_down(v1, 2, 64), a3 = __shfl_down(v1, 3, 64);
+        if ((int)threadIdx.x < d && (threadIdx.x & 3) == 0) {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            const f16x4 o4 = {(f16)v1, (f16)a1, (f16)a2, (f16)a3};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), jb_rsrc(out), (int)(((int64_t)n * ldo + och) * 2), 0, 16);
+        }
+        jb_pipe_publish(pipe, pipe_own);
+        return;
+    }
     if (threadIdx.x < d) {
         float a = 0.f;
         for (int w = 0; w < nw; ++w) a += s_o[w * d + threadIdx.x] * expf(s_ml[2 * w] - m);
@@ -617,6 +691,13 @@ extern "C" int jb_attn_decode_wide(int attn_func, const void* q, int64_t ldq, co
                                    int cache_cap, const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo,
                                    int n_batch, int d_head, int width, int block_ctx, const int* t_dev, int max_len,
                                    void* stream) {
+    return jb_attn_decode_wide_impl(attn_func, q, ldq, kcache, vcache_w, cache_cap, res, ldr, bias, x_out, ldo, n_batch, d_head,
+                                    width, block_ctx, t_dev, max_len, nullptr, stream);
+}
+
+int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache_w, int cache_cap,
+                             const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
+                             int width, int block_ctx, const int* t_dev, int max_len, const JbPipe* pipe, void* stream) {
     JB_REQUIRE(q && kcache && vcache_w && res && bias && x_out && t_dev, "null pointer");
     JB_REQUIRE(n_batch > 0 && max_len > 0, "bad dims");
     JB_REQUIRE(jb_attn_decode_wide_supported(attn_func, d_head, width, block_ctx, max_len) && ldq % 8 == 0,
@@ -625,10 +706,20 @@ extern "C" int jb_attn_decode_wide(int attn_func, const void* q, int64_t ldq, co
     const size_t lds = (size_t)(2 * nw + 16 * nw + nw * d_head) * sizeof(float);
     dim3 grid(n_batch, width / d_head);
     hipStream_t s = (hipStream_t)stream;
+    const JbPipe nopipe{nullptr, nullptr, nullptr, -1, -1, nullptr};
+    if (pipe) {
+        JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30),
+                   "a pipelined launch of the wide-value attention takes d_head = 480 and caches below 2 GiB");
+        attn_decode_wide_kernel<15, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+                                                                   (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, bias,
+                                                                   (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe);
+        JB_CHECK_LAUNCH();
+        return JB_OK;
+    }
 #define JB_LAUNCH_DECW(ND)                                                                                          \
     attn_decode_wide_kernel<ND><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,          \
                                                          (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, bias, \
-                                                         (f16*)x_out, ldo, width, block_ctx, t_dev)
+                                                         (f16*)x_out, ldo, width, block_ctx, t_dev, nopipe)
     switch (d_head / 32) {
         case 1: JB_LAUNCH_DECW(1); break;
         case 2: JB_LAUNCH_DECW(2); break;

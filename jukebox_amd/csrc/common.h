@@ -151,3 +151,101 @@ __device__ __forceinline__ float jb_wave_max(float v) {
 __device__ __forceinline__ float jb_load_any(const void* p, int dtype, int64_t i) {
     return dtype == JB_F16 ? (float)((const f16*)p)[i] : ((const float*)p)[i];
 }
+
+// ---- software-pipelined launches (engine.hip) ------------------------------------------------
+// The kernels of a decode step alternate between two streams, so launch j+1 is dispatched -- and requests its weights --
+// while launch j still runs; the dependency itself is a completion word per launch slot:
+//   runs[slot]    how often the slot has completed since the words were last zeroed (written by its last workgroup),
+//   tickets[slot] arrivals of the current run: 8 shard counters (workgroup index mod 8; 120-180 arrivals on ONE word
+//                 serialise at ~12 ns each) + one counter of finished shards, each in its own 128-byte line.
+// A launch reads its own count i, then thread 0 of every workgroup polls the producer slot until it has completed i + 1
+// times (slot 0 follows the last slot of the previous step: i times), and only then reads what the producer wrote -- with
+// sc1 loads (L1 bypass; the producer stored write-through and drained before it took its ticket), no cache-wide
+// invalidate or write-back anywhere.  Data of launches j-2 and older is ordinary: the same stream ordered it.
+// Polls are bounded (2 s of the 100 MHz clock): a timeout records slot + 1 in *err and goes on.
+struct JbPipe {
+    unsigned* runs; unsigned* tickets; unsigned* err;
+    int slot, prev;                                  // slot < 0: plain launch chain (every helper below compiles away)
+    long long* dbg;                                  // optional [slot][4] stamps of the 100 MHz clock (JB_PIPE_DEBUG): poll
+                                                     // entered, producer seen, own completion published
+};
+constexpr int JB_PIPE_PAD = 32;                      // words between two slots' completion words (128 bytes)
+constexpr int JB_PIPE_TICKET_WORDS = 9 * JB_PIPE_PAD;   // per slot: 8 shard tickets + the shard count
+// words the caller provides: completion counts, tickets, one error word
+__host__ __device__ constexpr size_t jb_pipe_words(int n_slots) { return (size_t)n_slots * (JB_PIPE_PAD + JB_PIPE_TICKET_WORDS) + JB_PIPE_PAD; }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t jb_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ unsigned jb_ld_word(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void jb_st_word(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16-byte operand fragment / scalar through the write-through path: `base` must be wave-uniform (a kernel argument), the
+// element offset may differ per lane (< 2^30 elements).
+template <typename T> __device__ __forceinline__ typename Frag<T>::vec jb_ld_frag_sc1(const T* base, int64_t el) {
+    return __builtin_bit_cast(typename Frag<T>::vec, __builtin_amdgcn_raw_buffer_load_b128(jb_rsrc(base), (int)(el * (int64_t)sizeof(T)), 0, 16));
+}
+__device__ __forceinline__ float jb_ld_sc1(const float* base, int64_t el) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(jb_rsrc(base), (int)(el * 4), 0, 16));
+}
+__device__ __forceinline__ f16 jb_ld_sc1(const f16* base, int64_t el) {
+    return __builtin_bit_cast(f16, __builtin_amdgcn_raw_buffer_load_b16(jb_rsrc(base), (int)(el * 2), 0, 16));
+}
+__device__ __forceinline__ void jb_st_sc1(float* base, int64_t el, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), jb_rsrc(base), (int)(el * 4), 0, 16);
+}
+__device__ __forceinline__ void jb_st_sc1(f16* base, int64_t el, f16 v) {
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), jb_rsrc(base), (int)(el * 2), 0, 16);
+}
+
+// Own completion count: every thread asks for it next to its first requests (a broadcast load).
+__device__ __forceinline__ unsigned jb_pipe_own(const JbPipe& P) { return jb_ld_word(P.runs + P.slot * JB_PIPE_PAD); }
+// Wait for the producer launch; ends in a workgroup barrier.
+__device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own) {
+    if (threadIdx.x == 0) {
+        const unsigned need = P.slot == 0 ? own : own + 1;
+        const unsigned* w = P.runs + P.prev * JB_PIPE_PAD;
+        const bool stamp = P.dbg && blockIdx.x == 0 && blockIdx.y == 0;
+        if (stamp) P.dbg[P.slot * 4] = wall_clock64();
+        if (jb_ld_word(w) < need) {
+            const long long t0 = wall_clock64();
+            unsigned spins = 0;
+            while (jb_ld_word(w) < need) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 255u) == 0 && wall_clock64() - t0 > 200000000ll) { jb_st_word(P.err, (unsigned)P.slot + 1u); break; }
+            }
+        }
+        if (stamp) P.dbg[P.slot * 4 + 1] = wall_clock64();
+    }
+    __syncthreads();
+}
+// After the last store of every thread: drain the write-through stores, count the workgroup in, the last one publishes.
+__device__ __forceinline__ void jb_pipe_publish(const JbPipe& P, unsigned own) {
+    if (P.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) P.dbg[P.slot * 4 + 3] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* tk = P.tickets + (size_t)P.slot * JB_PIPE_TICKET_WORDS;
+        const unsigned n_wg = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), shard = b & 7u;
+        const unsigned members = (n_wg - shard + 7u) >> 3, n_shards = n_wg < 8u ? n_wg : 8u;
+        if (__hip_atomic_fetch_add(tk + shard * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            jb_st_word(tk + shard * JB_PIPE_PAD, 0u);
+            if (__hip_atomic_fetch_add(tk + 8 * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_shards - 1) {
+                jb_st_word(tk + 8 * JB_PIPE_PAD, 0u);
+                jb_st_word(P.runs + P.slot * JB_PIPE_PAD, own + 1);
+                if (P.dbg) P.dbg[P.slot * 4 + 2] = wall_clock64();
+            }
+        }
+    }
+}
+
+// library-internal forms of the decode step's launches that take a pipeline slot (pipe == NULL: the exported behaviour)
+int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream);
+int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache_w, int cache_cap,
+                             const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
+                             int width, int block_ctx, const int* t_dev, int max_len, const JbPipe* pipe, void* stream);
+int jb_sample_step_impl(const float* logits, int n_batch, int bins, const jb_sample_params* params, int64_t* tokens,
+                        int64_t tok_stride, int* t_dev, float* preds, int64_t preds_n_stride, int x_dtype, void* x_next,
+                        const float* x_emb, const float* pos_emb, const float* x_cond, int64_t xc_n_stride, int64_t xc_t_stride,
+                        int width, int seq_len, unsigned* ticket, const JbPipe* pipe, void* stream);

@@ -255,23 +255,30 @@ struct SampleTail {
 };
 
 // One workgroup (4 waves) per sample row: temperature, top-k / nucleus filter, categorical draw.
+// PIPE: the last launch of a software-pipelined decode step (common.h, JbPipe): the logits are the producer launch's (read
+// write-through after the wait); the next position's embedding and the counter are read by the FIRST launch of the next
+// step, which is already waiting on the other stream: stored write-through, published at the end.
+template <bool PIPE>
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int bins, int n2,
                                                      const jb_sample_params* __restrict__ params,
                                                      int64_t* __restrict__ tokens, int64_t tok_stride,
                                                      const int* __restrict__ t_dev, float* __restrict__ preds,
-                                                     int64_t preds_n_stride, SampleTail tail) {
+                                                     int64_t preds_n_stride, SampleTail tail, JbPipe pipe) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_x = sm;              // [bins] filtered, temperature-scaled logits
     __shared__ float s_f[8];
     __shared__ int s_i[8];
     __shared__ int s_pick, s_owner;
     const int n = blockIdx.x, tid = threadIdx.x;
-    const int t = *t_dev;
+    unsigned pipe_own = 0;
+    if constexpr (PIPE) pipe_own = jb_pipe_own(pipe);
+    const int t = *t_dev;                                    // written by this launch slot's previous run: same stream
     const jb_sample_params P = *params;
+    if constexpr (PIPE) jb_pipe_wait(pipe, pipe_own);
     const float* row = logits + (int64_t)n * bins;
     float* pr = preds ? preds + (int64_t)n * preds_n_stride + (int64_t)t * bins : nullptr;
     for (int i = tid; i < bins; i += 256) {
-        const float v = row[i];
+        const float v = PIPE ? jb_ld_sc1(logits, (int64_t)n * bins + i) : row[i];
         if (pr) pr[i] = v;
         s_x[i] = v / P.temp;
     }
@@ -394,7 +401,12 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
             if (cd) v += *reinterpret_cast<const f32x4*>(cd + i);
             if (tail.x_dtype == JB_F16) {
                 const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                *reinterpret_cast<f16x4*>((f16*)tail.x_next + (int64_t)n * W + i) = o;
+                if constexpr (PIPE) {
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), jb_rsrc(tail.x_next), (int)(((int64_t)n * W + i) * 2), 0, 16);
+                } else {
+                    *reinterpret_cast<f16x4*>((f16*)tail.x_next + (int64_t)n * W + i) = o;
+                }
             } else {
                 *reinterpret_cast<f32x4*>((float*)tail.x_next + (int64_t)n * W + i) = v;
             }
@@ -404,19 +416,27 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         const unsigned prev = atomicAdd(tail.ticket, 1u);
         if (prev == gridDim.x - 1) {                           // last workgroup: everyone has read *t_dev
             *tail.ticket = 0u;
-            *tail.t_dev_w = t + 1;
+            if constexpr (PIPE) jb_st_word(reinterpret_cast<unsigned*>(tail.t_dev_w), (unsigned)(t + 1)); else *tail.t_dev_w = t + 1;
         }
     }
+    if constexpr (PIPE) jb_pipe_publish(pipe, pipe_own);
 }
 
 static int launch_sample(const float* logits, int n_batch, int bins, const jb_sample_params* params, int64_t* tokens,
                          int64_t tok_stride, const int* t_dev, float* preds, int64_t preds_n_stride, const SampleTail& tail,
-                         hipStream_t stream) {
+                         hipStream_t stream, const JbPipe* pipe = nullptr) {
     int n2 = 1;
     while (n2 < bins) n2 <<= 1;
     if (n2 > 4096) JB_UNSUPPORTED("vocabulary too large for the LDS sampler (bins <= 4096)");
     const size_t lds = (size_t)n2 * sizeof(float);
-    sample_kernel<<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds, preds_n_stride, tail);
+    if (pipe) {
+        if (tail.x_dtype != JB_F16 || !tail.x_next) JB_UNSUPPORTED("a pipelined sampler launch takes the fp16 decode step's tail");
+        sample_kernel<true><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds, preds_n_stride,
+                                                            tail, *pipe);
+    } else {
+        sample_kernel<false><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds,
+                                                             preds_n_stride, tail, JbPipe{nullptr, nullptr, nullptr, -1, -1, nullptr});
+    }
     JB_CHECK_LAUNCH();
     return JB_OK;
 }
@@ -434,6 +454,14 @@ extern "C" int jb_sample_step(const float* logits, int n_batch, int bins, const 
                               int64_t tok_stride, int* t_dev, float* preds, int64_t preds_n_stride, int x_dtype, void* x_next,
                               const float* x_emb, const float* pos_emb, const float* x_cond, int64_t xc_n_stride,
                               int64_t xc_t_stride, int width, int seq_len, unsigned* ticket, void* stream) {
+    return jb_sample_step_impl(logits, n_batch, bins, params, tokens, tok_stride, t_dev, preds, preds_n_stride, x_dtype, x_next, x_emb,
+                               pos_emb, x_cond, xc_n_stride, xc_t_stride, width, seq_len, ticket, nullptr, stream);
+}
+
+int jb_sample_step_impl(const float* logits, int n_batch, int bins, const jb_sample_params* params, int64_t* tokens,
+                        int64_t tok_stride, int* t_dev, float* preds, int64_t preds_n_stride, int x_dtype, void* x_next,
+                        const float* x_emb, const float* pos_emb, const float* x_cond, int64_t xc_n_stride, int64_t xc_t_stride,
+                        int width, int seq_len, unsigned* ticket, const JbPipe* pipe, void* stream) {
     JB_REQUIRE(logits && params && tokens && t_dev && x_next && x_emb && pos_emb && ticket, "null pointer");
     JB_REQUIRE(n_batch > 0 && bins > 0 && width > 0 && width % 4 == 0 && seq_len > 0, "bad dims (width must be a multiple of 4)");
     JB_REQUIRE(x_dtype == JB_F16 || x_dtype == JB_F32, "bad dtype");
@@ -441,7 +469,7 @@ extern "C" int jb_sample_step(const float* logits, int n_batch, int bins, const 
     tail.x_next = x_next; tail.x_dtype = x_dtype; tail.x_emb = x_emb; tail.pos_emb = pos_emb; tail.x_cond = x_cond;
     tail.xc_n = xc_n_stride; tail.xc_t = xc_t_stride; tail.W = width; tail.seq_len = seq_len;
     tail.t_dev_w = t_dev; tail.ticket = ticket;
-    return launch_sample(logits, n_batch, bins, params, tokens, tok_stride, t_dev, preds, preds_n_stride, tail, (hipStream_t)stream);
+    return launch_sample(logits, n_batch, bins, params, tokens, tok_stride, t_dev, preds, preds_n_stride, tail, (hipStream_t)stream, pipe);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -21,6 +21,13 @@ struct JbEngine {
     // wide-value layers append k and v' (not v) in the decode step: until the next window's prefill starts again at
     // position 0, the v rows of decoded positions are stale and a prefill that would attend to them is refused
     bool v_rows_stale = false;
+    // software-pipelined launches (jb_engine_pipeline): the launches of a step alternate between the caller's stream and a
+    // second stream of the same priority, as two single-stream graphs that are replayed side by side
+    bool pipelined = false;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipGraph_t pgraph[2] = {nullptr, nullptr};
+    hipGraphExec_t pexec[2] = {nullptr, nullptr};
 };
 
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
@@ -81,6 +88,13 @@ extern "C" int jb_engine_destroy(void* handle) {
     JbEngine* e = (JbEngine*)handle;
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
+    for (int k = 0; k < 2; ++k) {
+        if (e->pexec[k]) (void)hipGraphExecDestroy(e->pexec[k]);
+        if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
     if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
     delete e;
     return JB_OK;
@@ -160,15 +174,30 @@ static int enqueue_embed(JbEngine* e, int t0, hipStream_t s) {
 
 // One decode step at position *t_dev (x_a already holds that position's embedding); everything position-dependent is
 // read on the device.  Leaves the next position's embedding in x_a and *t_dev advanced.
-static int enqueue_step(JbEngine* e, hipStream_t s) {
+// parity < 0: every launch on `s` (the plain chain).  parity 0 / 1: software-pipelined step -- only the even / odd launches
+// are enqueued (on `s`), each with its completion slot; the other half goes to the other stream by a second call.
+static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
     const jb_engine_cfg& c = e->cfg;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
+    const int n_slots = jb_engine_launches_per_step(e);
+    int slot = 0;
+    JbPipe pp{c.pipe_words, c.pipe_words ? c.pipe_words + (size_t)n_slots * JB_PIPE_PAD : nullptr,
+              c.pipe_words ? c.pipe_words + jb_pipe_words(n_slots) - JB_PIPE_PAD : nullptr, 0, 0,
+              (c.pipe_words && getenv("JB_PIPE_DEBUG")) ? reinterpret_cast<long long*>(c.pipe_words + jb_pipe_words(n_slots)) : nullptr};
+    // the pipeline slot of the next launch, or NULL for the plain chain; `mine`: this call enqueues it
+    bool mine = true;
+    auto next = [&]() -> const JbPipe* {
+        mine = parity < 0 || (slot & 1) == parity;
+        pp.slot = slot; pp.prev = slot == 0 ? n_slots - 1 : slot - 1;
+        ++slot;
+        return parity < 0 ? nullptr : &pp;
+    };
     for (int l = 0; l < c.n_layers; ++l) {
         const jb_layer& L = e->layers[l];
         jb_gemv_args g;
         // a7/a8/a9: ln_0 + c_attn, k/v appended at *t_dev
         fill_c_attn(g, c, L);
-        JB_TRY(jb_gemv(&g, s));
+        { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
         // attention, then attn.c_proj + residual: x_b = x_a + a
         const int parts = layer_split_parts(c, L);
         g = {};
@@ -176,8 +205,12 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
         g.dtype = c.dtype; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
         g.out = c.x_b; g.ldo = W; g.res = c.x_a; g.ldr = W;
         if (layer_wide(c, L)) {
-            JB_TRY(jb_attn_decode_wide(L.attn_func, c.q, S, L.kcache, L.vcache_w, L.cache_cap, c.x_a, W, L.b_proj, c.x_b, W, N,
-                                       S, W, c.block_ctx, c.t_dev, c.seq_len, s));
+            const JbPipe* pipe = next();
+            if (mine) JB_TRY(jb_attn_decode_wide_impl(L.attn_func, c.q, S, L.kcache, L.vcache_w, L.cache_cap, c.x_a, W, L.b_proj, c.x_b,
+                                                      W, N, S, W, c.block_ctx, c.t_dev, c.seq_len, pipe, s));
+        } else if (parity >= 0) {
+            jb_set_error("jb_engine: pipelined launches need wide-value layers throughout");
+            return JB_ERR_UNSUPPORTED;
         } else if (parts > 0) {
             JB_TRY(jb_attn_decode_split(L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att_parts, c.att_ml, N, H, d,
                                         c.block_ctx, c.t_dev, layer_max_keys(c, L), parts, s));
@@ -194,7 +227,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
         g = {};
         fill_ln_proj(g, c, L, 1);
         g.x = c.x_b; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
-        JB_TRY(jb_gemv(&g, s));
+        { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
         // mlp.c_proj + residual: x_a = x_b + m   (h = x + a + m, transformer.py:82-83); the last layer also hands the
         // logits head xf = float(x_a) (+ cond[t], autoregressive.py:226-227)
         g = {};
@@ -204,14 +237,76 @@ static int enqueue_step(JbEngine* e, hipStream_t s) {
             g.out2 = c.xf; g.ldo2 = W; g.t_dev = c.t_dev;
             if (c.add_cond_after && c.x_cond) { g.add2 = c.x_cond; g.add2_n_stride = c.xc_n_stride; g.add2_t_stride = c.xc_t_stride; }
         }
-        JB_TRY(jb_gemv(&g, s));
+        { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
     }
     jb_gemv_args g = {};
     g.dtype = JB_F32; g.x = c.xf; g.ldx = W; g.n_rows = N; g.W = c.x_out_packed; g.K = W; g.J = c.bins;
     g.out = c.logits; g.ldo = c.bins;
-    JB_TRY(jb_gemv(&g, s));
-    JB_TRY(jb_sample_step(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds, c.preds_n_stride,
-                          c.dtype, c.x_a, c.x_emb, c.pos_emb, c.x_cond, c.xc_n_stride, c.xc_t_stride, W, c.seq_len, c.ticket, s));
+    { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
+    {
+        const JbPipe* pipe = next();
+        if (mine) JB_TRY(jb_sample_step_impl(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds,
+                                             c.preds_n_stride, c.dtype, c.x_a, c.x_emb, c.pos_emb, c.x_cond, c.xc_n_stride,
+                                             c.xc_t_stride, W, c.seq_len, c.ticket, pipe, s));
+    }
+    return JB_OK;
+}
+
+// Software-pipelined launches of the decode step.  Available where every launch of the step has a
+// pipelined form: fp16, <= 16 samples, wide-value layers throughout (one head of 480 channels), widths of 33..64 k-tiles.
+static bool pipeline_eligible(const JbEngine* e) {
+    const jb_engine_cfg& c = e->cfg;
+    if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || c.n_head != 1 || c.n_state != 480 || !c.x_out_packed) return false;
+    if (c.width % 32 || c.n_mlp % 32 || c.width / 32 < 33 || c.width / 32 > 64 || c.n_mlp / 32 < 33 || c.n_mlp / 32 > 64) return false;
+    for (const jb_layer& L : e->layers)
+        if (!layer_wide(c, L) || !L.w_fc_f || layer_max_keys(c, L) > 128) return false;     // one 16-key tile per attention wave
+    return true;
+}
+
+extern "C" int jb_engine_pipeline(void* handle, int enable) {
+    JB_REQUIRE(handle, "null engine");
+    JbEngine* e = (JbEngine*)handle;
+    if (enable && !pipeline_eligible(e)) JB_UNSUPPORTED("this engine's decode step has launches without a pipelined form (needs pipe_words, "
+                                                        "fp16, <= 16 samples, wide-value layers of one 480-channel head, 33..64 k-tiles)");
+    e->pipelined = enable != 0;
+    return JB_OK;
+}
+
+// n_steps pipelined decode steps from the state jb_engine_decode has prepared on `s`.
+static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s) {
+    const int n_slots = jb_engine_launches_per_step(e);
+    JB_REQUIRE(n_slots % 2 == 0, "pipelined launches need an even number of launches per step");
+    if (!e->side_stream) {
+        int prio = 0;
+        if (hipStreamGetPriority(s, &prio) != hipSuccess) prio = 0;
+        if (const char* ev = getenv("JB_PIPE_SIDE_PRIO")) prio = atoi(ev);        // experiment knob
+        JB_HIP(hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, prio));
+        JB_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        JB_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    if (!e->pexec[0]) {
+        if (!e->capture_stream) JB_HIP(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            JB_HIP(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_step(e, e->capture_stream, k);
+            hipGraph_t gph = nullptr;
+            const hipError_t ce = hipStreamEndCapture(e->capture_stream, &gph);
+            if (rc != JB_OK) { if (gph) (void)hipGraphDestroy(gph); return rc; }
+            if (ce != hipSuccess) { jb_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return JB_ERR_HIP; }
+            e->pgraph[k] = gph;
+            JB_HIP(hipGraphInstantiate(&e->pexec[k], gph, nullptr, nullptr, 0));
+        }
+    }
+    // completion counts and tickets start from zero in every call (both streams are idle for this engine here)
+    JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));
+    JB_HIP(hipEventRecord(e->ev_fork, s));
+    JB_HIP(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+    for (int i = 0; i < n_steps; ++i) {
+        JB_HIP(hipGraphLaunch(e->pexec[0], s));
+        JB_HIP(hipGraphLaunch(e->pexec[1], e->side_stream));
+    }
+    JB_HIP(hipEventRecord(e->ev_join, e->side_stream));
+    JB_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
     return JB_OK;
 }
 
@@ -230,6 +325,7 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
         for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
         return JB_OK;
     }
+    if (e->pipelined) return decode_pipelined(e, n_steps, s);
     if (!e->graph_exec) {
         // One eager step first, so that every kernel's dynamic-LDS attribute is configured outside of capture;
         // it computes position t0, which the first replay recomputes identically (the sampler's random stream is

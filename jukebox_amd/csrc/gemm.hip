@@ -77,14 +77,18 @@ struct EpiParams {
     const float* add2; int64_t add2_n, add2_t;
 };
 
+// One element of an output row: plain, or write-through (SC1) for a consumer launch that is already running (JbPipe).
+template <typename T, bool SC1> __device__ __forceinline__ void out_store(T* base, int64_t el, float x) {
+    if constexpr (SC1) jb_st_sc1(base, el, (T)x); else base[el] = (T)x;
+}
 // Column j of a q/k/v(/v') projection goes to the query row or to row `cache_row` of the matching cache.
-template <typename T>
+template <typename T, bool SC1 = false>
 __device__ __forceinline__ void qkv_store(const EpiParams& p, float x, int64_t orow, int j, int64_t cache_row) {
-    if (j < p.S) { ((T*)p.out)[orow * p.ldo + j] = (T)x; return; }
+    if (j < p.S) { out_store<T, SC1>((T*)p.out, orow * p.ldo + j, x); return; }
     if (cache_row < 0) return;
-    if (j < 2 * p.S) ((T*)p.kcache)[cache_row * p.S + (j - p.S)] = (T)x;
-    else if (j < 2 * p.S + p.v_cols) ((T*)p.vcache)[cache_row * p.S + (j - 2 * p.S)] = (T)x;
-    else ((T*)p.vcache2)[cache_row * p.v2w + (j - 2 * p.S - p.v_cols)] = (T)x;
+    if (j < 2 * p.S) out_store<T, SC1>((T*)p.kcache, cache_row * p.S + (j - p.S), x);
+    else if (j < 2 * p.S + p.v_cols) out_store<T, SC1>((T*)p.vcache, cache_row * p.S + (j - 2 * p.S), x);
+    else out_store<T, SC1>((T*)p.vcache2, cache_row * p.v2w + (j - 2 * p.S - p.v_cols), x);
 }
 
 // vals[r] is the accumulator of column jb + r of output row `orow`; cache_row < 0 disables the k/v write.
@@ -134,18 +138,59 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& p, f32x4 acc, in
 }
 
 // One output element (decode GEMV epilogue, spread over all threads of the workgroup).
-template <typename T>
+template <typename T, bool SC1 = false>
 __device__ __forceinline__ void epilogue_store1(const EpiParams& p, float x, int64_t orow, int j, int64_t cache_row,
                                                 float bias_v, float res_v, float add2_v = 0.f) {
     if (p.bias) x += jb_round<T>(bias_v);
     x = jb_round<T>(x);
     x = jb_apply_act<T>(x, p.act);
     if (p.res) x = (p.res_scale == 1.0f) ? jb_round<T>(res_v + x) : jb_round<T>(res_v + jb_round<T>(p.res_scale * x));
-    if (p.out2) p.out2[orow * p.ldo2 + j] = x + add2_v;
+    if (p.out2) out_store<float, SC1>(p.out2, orow * p.ldo2 + j, x + add2_v);
     if (!p.qkv_split) {
-        ((T*)p.out)[orow * p.ldo + j] = (T)x;
+        out_store<T, SC1>((T*)p.out, orow * p.ldo + j, x);
     } else {
-        qkv_store<T>(p, x, orow, j, cache_row);
+        qkv_store<T, SC1>(p, x, orow, j, cache_row);
+    }
+}
+
+// The arithmetic of epilogue_store1 without the store.
+template <typename T>
+__device__ __forceinline__ float epilogue_value(const EpiParams& p, float x, float bias_v, float res_v) {
+    if (p.bias) x += jb_round<T>(bias_v);
+    x = jb_round<T>(x);
+    x = jb_apply_act<T>(x, p.act);
+    if (p.res) x = (p.res_scale == 1.0f) ? jb_round<T>(res_v + x) : jb_round<T>(res_v + jb_round<T>(p.res_scale * x));
+    return x;
+}
+// Pipelined launches: the four consecutive threads that hold columns jb .. jb+3 of output row `orow` (epi_coords<true>)
+// hand them to the first, which stores them write-through in one piece (f16: 8 bytes, fp32: 16); likewise the fp32 second
+// output.  Called by whole waves; jt16 = first column of the workgroup's tile (its destination region is uniform).
+template <typename T>
+__device__ __forceinline__ void pipe_store4(const EpiParams& p, float x, float x2, int64_t orow, int jb, int jt16, int64_t cache_row, bool valid) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const float a1 = __shfl_down(x, 1, 64), a2 = __shfl_down(x, 2, 64), a3 = __shfl_down(x, 3, 64);
+    float b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (p.out2) { b1 = __shfl_down(x2, 1, 64); b2 = __shfl_down(x2, 2, 64); b3 = __shfl_down(x2, 3, 64); }
+    if (!valid || (threadIdx.x & 3)) return;
+    if (p.out2) {
+        const f32x4 o2 = {x2, b1, b2, b3};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o2), jb_rsrc(p.out2), (int)((orow * p.ldo2 + jb) * 4), 0, 16);
+    }
+    T* base = (T*)p.out;
+    int64_t el = orow * p.ldo + jb;
+    if (p.qkv_split && jt16 >= p.S) {
+        if (cache_row < 0) return;
+        if (jt16 < 2 * p.S) { base = (T*)p.kcache; el = cache_row * p.S + (jb - p.S); }
+        else if (jt16 < 2 * p.S + p.v_cols) { base = (T*)p.vcache; el = cache_row * p.S + (jb - 2 * p.S); }
+        else { base = (T*)p.vcache2; el = cache_row * p.v2w + (jb - 2 * p.S - p.v_cols); }
+    }
+    if constexpr (sizeof(T) == 2) {
+        const f16x4 o = {(f16)x, (f16)a1, (f16)a2, (f16)a3};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), jb_rsrc(base), (int)(el * 2), 0, 16);
+    } else {
+        const f32x4 o = {x, a1, a2, a3};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), jb_rsrc(base), (int)(el * 4), 0, 16);
     }
 }
 
@@ -419,6 +464,7 @@ struct GemvParams {
     const int* t_dev;
     // key-split attention output as the operand (gemv_merge_kernel): x[n][k] = sum_s w_s(n, head(k)) * parts[n][s][k]
     const void* x_parts; const float* x_ml; int n_parts, n_head, d_head;
+    JbPipe pipe;                                // software-pipelined launch (common.h); slot < 0: plain
     EpiParams epi;
 };
 
@@ -453,7 +499,16 @@ __device__ __forceinline__ float frag_sum(typename Frag<T>::vec v) {
 // compiler from moving the requests below it (nothing waits there).
 __device__ __forceinline__ void jb_issue_fence() { asm volatile("" ::: "memory"); }
 
-template <typename T, int EPT, int NT>
+// Which element of the MT 16x16 output tiles flat index i stands for: fragment lane l, register r of tile mt.  The plain
+// kernels put consecutive threads on consecutive lanes (r = wave); ALT (pipelined launches) puts the four registers of a
+// lane on four consecutive threads, so that a lane's 4 consecutive columns can be gathered by shuffles and leave as ONE
+// 8- or 16-byte write-through store instead of four 2-byte ones.
+template <bool ALT> __device__ __forceinline__ void epi_coords(int i, int& mt, int& r, int& l) {
+    mt = i >> 8;
+    if (ALT) { l = (i >> 2) & 63; r = i & 3; } else { r = (i >> 6) & 3; l = i & 63; }
+}
+
+template <typename T, int EPT, int NT, bool ALT = false>
 struct EpiOperands {
     float bias[EPT], res[EPT], c1[EPT];
     __device__ __forceinline__ void request(const GemvParams& p, int jt, int MT) {
@@ -464,7 +519,9 @@ struct EpiOperands {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
             const int i = threadIdx.x + u * NT;
-            const int row = (i >> 8) * 16 + (i & 15), j = blockIdx.x * 16 + ((i & 63) >> 4) * 4 + ((i >> 6) & 3);
+            int emt, er, el;
+            epi_coords<ALT>(i, emt, er, el);
+            const int row = emt * 16 + (el & 15), j = blockIdx.x * 16 + (el >> 4) * 4 + er;
             const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
             bias[u] = bias_p[jc];
             c1[u] = c1_p[jc];
@@ -482,8 +539,9 @@ struct EpiOperands {
     }
 };
 
-template <typename T, int MT, int NW, bool LNS, bool FAST, int NV>
+template <typename T, int MT, int NW, bool LNS, bool FAST, int NV, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
+    static_assert(!PIPE || (!LNS && FAST), "pipelined launches: plain fast path only");
     using V = typename Frag<T>::vec;
     constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
     constexpr int WB = NW == 16 ? 10 : (MT <= 2 ? 8 : 4);   // weight (and activation) fragments in flight per wave
@@ -501,6 +559,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     const T* wbase = (const T*)p.W + ((int64_t)jt * p.nkt) * (64 * E) + (int64_t)lane * E;
 
     JB_STAMP(0);
+    unsigned pipe_own = 0;
+    if constexpr (PIPE) pipe_own = jb_pipe_own(p.pipe);
     // ---- everything this workgroup needs from memory is requested here ----
     V wf[WB];
 #pragma unroll
@@ -516,10 +576,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     // i = (mt, r, l) is element r of fragment lane l of tile mt) and, on the plain fast path, the activation fragments of
     // the first (usually only) batch: everything is in flight before anything is waited for.
     constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);      // elements per thread
-    EpiOperands<T, EPT, NW * 64> eo;
+    EpiOperands<T, EPT, NW * 64, PIPE> eo;
     eo.request(p, jt, MT);
     V xf0[(!LNS && FAST) ? WB : 1][MT];
-    if constexpr (!LNS && FAST) {
+    if constexpr (!LNS && FAST && !PIPE) {
 #pragma unroll
         for (int i = 0; i < WB; ++i) {
             const int k0 = min(kt0 + i, p.nkt - 1) * KT + g * E;
@@ -528,13 +588,16 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
         }
     }
     jb_issue_fence();
+    if constexpr (PIPE) jb_pipe_wait(p.pipe, pipe_own);     // the weights (and the epilogue operands of older launches) are in flight
     int t = 0;
-    if (p.epi.qkv_split || p.epi.add2) t = *p.t_dev;
+    if (p.epi.qkv_split || p.epi.add2) t = PIPE ? (int)jb_ld_word(reinterpret_cast<const unsigned*>(p.t_dev)) : *p.t_dev;
     float e_add2[EPT];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
         const int i = threadIdx.x + u * NW * 64;
-        const int row = (i >> 8) * 16 + (i & 15), j = jt * 16 + ((i & 63) >> 4) * 4 + ((i >> 6) & 3);
+        int emt, er, el;
+        epi_coords<PIPE>(i, emt, er, el);
+        const int row = emt * 16 + (el & 15), j = jt * 16 + (el >> 4) * 4 + er;
         const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
         e_add2[u] = p.epi.add2 ? p.epi.add2[(int64_t)rc * p.epi.add2_n + (int64_t)t * p.epi.add2_t + jc] : 0.f;
     }
@@ -711,6 +774,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
                     const int row = min(mt * 16 + c, p.n_rows - 1);
                     if constexpr (LNS) {
                         xf[i][mt] = *reinterpret_cast<const V*>(s_x + (int64_t)row * pitch + k0);
+                    } else if constexpr (PIPE) {
+                        xf[i][mt] = jb_ld_frag_sc1<T>(x, (int64_t)row * p.ldx + k0);       // the producer launch's rows
                     } else {
                         if (kb == kt0) xf[i][mt] = xf0[i][mt];
                         else xf[i][mt] = ld_frag<T>(x + (int64_t)row * p.ldx + k0);
@@ -749,6 +814,23 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     __syncthreads();
     JB_STAMP(6);
     eo.finish(p);
+    if constexpr (PIPE) {
+        // MT == 1: the 256 elements of the tile on the first four waves, four consecutive threads per fragment lane
+        if (wave < 4) {
+            const float* sa = reinterpret_cast<const float*>(s_acc);
+            int mt, r, l;
+            epi_coords<true>(threadIdx.x, mt, r, l);
+            const int row = l & 15, j = jt * 16 + (l >> 4) * 4 + r;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += sa[(w * 64 + l) * 4 + r];
+            const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
+            const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
+            pipe_store4<T>(p.epi, xo, xo + e_add2[0], row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J);
+        }
+        jb_pipe_publish(p.pipe, pipe_own);
+        return;
+    }
     {
         const float* sa = reinterpret_cast<const float*>(s_acc);
 #pragma unroll
@@ -774,7 +856,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
 // whose diagonal is sum(x^2) (f16 products are exact in the fp32 accumulator).  The per-wave partial sums join the
 // partial tiles in the single LDS exchange before the epilogue, where mean / rstd meet the accumulators.
 // A wave keeps all of its k-tiles' fragments in registers: needs ceil(nkt / NW) <= NF.
-template <typename T, int MT, int NW, int NF>
+template <typename T, int MT, int NW, int NF, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     using V = typename Frag<T>::vec;
     constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
@@ -792,23 +874,38 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
 
     // ---- every request of this workgroup, issued back to back ----
     V xf[NF][MT];
+    unsigned pipe_own = 0;
+    if constexpr (PIPE) pipe_own = jb_pipe_own(p.pipe);
+    if constexpr (!PIPE) {
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const int k0 = min(kt0 + i, p.nkt - 1) * KT + g * E;
+        for (int i = 0; i < NF; ++i) {
+            const int k0 = min(kt0 + i, p.nkt - 1) * KT + g * E;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            xf[i][mt] = ld_frag<T>(x + (int64_t)min(mt * 16 + c, p.n_rows - 1) * p.ldx + k0);
+            for (int mt = 0; mt < MT; ++mt)
+                xf[i][mt] = ld_frag<T>(x + (int64_t)min(mt * 16 + c, p.n_rows - 1) * p.ldx + k0);
+        }
     }
     V wf[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i)
         wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)min(kt0 + i, p.nkt - 1) * (64 * E)));
     constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);
-    EpiOperands<T, EPT, NW * 64> eo;           // bias, column sums c1, residual: in flight with the weights
+    EpiOperands<T, EPT, NW * 64, PIPE> eo;     // bias, column sums c1, residual: in flight with the weights
     eo.request(p, jt, MT);
     jb_issue_fence();
+    if constexpr (PIPE) {
+        // the weight stream is in flight; the rows are the producer launch's: wait for it, then read them write-through
+        jb_pipe_wait(p.pipe, pipe_own);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int k0 = min(kt0 + i, p.nkt - 1) * KT + g * E;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                xf[i][mt] = jb_ld_frag_sc1<T>(x, (int64_t)min(mt * 16 + c, p.n_rows - 1) * p.ldx + k0);
+        }
+    }
     int t = 0;
-    if (p.epi.qkv_split) t = *p.t_dev;
+    if (p.epi.qkv_split) t = PIPE ? (int)jb_ld_word(reinterpret_cast<const unsigned*>(p.t_dev)) : *p.t_dev;
 
     // ---- projection and row statistics, all on MFMA (tiles past kt1 are neutralised by zeroing the activations) ----
     V ones;
@@ -839,6 +936,29 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     __syncthreads();
     eo.finish(p);
     const float* sa = reinterpret_cast<const float*>(s_acc);
+    if constexpr (PIPE) {
+        // MT == 1: the 256 elements of the tile on the first four waves, four consecutive threads per fragment lane
+        if (wave < 4) {
+            int mt, r, l;
+            epi_coords<true>(threadIdx.x, mt, r, l);
+            const int row = l & 15, j = jt * 16 + (l >> 4) * 4 + r;
+            float v = 0.f, sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                v += sa[(w * 64 + l) * 4 + r];
+                sm += s_sum[w * 16 + row];
+                sq += s_sq[w * 16 + row];
+            }
+            const float mean = sm / (float)p.K;
+            const float var = fmaxf(sq / (float)p.K - mean * mean, 0.f);
+            v = (v - mean * eo.c1[0]) / sqrtf(var + p.ln_eps);
+            const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
+            const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
+            pipe_store4<T>(p.epi, xo, xo, row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J);
+        }
+        jb_pipe_publish(p.pipe, pipe_own);
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
         const int i = threadIdx.x + u * NW * 64;
@@ -1001,6 +1121,13 @@ extern "C" int jb_gemv_ln_fold_supported(int dtype, int K, int J, int n_rows) {
 template <typename T, int MT, int NW>
 static int launch_gemv_lnf_nf(const GemvParams& p, int njt, int nf, hipStream_t s) {
     const size_t lds = (size_t)NW * MT * 64 * sizeof(f32x4) + (size_t)2 * NW * MT * 16 * sizeof(float);
+    if (p.pipe.slot >= 0) {
+        if constexpr (MT == 1 && NW == 8 && sizeof(T) == 2) {
+            if (nf == 8) { gemv_lnf_kernel<T, 1, 8, 8, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+        }
+        jb_set_error("jb_gemv: a pipelined launch of the folded-LayerNorm projection takes fp16, <= 16 rows, 33..64 k-tiles");
+        return JB_ERR_UNSUPPORTED;
+    }
     if (nf == 8) gemv_lnf_kernel<T, MT, NW, 8><<<njt, NW * 64, lds, s>>>(p);
     else if constexpr (NW == 16) gemv_lnf_kernel<T, MT, NW, 10><<<njt, NW * 64, lds, s>>>(p);
     else gemv_lnf_kernel<T, MT, NW, 16><<<njt, NW * 64, lds, s>>>(p);
@@ -1037,6 +1164,13 @@ static int launch_gemv_fast(const GemvParams& p, int njt, size_t lds, hipStream_
 
 template <typename T, int MT, int NW, bool LNS>
 static int launch_gemv_inst(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
+    if (p.pipe.slot >= 0) {
+        if constexpr (MT == 1 && NW == 8 && !LNS) {
+            if (p.fast) { gemv_kernel<T, 1, 8, false, true, 0, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+        }
+        jb_set_error("jb_gemv: a pipelined launch of the plain projection takes <= 16 rows, >= 32 whole k-tiles, aligned operands");
+        return JB_ERR_UNSUPPORTED;
+    }
     if (!p.fast) return launch_gemv_fast<T, MT, NW, LNS, false, 0>(p, njt, lds, s);
     if (LNS) {
         // vectors per lane per row on the register LayerNorm path (0 = staged-through-LDS variant)
@@ -1096,7 +1230,10 @@ long long* jb_dbg_ptr = nullptr;
 extern "C" void jb_set_dbg(long long* p) { jb_dbg_ptr = p; }
 #endif
 
-extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
+extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) { return jb_gemv_impl(a, nullptr, stream); }
+
+// pipe != NULL: one launch of a software-pipelined chain (common.h, JbPipe)
+int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream) {
     JB_REQUIRE(a && (a->x || a->x_parts) && a->W && a->out, "null pointer");
     JB_REQUIRE(a->dtype == JB_F32 || a->dtype == JB_F16, "bad dtype");
     JB_REQUIRE(a->n_rows >= 1 && a->n_rows <= 64, "n_rows must be 1..64");
@@ -1124,6 +1261,10 @@ extern "C" int jb_gemv(const jb_gemv_args* a, void* stream) {
     p.vec_x = a->x && (a->ldx % E == 0) && aligned_to(a->x, 16);
     p.t_dev = a->t_dev;
     p.x_parts = a->x_parts; p.x_ml = a->x_ml; p.n_parts = a->n_parts; p.n_head = a->n_head; p.d_head = a->d_head;
+    p.pipe = pipe ? *pipe : JbPipe{nullptr, nullptr, nullptr, -1, -1, nullptr};
+    JB_REQUIRE(!pipe || (!a->x_parts && !a->ln_gamma && a->J % 16 == 0 && a->n_rows <= 16 && a->ldo % 4 == 0 &&
+                         (!a->qkv_split || a->S % 16 == 0) && (!a->out2 || a->ldo2 % 4 == 0)),
+               "a pipelined launch takes the plain or the folded-LayerNorm projection, <= 16 rows, whole 16-column tiles");
     p.dbg = nullptr;
 #ifdef JB_TIMING
     p.dbg = jb_dbg_ptr;

@@ -209,6 +209,10 @@ class PriorEngine:
         if any(splits(lay) for lay in pk.layers):
             self.att_parts = e(N, 4, S)
             self.att_ml = e(N, self.H, 4, 2, dtype=torch.float32)
+        # completion words of software-pipelined launches (jb_engine_pipeline): counts + tickets per launch slot, error word last
+        # (+ room for the JB_PIPE_DEBUG stamps: 4 x int64 per slot behind the error group)
+        self.pipe_words = torch.zeros((10 * (5 * self.depth + 2) + 1) * 32 + (5 * self.depth + 2) * 8, dtype=torch.int32, device=dev)
+        self.pipelined = False
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -276,6 +280,7 @@ class PriorEngine:
             c.att_parts, c.att_ml = self.att_parts.data_ptr(), self.att_ml.data_ptr()
         c.ticket = self.ticket.data_ptr()
         c.att_ld = self.att_ld
+        c.pipe_words = self.pipe_words.data_ptr()
         c.chunk_cap = self.chunk_cap
         c.c_xf = b["c_xf"].data_ptr() if "c_xf" in b else None
         c.tokens, c.tok_stride, c.t_dev = self.tokens.data_ptr(), self.tokens.stride(0), self.t_dev.data_ptr()
@@ -289,6 +294,32 @@ class PriorEngine:
         h = C.c_void_p()
         L.check(L.lib().jb_engine_create(C.byref(c), self.layers_c, C.byref(h)))
         self.handle = h
+        # Software-pipelined launches: on where every launch of the step has a pipelined form (the 1b upsamplers), unless
+        # JB_PIPELINE_LAUNCHES=0; engines of other shapes keep the plain launch chain.
+        self.pipelined = False
+        if os.environ.get("JB_PIPELINE_LAUNCHES", "1") != "0" and not self.only_encode:
+            self.pipelined = L.lib().jb_engine_pipeline(self.handle, 1) == 0
+
+    def set_pipelined(self, on):
+        """Switch software-pipelined launches of the decode step on / off; returns whether they are on."""
+        rc = L.lib().jb_engine_pipeline(self.handle, int(bool(on)))
+        if on and rc != 0:
+            self.pipelined = False
+            return False
+        L.check(rc)
+        self.pipelined = bool(on)
+        return self.pipelined
+
+    def pipe_stamps(self):
+        """JB_PIPE_DEBUG=1: (n_slots, 4) int64 ticks of the 100 MHz clock of the last pipelined step: poll entered, producer
+        seen, completion published."""
+        n = self.launches_per_step
+        base = (10 * n + 1) * 32
+        return self.pipe_words[base:base + n * 8].view(torch.int64).reshape(n, 4).cpu().numpy()
+
+    def pipe_error(self):
+        """0, or slot + 1 of a pipelined launch whose wait for its producer timed out (sticky)."""
+        return int(self.pipe_words[10 * self.launches_per_step * 32].item())
 
     def close(self):
         if getattr(self, "handle", None):

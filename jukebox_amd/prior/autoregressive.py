@@ -215,6 +215,9 @@ class ConditionalAutoregressive2D(nn.Module):
                 fn(eng.tokens, pos, pos + n)
                 pos += n
         x = eng.tokens[:, :sample_tokens].clone()
+        if eng.pipelined and eng.pipe_error():
+            raise RuntimeError(f"pipelined decode: launch slot {eng.pipe_error() - 1} timed out waiting for its producer; the "
+                               "tokens of this window are not valid (JB_PIPELINE_LAUNCHES=0 selects the plain launch chain)")
         x = self.postprocess(x, sample_tokens)
         if get_preds:
             return x, eng.preds[:, :sample_tokens].clone()

@@ -219,3 +219,41 @@ def test_wide_value_engine_refuses_prefill_behind_decoded_positions(PE):
     eng.decode(8, 2)
     torch.cuda.synchronize()
     assert int(eng.t_dev.item()) == 10
+
+
+def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch):
+    """Software-pipelined launches (jb_engine_pipeline: the launches of a step alternate between two streams, launch j+1
+    waits on launch j's completion word instead of on a kernel boundary): same kernels' arithmetic in the same order, so
+    logits and tokens are BIT-identical to the plain chain -- upsampler geometry (one 480-channel head, wide-value layers),
+    N = 16, primed window + sampled decode in several calls, then a second window on the same engine."""
+    rng = np.random.default_rng(21)
+    width, depth, bins, seq, blocks, N = 1920, 6, 512, 1024, 16, 16
+    sd = to_dev(_random_sd(rng, width, depth, bins, seq, 2, scale=0.02))
+    xc = torch.from_numpy((rng.standard_normal((N, seq, width)) * 0.1).astype(np.float32))
+    prime = torch.from_numpy(rng.integers(0, bins, (N, 200))).cuda()
+    outs = {}
+    for mode in ("chain", "pipelined"):
+        monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1" if mode == "pipelined" else "0")
+        eng = PE(sd, "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=1, attn_order=2, blocks=blocks,
+                 y_cond=False, fp16=True, want_preds=True, chunk_cap=64)
+        eng.set_cond(xc, None)
+        assert eng.pipelined == (mode == "pipelined") and eng.launches_per_step == 4 * depth + 2
+        eng.set_sampling(temp=0.98, seed=5)
+        res = []
+        for window in range(2):
+            eng.tokens[:, :200] = prime
+            eng.prefill(0, 200)
+            t = 200
+            for n_steps in (1, 7, 64, 150, 3):                 # several calls: the completion words restart in each
+                eng.decode(t, n_steps)
+                t += n_steps
+            torch.cuda.synchronize()
+            res.append((eng.tokens[:, :t].cpu().numpy().copy(), eng.preds[:, 200:t].cpu().numpy().copy()))
+            assert int(eng.t_dev.item()) == t
+        assert eng.pipe_error() == 0
+        outs[mode] = res
+        eng.close()
+    for (z0, p0), (z1, p1) in zip(outs["chain"], outs["pipelined"]):
+        assert np.array_equal(z0, z1), "tokens differ between the plain chain and pipelined launches"
+        assert np.array_equal(p0, p1), "logits differ between the plain chain and pipelined launches"
+    assert not np.array_equal(outs["chain"][0][0][:, 200:], np.zeros_like(outs["chain"][0][0][:, 200:]))

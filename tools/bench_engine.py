@@ -2,6 +2,7 @@
 ms per decode step (eager vs hipGraph) and achieved HBM GB/s against the algorithmic bytes of
 SURVEY.md section 8d.  Usage: python tools/bench_engine.py [1b|up|small] [--steps K] [--t0 T] [--fp32]"""
 import argparse
+import os
 import time
 
 import torch
@@ -63,6 +64,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--prio", type=int, default=None, help="run on a torch stream of this priority (-1 = high) instead of the default stream")
+    ap.add_argument("--pipelined", type=int, default=-1, help="1 / 0: software-pipelined launches on / off (default: the engine's choice)")
     a = ap.parse_args()
     cfg = CFGS[a.model]
     dev = torch.device("cuda:0")
@@ -75,9 +78,13 @@ def main():
     if cfg.get("encoder_dims"):
         eng.set_encoder_kv(torch.randn(a.batch, cfg["encoder_dims"], cfg["width"], device=dev) * 0.1)
     del sd
+    if a.pipelined >= 0:
+        eng.set_pipelined(bool(a.pipelined))
     torch.cuda.synchronize()
     print(f"model={a.model} N={a.batch} dtype={'f32' if a.fp32 else 'f16'} weights={eng.weight_bytes() / 1e9:.2f} GB "
-          f"kv={eng.cache_bytes() / 1e9:.2f} GB launches/step={eng.launches_per_step}")
+          f"kv={eng.cache_bytes() / 1e9:.2f} GB launches/step={eng.launches_per_step} pipelined={eng.pipelined}")
+    if a.prio is not None:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=a.prio))
     for use_graph in ([False] if a.eager else [False, True]):
         eng.decode(a.t0, 8, use_graph=use_graph)      # warm-up (+ capture)
         torch.cuda.synchronize()
@@ -86,6 +93,20 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / a.steps
         b = eng.step_bytes(a.t0 + a.steps // 2)
+        if use_graph and eng.pipelined and eng.pipe_error():
+            print("  !! pipelined launch timed out waiting for slot", eng.pipe_error() - 1)
+        if use_graph and eng.pipelined and os.environ.get("JB_PIPE_DEBUG"):
+            import numpy as np
+            st = eng.pipe_stamps().astype(np.float64) * 0.01          # us
+            n = st.shape[0]
+            pub = st[:, 2]
+            kinds = ["c_attn", "attention", "c_fc", "c_proj"]
+            for k in range(4):
+                idx = np.arange(8 + k, n - 2, 4)
+                print(f"    {kinds[k]:10s} published - producer published {np.mean(pub[idx] - pub[idx - 1]):6.2f} us | poll entered - "
+                      f"same-stream predecessor published {np.mean(st[idx, 0] - pub[idx - 2]):6.2f} | producer seen - producer "
+                      f"published {np.mean(st[idx, 1] - pub[idx - 1]):6.2f} | published - producer seen {np.mean(pub[idx] - st[idx, 1]):6.2f}"
+                      f" (of which workgroup 0: seen -> stores issued {np.mean(st[idx, 3] - st[idx, 1]):5.2f}, then drain + tickets of all {np.mean(pub[idx] - st[idx, 3]):5.2f})")
         print(f"  graph={use_graph}: {dt * 1e3:.3f} ms/step  algorithmic {b / 1e9:.3f} GB/step -> {b / dt / 1e12:.2f} TB/s "
               f"({b / dt / 8e12 * 100:.1f}% of 8 TB/s)")
 
