@@ -163,6 +163,9 @@ __device__ __forceinline__ float jb_load_any(const void* p, int dtype, int64_t i
 // sc1 loads (L1 bypass; the producer stored write-through and drained before it took its ticket), no cache-wide
 // invalidate or write-back anywhere.  Data of launches j-2 and older is ordinary: the same stream ordered it.
 // Polls are bounded (2 s of the 100 MHz clock): a timeout records slot + 1 in *err and goes on.
+// Measured alternatives (round 3, upsampler step): ONE ticket word for all 120-180 workgroups -- its returning atomics
+// serialise; the last workgroup of a shard ADDING to the polled word with a fire-and-forget atomic instead of the
+// second ticket + flag store -- 1.71 vs 1.59 ms per step: a word that is being polled must be written once, by a store.
 struct JbPipe {
     unsigned* runs; unsigned* tickets; unsigned* err;
     int slot, prev;                                  // slot < 0: plain launch chain (every helper below compiles away)

@@ -97,16 +97,15 @@ def main():
             print("  !! pipelined launch timed out waiting for slot", eng.pipe_error() - 1)
         if use_graph and eng.pipelined and os.environ.get("JB_PIPE_DEBUG"):
             import numpy as np
-            st = eng.pipe_stamps().astype(np.float64) * 0.01          # us
+            st = eng.pipe_stamps().astype(np.float64) * 0.01          # us: poll entered, producer seen, -, stores issued (workgroup 0)
             n = st.shape[0]
-            pub = st[:, 2]
+            seen, issued = st[:, 1], st[:, 3]
             kinds = ["c_attn", "attention", "c_fc", "c_proj"]
             for k in range(4):
-                idx = np.arange(8 + k, n - 2, 4)
-                print(f"    {kinds[k]:10s} published - producer published {np.mean(pub[idx] - pub[idx - 1]):6.2f} us | poll entered - "
-                      f"same-stream predecessor published {np.mean(st[idx, 0] - pub[idx - 2]):6.2f} | producer seen - producer "
-                      f"published {np.mean(st[idx, 1] - pub[idx - 1]):6.2f} | published - producer seen {np.mean(pub[idx] - st[idx, 1]):6.2f}"
-                      f" (of which workgroup 0: seen -> stores issued {np.mean(st[idx, 3] - st[idx, 1]):5.2f}, then drain + tickets of all {np.mean(pub[idx] - st[idx, 3]):5.2f})")
+                idx = np.arange(8 + k, n - 3, 4)
+                print(f"    {kinds[k]:10s} consumer sees it - it saw its producer {np.mean(seen[idx + 1] - seen[idx]):6.2f} us = inputs seen -> "
+                      f"stores issued {np.mean(issued[idx] - seen[idx]):5.2f} + drain, tickets, propagation {np.mean(seen[idx + 1] - issued[idx]):5.2f}"
+                      f" | poll entered {np.mean(seen[idx] - st[idx, 0]):5.2f} before the producer was seen")
         print(f"  graph={use_graph}: {dt * 1e3:.3f} ms/step  algorithmic {b / 1e9:.3f} GB/step -> {b / dt / 1e12:.2f} TB/s "
               f"({b / dt / 8e12 * 100:.1f}% of 8 TB/s)")
 
