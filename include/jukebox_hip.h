@@ -330,8 +330,11 @@ int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* str
  * after polling j's completion word, through write-through stores / L1-bypassing loads.  Same kernels' arithmetic in the
  * same order: tokens and logits are bit-identical to the plain chain.  enable != 0 returns JB_ERR_UNSUPPORTED unless every
  * launch of this engine's step has a pipelined form (cfg.pipe_words given, fp16, <= 16 samples, every layer a wide-value
- * layer of one 480-channel head, width and n_mlp of 33..64 k-tiles: the 1b upsamplers).  Replaces the same reference code
- * as jb_engine_decode. */
+ * layer of one 480-channel head, width and n_mlp of 33..64 k-tiles: the 1b upsamplers), and while ANOTHER engine of the
+ * process has them on: a waiting launch occupies compute units, and the waiters of two engines can leave no room for the
+ * launches they wait for -- one pipelined engine at a time (enable = 0 or jb_engine_destroy releases the right).  The two
+ * streams must feed different hardware queues; the first pipelined decode checks that with a two-kernel handshake and
+ * keeps the plain chain otherwise.  Replaces the same reference code as jb_engine_decode. */
 int jb_engine_pipeline(void* handle, int enable);
 /* Measurement aid: n_steps passes over all layers launching only the LayerNorm-fused projections (attn.c_attn and
  * mlp.c_fc -- the dominant kernel of the decode step) with their real arguments, back to back on `stream`, bracketed

@@ -706,7 +706,7 @@ int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const vo
     const size_t lds = (size_t)(2 * nw + 16 * nw + nw * d_head) * sizeof(float);
     dim3 grid(n_batch, width / d_head);
     hipStream_t s = (hipStream_t)stream;
-    const JbPipe nopipe{nullptr, nullptr, nullptr, -1, -1, nullptr};
+    const JbPipe nopipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr};
     if (pipe) {
         JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30),
                    "a pipelined launch of the wide-value attention takes d_head = 480 and caches below 2 GiB");

@@ -169,6 +169,7 @@ __device__ __forceinline__ float jb_load_any(const void* p, int dtype, int64_t i
 struct JbPipe {
     unsigned* runs; unsigned* tickets; unsigned* err;
     int slot, prev;                                  // slot < 0: plain launch chain (every helper below compiles away)
+    long long timeout;                               // poll bound in ticks of the 100 MHz clock (engine: 2 s, JB_PIPE_TIMEOUT_MS)
     long long* dbg;                                  // optional [slot][4] stamps of the 100 MHz clock (JB_PIPE_DEBUG): poll
                                                      // entered, producer seen, own completion published
 };
@@ -215,7 +216,7 @@ __device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own) {
             unsigned spins = 0;
             while (jb_ld_word(w) < need) {
                 __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 255u) == 0 && wall_clock64() - t0 > 200000000ll) { jb_st_word(P.err, (unsigned)P.slot + 1u); break; }
+                if ((++spins & 255u) == 0 && wall_clock64() - t0 > P.timeout) { jb_st_word(P.err, (unsigned)P.slot + 1u); break; }
             }
         }
         if (stamp) P.dbg[P.slot * 4 + 1] = wall_clock64();

@@ -435,7 +435,7 @@ static int launch_sample(const float* logits, int n_batch, int bins, const jb_sa
                                                             tail, *pipe);
     } else {
         sample_kernel<false><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds,
-                                                             preds_n_stride, tail, JbPipe{nullptr, nullptr, nullptr, -1, -1, nullptr});
+                                                             preds_n_stride, tail, JbPipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr});
     }
     JB_CHECK_LAUNCH();
     return JB_OK;

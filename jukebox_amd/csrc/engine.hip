@@ -8,9 +8,15 @@
 //                  wide-value layers (single head, jb_layer.vcache_w) have no attn.c_proj launch: 4 launches per layer
 //   prefill      = the same per layer on a chunk of positions with the tiled GEMM and the MFMA attention.
 // The position t lives in device memory (*t_dev) so that the captured graph is replayable for every step.
+#include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
+
+// the ONE engine of the process that may run pipelined launches (jb_engine_pipeline)
+static std::mutex g_pipe_mutex;
+static void* g_pipe_owner = nullptr;
 
 struct JbEngine {
     jb_engine_cfg cfg;
@@ -24,8 +30,8 @@ struct JbEngine {
     // software-pipelined launches (jb_engine_pipeline): the launches of a step alternate between the caller's stream and a
     // second stream of the same priority, as two single-stream graphs that are replayed side by side
     bool pipelined = false;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t pstream[2] = {nullptr, nullptr};                   // the engine's own pair (setup_pipeline_streams)
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     hipGraph_t pgraph[2] = {nullptr, nullptr};
     hipGraphExec_t pexec[2] = {nullptr, nullptr};
 };
@@ -93,8 +99,14 @@ extern "C" int jb_engine_destroy(void* handle) {
         if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+    for (int k = 0; k < 2; ++k) {
+        if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+        if (e->pstream[k]) (void)hipStreamDestroy(e->pstream[k]);
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_pipe_mutex);
+        if (g_pipe_owner == e) g_pipe_owner = nullptr;
+    }
     if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
     delete e;
     return JB_OK;
@@ -183,6 +195,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
     int slot = 0;
     JbPipe pp{c.pipe_words, c.pipe_words ? c.pipe_words + (size_t)n_slots * JB_PIPE_PAD : nullptr,
               c.pipe_words ? c.pipe_words + jb_pipe_words(n_slots) - JB_PIPE_PAD : nullptr, 0, 0,
+              (getenv("JB_PIPE_TIMEOUT_MS") ? atoll(getenv("JB_PIPE_TIMEOUT_MS")) : 2000ll) * 100000ll,
               (c.pipe_words && getenv("JB_PIPE_DEBUG")) ? reinterpret_cast<long long*>(c.pipe_words + jb_pipe_words(n_slots)) : nullptr};
     // the pipeline slot of the next launch, or NULL for the plain chain; `mine`: this call enqueues it
     bool mine = true;
@@ -268,7 +281,77 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     JbEngine* e = (JbEngine*)handle;
     if (enable && !pipeline_eligible(e)) JB_UNSUPPORTED("this engine's decode step has launches without a pipelined form (needs pipe_words, "
                                                         "fp16, <= 16 samples, wide-value layers of one 480-channel head, 33..64 k-tiles)");
+    // ONE pipelined engine per process.  Its waiting launch holds up to 180 workgroup slots while it spins; the producer it
+    // waits for -- in particular the attention launch, 198 registers per lane: one workgroup per otherwise empty compute
+    // unit -- must still find room.  One waiter leaves >= 76 compute units free of waiters; the waiters of two engines can
+    // cover all 256, and then neither producer is ever placed (seen in the 3-level job: every slot timed out).
+    std::lock_guard<std::mutex> lock(g_pipe_mutex);
+    if (enable) {
+        if (g_pipe_owner && g_pipe_owner != e) JB_UNSUPPORTED("another engine of this process runs pipelined launches (one at a time: "
+                                                              "switch it off or destroy it first)");
+        g_pipe_owner = e;
+    } else if (g_pipe_owner == e) {
+        g_pipe_owner = nullptr;
+    }
     e->pipelined = enable != 0;
+    return JB_OK;
+}
+
+// Pipelined launches wait on each other ACROSS streams, and HIP multiplexes streams onto a few in-order hardware queues
+// (GPU_MAX_HW_QUEUES, 4 by default): a waiting launch that sits in the same hardware queue AHEAD of its producer -- or, with
+// two pipelined engines, ahead of the other engine's producer while that engine's waiter sits ahead of ours -- never ends.
+// Every stream that carries pipelined launches is therefore checked, once, against every other such stream of the process
+// with a two-kernel handshake: a kernel on stream a spins (bounded: 20 ms) for a flag that a kernel on stream b sets; if
+// both streams feed one in-order queue the setter cannot start and the spin times out.  Engines whose streams cannot be
+// told apart keep the plain launch chain.
+__global__ void pipe_probe_wait_kernel(unsigned* flag, unsigned* result) {
+    const long long t0 = wall_clock64();
+    while (jb_ld_word(flag) == 0u) {
+        if (wall_clock64() - t0 > 150000000ll) { *result = 0u; return; }      // 1.5 s: longer than a busy stream's backlog
+        __builtin_amdgcn_s_sleep(32);
+    }
+    *result = 1u;
+}
+__global__ void pipe_probe_set_kernel(unsigned* flag) { jb_st_word(flag, 1u); }
+
+// 1: launches on a and b run side by side, 0: they share an in-order queue, < 0: error.  `a` must be the caller's own (or a
+// fresh) stream: it is synchronised; `b` may be another engine's busy stream: the setter just queues behind its backlog.
+static int streams_overlap(hipStream_t a, hipStream_t b, unsigned* scratch /* device, 2 words */) {
+    if (a == b) return 0;
+    JB_HIP(hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned), a));
+    JB_HIP(hipStreamSynchronize(a));
+    pipe_probe_wait_kernel<<<1, 1, 0, a>>>(scratch, scratch + 1);
+    pipe_probe_set_kernel<<<1, 1, 0, b>>>(scratch);
+    JB_CHECK_LAUNCH();
+    unsigned r = 0;
+    JB_HIP(hipMemcpyAsync(&r, scratch + 1, sizeof(unsigned), hipMemcpyDeviceToHost, a));      // never the legacy stream
+    JB_HIP(hipStreamSynchronize(a));
+    return r == 1u ? 1 : 0;
+}
+
+// The two streams of a pipelined engine are the engine's own.  A waiting launch blocks the in-order hardware queue it sits
+// in, so these streams must not share a queue with each other (deadlock) nor with anybody else (everything behind a waiter
+// crawls: measured, the 3-level job went from 80 to 128 s when the side stream was an ordinary pooled stream).  HIP gives
+// no handle on the stream -> queue mapping, except that a stream created with a compute-unit mask gets a hardware queue
+// with that mask: two masks that differ in one bit (all 256 compute units / all but one) are two queues of their own.  The
+// pair is still verified with the handshake above.  The caller's stream only forks to and joins from them with events.
+static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mutex
+    unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(jb_engine_launches_per_step(e)) - JB_PIPE_PAD + 8;
+    uint32_t mask[8];
+    for (int k = 0; k < 2; ++k) {
+        for (int w = 0; w < 8; ++w) mask[w] = 0xffffffffu;
+        if (k == 1) mask[7] = 0x7fffffffu;
+        JB_HIP(hipExtStreamCreateWithCUMask(&e->pstream[k], 8, mask));
+    }
+    const int ov = streams_overlap(e->pstream[0], e->pstream[1], scratch);
+    if (ov != 1) {
+        for (int k = 0; k < 2; ++k) { (void)hipStreamDestroy(e->pstream[k]); e->pstream[k] = nullptr; }
+        if (ov < 0) return ov;
+        JB_UNSUPPORTED("the two streams of the pipelined launches share a hardware queue");
+    }
+    JB_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    JB_HIP(hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming));
+    JB_HIP(hipEventCreateWithFlags(&e->ev_join[1], hipEventDisableTiming));
     return JB_OK;
 }
 
@@ -276,15 +359,11 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
 static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s) {
     const int n_slots = jb_engine_launches_per_step(e);
     JB_REQUIRE(n_slots % 2 == 0, "pipelined launches need an even number of launches per step");
-    if (!e->side_stream) {
-        int prio = 0;
-        if (hipStreamGetPriority(s, &prio) != hipSuccess) prio = 0;
-        if (const char* ev = getenv("JB_PIPE_SIDE_PRIO")) prio = atoi(ev);        // experiment knob
-        JB_HIP(hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, prio));
-        JB_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-        JB_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-    }
-    if (!e->pexec[0]) {
+    if (!e->pstream[0] || !e->pexec[0]) {
+        // one engine at a time: the handshake synchronises, and another thread's synchronous calls must not fall into this
+        // thread's capture
+        std::lock_guard<std::mutex> lock(g_pipe_mutex);
+        if (!e->pstream[0]) JB_TRY(setup_pipeline_streams(e));
         if (!e->capture_stream) JB_HIP(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k) {
             JB_HIP(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
@@ -297,16 +376,17 @@ static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s) {
             JB_HIP(hipGraphInstantiate(&e->pexec[k], gph, nullptr, nullptr, 0));
         }
     }
-    // completion counts and tickets start from zero in every call (both streams are idle for this engine here)
+    // completion counts and tickets start from zero in every call (the engine's streams are idle here: the previous call
+    // joined them into the caller's stream)
     JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));
     JB_HIP(hipEventRecord(e->ev_fork, s));
-    JB_HIP(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-    for (int i = 0; i < n_steps; ++i) {
-        JB_HIP(hipGraphLaunch(e->pexec[0], s));
-        JB_HIP(hipGraphLaunch(e->pexec[1], e->side_stream));
+    for (int k = 0; k < 2; ++k) JB_HIP(hipStreamWaitEvent(e->pstream[k], e->ev_fork, 0));
+    for (int i = 0; i < n_steps; ++i)
+        for (int k = 0; k < 2; ++k) JB_HIP(hipGraphLaunch(e->pexec[k], e->pstream[k]));
+    for (int k = 0; k < 2; ++k) {
+        JB_HIP(hipEventRecord(e->ev_join[k], e->pstream[k]));
+        JB_HIP(hipStreamWaitEvent(s, e->ev_join[k], 0));
     }
-    JB_HIP(hipEventRecord(e->ev_join, e->side_stream));
-    JB_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
     return JB_OK;
 }
 
@@ -325,7 +405,11 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
         for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
         return JB_OK;
     }
-    if (e->pipelined) return decode_pipelined(e, n_steps, s);
+    if (e->pipelined) {
+        const int rc = decode_pipelined(e, n_steps, s);
+        if (rc != JB_ERR_UNSUPPORTED || e->pstream[0]) return rc;
+        e->pipelined = false;             // no hardware queue of its own for the side stream: the plain chain from here on
+    }
     if (!e->graph_exec) {
         // One eager step first, so that every kernel's dynamic-LDS attribute is configured outside of capture;
         // it computes position t0, which the first replay recomputes identically (the sampler's random stream is

@@ -1261,7 +1261,7 @@ int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream) {
     p.vec_x = a->x && (a->ldx % E == 0) && aligned_to(a->x, 16);
     p.t_dev = a->t_dev;
     p.x_parts = a->x_parts; p.x_ml = a->x_ml; p.n_parts = a->n_parts; p.n_head = a->n_head; p.d_head = a->d_head;
-    p.pipe = pipe ? *pipe : JbPipe{nullptr, nullptr, nullptr, -1, -1, nullptr};
+    p.pipe = pipe ? *pipe : JbPipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr};
     JB_REQUIRE(!pipe || (!a->x_parts && !a->ln_gamma && a->J % 16 == 0 && a->n_rows <= 16 && a->ldo % 4 == 0 &&
                          (!a->qkv_split || a->S % 16 == 0) && (!a->out2 || a->ldo2 % 4 == 0)),
                "a pipelined launch takes the plain or the folded-LayerNorm projection, <= 16 rows, whole 16-column tiles");

@@ -294,14 +294,22 @@ class PriorEngine:
         h = C.c_void_p()
         L.check(L.lib().jb_engine_create(C.byref(c), self.layers_c, C.byref(h)))
         self.handle = h
-        # Software-pipelined launches: on where every launch of the step has a pipelined form (the 1b upsamplers), unless
-        # JB_PIPELINE_LAUNCHES=0; engines of other shapes keep the plain launch chain.
+        # Software-pipelined launches (one engine per process at a time, jb_engine_pipeline): requested by the sampler for the
+        # level that is the long pole (set_pipelined), or for every eligible engine as it is created with
+        # JB_PIPELINE_LAUNCHES=1 (first come, first served); JB_PIPELINE_LAUNCHES=0 forbids them.
+        want = self.pipelined or os.environ.get("JB_PIPELINE_LAUNCHES", "") == "1"
         self.pipelined = False
-        if os.environ.get("JB_PIPELINE_LAUNCHES", "1") != "0" and not self.only_encode:
+        if want and not self.only_encode and os.environ.get("JB_PIPELINE_LAUNCHES", "") != "0":
             self.pipelined = L.lib().jb_engine_pipeline(self.handle, 1) == 0
 
     def set_pipelined(self, on):
-        """Switch software-pipelined launches of the decode step on / off; returns whether they are on."""
+        """Switch software-pipelined launches of the decode step on / off; returns whether they are on (they stay off for
+        shapes without pipelined kernels, while another engine has them, and under JB_PIPELINE_LAUNCHES=0)."""
+        if on and os.environ.get("JB_PIPELINE_LAUNCHES", "") == "0":
+            return False
+        if self.handle is None:
+            self.pipelined = bool(on)          # remembered for _create
+            return self.pipelined
         rc = L.lib().jb_engine_pipeline(self.handle, int(bool(on)))
         if on and rc != 0:
             self.pipelined = False

@@ -101,7 +101,18 @@ class ConditionalAutoregressive2D(nn.Module):
             self._engines[key] = PriorEngine(packed=packed, n_batch=n_samples, chunk_cap=chunk_cap,
                                              want_preds=want_preds)
         self._last_engine = self._engines[key]
+        self._apply_pipeline(self._last_engine)
         return self._last_engine
+
+    def _apply_pipeline(self, eng):
+        """Software-pipelined launches as the sampler asks for them: `pipeline_launches` is None (leave the engine alone), a
+        bool, or a callable that is asked again before every chunk of decode steps (the level pipeline: only while the level
+        runs alone)."""
+        want = getattr(self, "pipeline_launches", None)
+        if callable(want):
+            want = want()
+        if want is not None and eng.pipelined != bool(want):
+            eng.set_pipelined(bool(want))
 
     def packed(self, fp16):
         """This prior's weights in MFMA order for one engine dtype (built on first use, dropped when the module moves)."""
@@ -211,6 +222,7 @@ class ConditionalAutoregressive2D(nn.Module):
             pos = n_prime
             while pos < sample_tokens:
                 n = min(int(every), sample_tokens - pos)
+                self._apply_pipeline(eng)
                 eng.decode(pos, n)
                 fn(eng.tokens, pos, pos + n)
                 pos += n

@@ -107,6 +107,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         zbuf[l][:, :zs_local[l].shape[1]] = zs_local[l]
     ready_event = {}
     errors = []
+    finished = set()                                       # levels whose codes are complete (their streams drained)
     levels = sorted(sample_levels, reverse=True)
     on_gpu = str(device).startswith("cuda")            # on CPU (host-logic tests) the schedule runs without streams
     current = torch_cuda_current_stream(device) if on_gpu else None
@@ -193,6 +194,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 callback = getattr(_sample, "level_done", None)
                 if on_gpu:
                     stream.synchronize()
+                finished.add(level)
                 if callable(callback):
                     callback(level)
                 # This level's audio (VQVAE.decode of its codes, sample.py:105) right away, on the level's stream, while the
@@ -208,6 +210,16 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 errors.append(e)
                 cond.notify_all()
 
+    # Software-pipelined launches for the lowest level (the long pole) ONLY WHILE IT RUNS ALONE.  Its waiting launches keep
+    # most compute units occupied for good; a concurrent level's attention launch (216 registers per lane: an otherwise
+    # empty compute unit per workgroup) then hardly ever finds room -- measured on the 6-second job: 80 s plain, 176 s with
+    # level 0 pipelined from the start (level 1 at 1700 instead of 6300 tokens/s).  The engine checks before every chunk.
+    # OPT-IN (hps.pipeline_launches / JB_PIPELINE_LAUNCHES=1): even so the same job measured 84.5 s against 79.8 s plain --
+    # inside the multi-stream job the pipelined step ran at 5.8 ms instead of the 1.6 ms it takes in a process of its own
+    # (DESIGN.md section 4.2); not understood yet, so the job keeps the plain launch chain by default.
+    lowest = min(sample_levels)
+    if _want_pipelined_launches(hps) and getattr(priors[lowest], "prior", None) is not None:
+        priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
     # (level, window start, seconds into the job at which the window's sampling began / ended) per window: diagnostics
@@ -233,6 +245,12 @@ def _shard_labels(labels, lo, hi):
     return dict(y=labels["y"][lo:hi].contiguous(), info=labels["info"][lo:hi])
 
 
+def _want_pipelined_launches(hps):
+    """Software-pipelined launches of the decode step are opt-in for the sampler: hps.pipeline_launches or
+    JB_PIPELINE_LAUNCHES=1 (-15 % per token step for an engine that has the GPU to itself)."""
+    return bool(hps.get("pipeline_launches", False)) or os.environ.get("JB_PIPELINE_LAUNCHES", "") == "1"
+
+
 def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, device="cuda"):
     """sample.py:91-121 with n_samples sharded over the ranks.  `zs`, `labels` describe ALL hps.n_samples samples
     (identical on every rank -- see broadcast_conditioning); returns the full zs on every rank."""
@@ -254,6 +272,12 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
     alignments = None
     pipelined = bool(hps.get("pipeline_levels", False)) and hps.get("keep_priors_resident", False) \
         and len(sample_levels) > 1 and local_hps.n_samples > 0
+    # Software-pipelined launches (one engine per process at a time): the lowest level sampled has by far the most token
+    # steps (x4 per level) and is the long pole of the job; when the levels run one after the other, each in its turn.
+    ar = lambda p: getattr(p, "prior", None)               # the autoregressive model that owns the engine
+    for level in sample_levels:
+        if ar(priors[level]) is not None:
+            ar(priors[level]).pipeline_launches = False if pipelined else None   # (the level pipeline sets the lowest level's)
     if pipelined:
         for level in sample_levels:
             priors[level].to(device)
@@ -272,8 +296,17 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
         if local_hps.n_samples > 0 and not pipelined:
             if callable(getattr(_sample, "level_start", None)):
                 _sample.level_start(level)
-            zs_local = sample_level(zs_local, _shard_labels(labels[level], lo, hi), kw, level, prior, total_length,
-                                    hop_length, local_hps)
+            if ar(prior) is not None:
+                ar(prior).pipeline_launches = _want_pipelined_launches(hps)     # one level at a time: the GPU is this level's
+            try:
+                zs_local = sample_level(zs_local, _shard_labels(labels[level], lo, hi), kw, level, prior, total_length,
+                                        hop_length, local_hps)
+            finally:
+                if ar(prior) is not None:
+                    ar(prior).pipeline_launches = False        # the next level's engine may take them over
+                    eng = ar(prior).bound_engine() if hasattr(ar(prior), "bound_engine") else None
+                    if eng is not None:
+                        eng.set_pipelined(False)
         if not hps.get("keep_priors_resident", False):
             prior.cpu()                          # sample.py:104: drops the engine's device copies
             empty_cache()
