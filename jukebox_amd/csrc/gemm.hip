@@ -77,18 +77,14 @@ struct EpiParams {
     const float* add2; int64_t add2_n, add2_t;
 };
 
-// One element of an output row: plain, or write-through (SC1) for a consumer launch that is already running (JbPipe).
-template <typename T, bool SC1> __device__ __forceinline__ void out_store(T* base, int64_t el, float x) {
-    if constexpr (SC1) jb_st_sc1(base, el, (T)x); else base[el] = (T)x;
-}
 // Column j of a q/k/v(/v') projection goes to the query row or to row `cache_row` of the matching cache.
-template <typename T, bool SC1 = false>
+template <typename T>
 __device__ __forceinline__ void qkv_store(const EpiParams& p, float x, int64_t orow, int j, int64_t cache_row) {
-    if (j < p.S) { out_store<T, SC1>((T*)p.out, orow * p.ldo + j, x); return; }
+    if (j < p.S) { ((T*)p.out)[orow * p.ldo + j] = (T)x; return; }
     if (cache_row < 0) return;
-    if (j < 2 * p.S) out_store<T, SC1>((T*)p.kcache, cache_row * p.S + (j - p.S), x);
-    else if (j < 2 * p.S + p.v_cols) out_store<T, SC1>((T*)p.vcache, cache_row * p.S + (j - 2 * p.S), x);
-    else out_store<T, SC1>((T*)p.vcache2, cache_row * p.v2w + (j - 2 * p.S - p.v_cols), x);
+    if (j < 2 * p.S) ((T*)p.kcache)[cache_row * p.S + (j - p.S)] = (T)x;
+    else if (j < 2 * p.S + p.v_cols) ((T*)p.vcache)[cache_row * p.S + (j - 2 * p.S)] = (T)x;
+    else ((T*)p.vcache2)[cache_row * p.v2w + (j - 2 * p.S - p.v_cols)] = (T)x;
 }
 
 // vals[r] is the accumulator of column jb + r of output row `orow`; cache_row < 0 disables the k/v write.
@@ -138,18 +134,18 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& p, f32x4 acc, in
 }
 
 // One output element (decode GEMV epilogue, spread over all threads of the workgroup).
-template <typename T, bool SC1 = false>
+template <typename T>
 __device__ __forceinline__ void epilogue_store1(const EpiParams& p, float x, int64_t orow, int j, int64_t cache_row,
                                                 float bias_v, float res_v, float add2_v = 0.f) {
     if (p.bias) x += jb_round<T>(bias_v);
     x = jb_round<T>(x);
     x = jb_apply_act<T>(x, p.act);
     if (p.res) x = (p.res_scale == 1.0f) ? jb_round<T>(res_v + x) : jb_round<T>(res_v + jb_round<T>(p.res_scale * x));
-    if (p.out2) out_store<float, SC1>(p.out2, orow * p.ldo2 + j, x + add2_v);
+    if (p.out2) p.out2[orow * p.ldo2 + j] = x + add2_v;
     if (!p.qkv_split) {
-        out_store<T, SC1>((T*)p.out, orow * p.ldo + j, x);
+        ((T*)p.out)[orow * p.ldo + j] = (T)x;
     } else {
-        qkv_store<T, SC1>(p, x, orow, j, cache_row);
+        qkv_store<T>(p, x, orow, j, cache_row);
     }
 }
 
