@@ -163,7 +163,9 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                     if (level + 1) in zbuf:
                         view[level + 1] = zbuf[level + 1]          # only [start/cd, end/cd) is read: published above
                     known = int(zs_local[level].shape[1])
-                    tapped = local_hps.n_samples <= k["max_batch_size"] and chunk > 0
+                    # partial windows are published for the level BELOW; the lowest level sampled has no consumer and
+                    # decodes a window in one call
+                    tapped = local_hps.n_samples <= k["max_batch_size"] and chunk > 0 and (level - 1) in sample_levels
 
                     def publish(lo, hi, tok, start=start, known=known):
                         # window-relative music tokens [lo, hi), all new (the primed part is never decoded)

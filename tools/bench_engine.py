@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--prio", type=int, default=None, help="run on a torch stream of this priority (-1 = high) instead of the default stream")
+    ap.add_argument("--plain-first", type=int, default=0, help="run this many plain graph-replayed steps before switching the engine to pipelined launches")
+    ap.add_argument("--noise-streams", type=int, default=0, help="touch this many extra torch streams first (hardware-queue pressure)")
     ap.add_argument("--pipelined", type=int, default=-1, help="1 / 0: software-pipelined launches on / off (default: the engine's choice)")
     a = ap.parse_args()
     cfg = CFGS[a.model]
@@ -78,11 +80,21 @@ def main():
     if cfg.get("encoder_dims"):
         eng.set_encoder_kv(torch.randn(a.batch, cfg["encoder_dims"], cfg["width"], device=dev) * 0.1)
     del sd
+    if a.plain_first:
+        eng.set_pipelined(False)
+        eng.decode(a.t0, a.plain_first, use_graph=True)
+        torch.cuda.synchronize()
     if a.pipelined >= 0:
         eng.set_pipelined(bool(a.pipelined))
     torch.cuda.synchronize()
     print(f"model={a.model} N={a.batch} dtype={'f32' if a.fp32 else 'f16'} weights={eng.weight_bytes() / 1e9:.2f} GB "
           f"kv={eng.cache_bytes() / 1e9:.2f} GB launches/step={eng.launches_per_step} pipelined={eng.pipelined}")
+    noise = []
+    for i in range(a.noise_streams):
+        st = torch.cuda.Stream(device=dev, priority=-1 if i % 2 == 0 else 0)
+        with torch.cuda.stream(st):
+            noise.append((st, torch.zeros(1024, device=dev).add_(1)))
+    torch.cuda.synchronize()
     if a.prio is not None:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=a.prio))
     for use_graph in ([False] if a.eager else [False, True]):
