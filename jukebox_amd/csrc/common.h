@@ -162,7 +162,8 @@ __device__ __forceinline__ float jb_load_any(const void* p, int dtype, int64_t i
 // times (slot 0 follows the last slot of the previous step: i times), and only then reads what the producer wrote -- with
 // sc1 loads (L1 bypass; the producer stored write-through and drained before it took its ticket), no cache-wide
 // invalidate or write-back anywhere.  Data of launches j-2 and older is ordinary: the same stream ordered it.
-// Polls are bounded (2 s of the 100 MHz clock): a timeout records slot + 1 in *err and goes on.
+// Polls are bounded (2 s of the 100 MHz clock): a timeout records slot + 1 in *err and goes on; every later wait gives up as
+// soon as it sees the error word set (the caller clears it), so a failed call ends in about one bound, not one per launch.
 // Measured alternatives (round 3, upsampler step): ONE ticket word for all 120-180 workgroups -- its returning atomics
 // serialise; the last workgroup of a shard ADDING to the polled word with a fire-and-forget atomic instead of the
 // second ticket + flag store -- 1.71 vs 1.59 ms per step: a word that is being polled must be written once, by a store.
@@ -216,7 +217,12 @@ __device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own) {
             unsigned spins = 0;
             while (jb_ld_word(w) < need) {
                 __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 255u) == 0 && wall_clock64() - t0 > P.timeout) { jb_st_word(P.err, (unsigned)P.slot + 1u); break; }
+                if ((++spins & 255u) == 0) {
+                    // the error word is sticky: once ONE wait of this engine has timed out, the tokens are void and the
+                    // remaining launches of the call must not each sit out their own bound (290 waits per step)
+                    if (jb_ld_word(P.err) != 0u) break;
+                    if (wall_clock64() - t0 > P.timeout) { jb_st_word(P.err, (unsigned)P.slot + 1u); break; }
+                }
             }
         }
         if (stamp) P.dbg[P.slot * 4 + 1] = wall_clock64();

@@ -290,6 +290,17 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
         if (g_pipe_owner && g_pipe_owner != e) JB_UNSUPPORTED("another engine of this process runs pipelined launches (one at a time: "
                                                               "switch it off or destroy it first)");
         g_pipe_owner = e;
+        if (enable == 2) {        // a fresh pair of streams and fresh graphs at the next decode (the engine must be idle)
+            for (int k = 0; k < 2; ++k) {
+                if (e->pexec[k]) (void)hipGraphExecDestroy(e->pexec[k]);
+                if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
+                if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+                if (e->pstream[k]) (void)hipStreamDestroy(e->pstream[k]);
+                e->pexec[k] = nullptr; e->pgraph[k] = nullptr; e->ev_join[k] = nullptr; e->pstream[k] = nullptr;
+            }
+            if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+            e->ev_fork = nullptr;
+        }
     } else if (g_pipe_owner == e) {
         g_pipe_owner = nullptr;
     }

@@ -302,15 +302,16 @@ class PriorEngine:
         if want and not self.only_encode and os.environ.get("JB_PIPELINE_LAUNCHES", "") != "0":
             self.pipelined = L.lib().jb_engine_pipeline(self.handle, 1) == 0
 
-    def set_pipelined(self, on):
+    def set_pipelined(self, on, fresh=False):
         """Switch software-pipelined launches of the decode step on / off; returns whether they are on (they stay off for
-        shapes without pipelined kernels, while another engine has them, and under JB_PIPELINE_LAUNCHES=0)."""
+        shapes without pipelined kernels, while another engine has them, and under JB_PIPELINE_LAUNCHES=0).  `fresh`: drop
+        the engine's pair of streams and its captured graphs, the next decode makes new ones (diagnostics)."""
         if on and os.environ.get("JB_PIPELINE_LAUNCHES", "") == "0":
             return False
         if self.handle is None:
             self.pipelined = bool(on)          # remembered for _create
             return self.pipelined
-        rc = L.lib().jb_engine_pipeline(self.handle, int(bool(on)))
+        rc = L.lib().jb_engine_pipeline(self.handle, (2 if fresh else 1) if on else 0)
         if on and rc != 0:
             self.pipelined = False
             return False
@@ -328,6 +329,10 @@ class PriorEngine:
     def pipe_error(self):
         """0, or slot + 1 of a pipelined launch whose wait for its producer timed out (sticky)."""
         return int(self.pipe_words[10 * self.launches_per_step * 32].item())
+
+    def clear_pipe_error(self):
+        """Forget a recorded timeout (the engine must be idle).  Until then every pipelined wait gives up at once."""
+        self.pipe_words[10 * self.launches_per_step * 32] = 0
 
     def close(self):
         if getattr(self, "handle", None):

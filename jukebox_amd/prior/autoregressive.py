@@ -3,6 +3,7 @@
 the HIP decode engine (jukebox_amd.engine.PriorEngine): one hipGraph replay per token, chunked MFMA
 prefill for the primed part; nothing is computed in torch."""
 import math
+import os
 
 import numpy as np
 import torch as t
@@ -100,9 +101,40 @@ class ConditionalAutoregressive2D(nn.Module):
         if key not in self._engines:
             self._engines[key] = PriorEngine(packed=packed, n_batch=n_samples, chunk_cap=chunk_cap,
                                              want_preds=want_preds)
-        self._last_engine = self._engines[key]
-        self._apply_pipeline(self._last_engine)
-        return self._last_engine
+        eng = self._engines.pop(key)
+        self._engines[key] = eng                     # dicts keep insertion order: most recently used last
+        self._evict_engines()
+        self._last_engine = eng
+        self._apply_pipeline(eng)
+        return eng
+
+    def engine_cache_budget(self):
+        """Bytes of k/v caches this prior keeps bound across calls (`engine_cache_bytes` attribute, JB_ENGINE_CACHE_GB, or 30 %
+        of the device's memory: one 16-sample upsampler engine is 54 GB, 36 GB of it the wide-value cache)."""
+        b = getattr(self, "engine_cache_bytes", None)
+        if b is None and os.environ.get("JB_ENGINE_CACHE_GB"):
+            b = float(os.environ["JB_ENGINE_CACHE_GB"]) * 1e9
+        if b is None:
+            dev = self.x_emb.weight.device
+            b = 0.3 * t.cuda.get_device_properties(dev).total_memory if dev.type == "cuda" else float("inf")
+        return b
+
+    def _evict_engines(self):
+        """Least recently used engines go while the bound caches exceed the budget; the one just asked for always stays.
+        The packed weights are shared and stay."""
+        budget = self.engine_cache_budget()
+        keys = list(self._engines)
+        total = sum(self._engines[k].cache_bytes() for k in keys)
+        for k in keys[:-1]:
+            if total <= budget:
+                break
+            eng = self._engines.pop(k)
+            total -= eng.cache_bytes()
+            if eng is self._last_engine:
+                self._last_engine = None
+            if self.x_emb.weight.device.type == "cuda":
+                t.cuda.synchronize(self.x_emb.weight.device)     # its graphs and buffers may still be in flight (rare path)
+            eng.close()
 
     def _apply_pipeline(self, eng):
         """Software-pipelined launches as the sampler asks for them: `pipeline_launches` is None (leave the engine alone), a

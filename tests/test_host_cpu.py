@@ -413,3 +413,39 @@ def test_engine_layer_policy_without_a_gpu(monkeypatch):
             eng.layers_c[1].vcache_w = keep
             eng._create()
         eng.close()
+
+
+def test_engine_cache_is_bounded_lru(monkeypatch):
+    """ConditionalAutoregressive2D.engine keeps engines bound per (batch, dtype, want_preds) within a byte budget of k/v
+    caches: the least recently used go first, the one just asked for always stays, the packed weights are shared."""
+    from jukebox_amd.prior import autoregressive as A
+
+    closed = []
+
+    class FakeEngine:
+        pipelined = False
+
+        def __init__(self, packed=None, n_batch=1, chunk_cap=0, want_preds=False):
+            self.n_batch, self.handle = n_batch, object()
+
+        def cache_bytes(self):
+            return self.n_batch * 10
+
+        def close(self):
+            closed.append(self.n_batch)
+            self.handle = None
+
+    monkeypatch.setattr(A, "PriorEngine", FakeEngine)
+    prior = A.ConditionalAutoregressive2D(input_shape=(32,), bins=16, width=32, depth=2, heads=1, blocks=4, attn_order=0)
+    monkeypatch.setattr(prior, "packed", lambda fp16: "packed")
+    prior.engine_cache_bytes = 250
+    e16 = prior.engine(16, True)
+    e8 = prior.engine(8, True)
+    assert prior.engine(16, True) is e16 and not closed                  # 240 bytes bound, both stay; 16 is now the newest
+    e4 = prior.engine(4, True)                                           # 280 > 250: the least recently used (8) goes
+    assert closed == [8] and e8.handle is None and prior.engine(16, True) is e16 and prior.engine(4, True) is e4
+    big = prior.engine(30, False)                                        # larger than the budget alone: it stays, alone
+    assert sorted(closed) == [4, 8, 16] and prior.bound_engine() is big and list(prior._engines) == [(30, False, False)]
+    monkeypatch.setenv("JB_ENGINE_CACHE_GB", "1")
+    del prior.engine_cache_bytes
+    assert prior.engine_cache_budget() == 1e9

@@ -56,6 +56,22 @@ def step_bytes(cfg, N, t, esz):
     return D * per_layer_w + kv + B * W * 4
 
 
+def report_stamps(eng, indent="    "):
+    """JB_PIPE_DEBUG=1: where the last pipelined step spent its time, per kind of launch (workgroup 0's stamps)."""
+    import numpy as np
+    st = eng.pipe_stamps().astype(np.float64) * 0.01          # us: poll entered, producer seen, published (last workgroup), stores issued
+    n = st.shape[0]
+    entered, seen, published, issued = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+    kinds = ["c_attn", "attention", "c_fc", "c_proj"]
+    for k in range(4):
+        idx = np.arange(8 + k, n - 3, 4)
+        print(f"{indent}{kinds[k]:10s} consumer sees it - it saw its producer {np.mean(seen[idx + 1] - seen[idx]):6.2f} us = inputs seen -> "
+              f"stores issued {np.mean(issued[idx] - seen[idx]):5.2f} + drain, tickets {np.mean(published[idx] - issued[idx]):5.2f} + "
+              f"propagation {np.mean(seen[idx + 1] - published[idx]):5.2f} | poll entered {np.mean(seen[idx] - entered[idx]):5.2f} before the "
+              f"producer was seen, {np.mean(entered[idx + 2] - published[idx]):6.2f} after its same-stream predecessor published")
+    print(f"{indent}whole step by the stamps: {seen[n - 1] - seen[1]:8.1f} us for slots 1..{n - 1}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("model", nargs="?", default="up")
@@ -108,16 +124,7 @@ def main():
         if use_graph and eng.pipelined and eng.pipe_error():
             print("  !! pipelined launch timed out waiting for slot", eng.pipe_error() - 1)
         if use_graph and eng.pipelined and os.environ.get("JB_PIPE_DEBUG"):
-            import numpy as np
-            st = eng.pipe_stamps().astype(np.float64) * 0.01          # us: poll entered, producer seen, -, stores issued (workgroup 0)
-            n = st.shape[0]
-            seen, issued = st[:, 1], st[:, 3]
-            kinds = ["c_attn", "attention", "c_fc", "c_proj"]
-            for k in range(4):
-                idx = np.arange(8 + k, n - 3, 4)
-                print(f"    {kinds[k]:10s} consumer sees it - it saw its producer {np.mean(seen[idx + 1] - seen[idx]):6.2f} us = inputs seen -> "
-                      f"stores issued {np.mean(issued[idx] - seen[idx]):5.2f} + drain, tickets, propagation {np.mean(seen[idx + 1] - issued[idx]):5.2f}"
-                      f" | poll entered {np.mean(seen[idx] - st[idx, 0]):5.2f} before the producer was seen")
+            report_stamps(eng)
         print(f"  graph={use_graph}: {dt * 1e3:.3f} ms/step  algorithmic {b / 1e9:.3f} GB/step -> {b / dt / 1e12:.2f} TB/s "
               f"({b / dt / 8e12 * 100:.1f}% of 8 TB/s)")
 

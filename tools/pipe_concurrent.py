@@ -1,5 +1,6 @@
-"""Two pipelined upsampler engines and a plain one decoding side by side from three host threads, as the level pipeline
-runs them: ms per step each, whether an engine kept its pipelined launches, and the error words."""
+"""Three upsampler engines decoding side by side from three host threads, as the level pipeline runs them; engine 0 asks for
+pipelined launches, engine 1 asks too and is refused (one pipelined engine per process), engine 2 is plain: ms per step
+each, whether an engine has pipelined launches, and the error words."""
 import sys, threading, time
 import torch
 sys.path.insert(0, ".")
@@ -15,7 +16,7 @@ for i in range(3):
     e.set_cond(torch.randn(16, cfg["seq_len"], cfg["width"], device=dev) * 0.01, torch.randn(16, 1, cfg["width"], device=dev) * 0.01)
     e.set_sampling(temp=0.99, seed=i)
     engs.append(e)
-engs[2].set_pipelined(False)
+print("pipelined launches granted:", [e.set_pipelined(i < 2) for i, e in enumerate(engs)], flush=True)
 STEPS = 256
 
 
