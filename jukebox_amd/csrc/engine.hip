@@ -344,14 +344,19 @@ static int streams_overlap(hipStream_t a, hipStream_t b, unsigned* scratch /* de
 // in, so these streams must not share a queue with each other (deadlock) nor with anybody else (everything behind a waiter
 // crawls: measured, the 3-level job went from 80 to 128 s when the side stream was an ordinary pooled stream).  HIP gives
 // no handle on the stream -> queue mapping, except that a stream created with a compute-unit mask gets a hardware queue
-// with that mask: two masks that differ in one bit (all 256 compute units / all but one) are two queues of their own.  The
+// with that mask: two masks that differ (each all compute units but one) are two queues of their own.  The
 // pair is still verified with the handshake above.  The caller's stream only forks to and joins from them with events.
 static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mutex
     unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(jb_engine_launches_per_step(e)) - JB_PIPE_PAD + 8;
+    // every pair of the process gets two masks nobody else has (each leaves out ONE compute unit of 256): should the runtime
+    // key hardware queues by mask, two engines' pairs still never meet in one queue
+    static int g_pairs = 0;
+    const int pair = g_pairs++;
     uint32_t mask[8];
     for (int k = 0; k < 2; ++k) {
         for (int w = 0; w < 8; ++w) mask[w] = 0xffffffffu;
-        if (k == 1) mask[7] = 0x7fffffffu;
+        const int bit = 255 - (2 * pair + k) % 256;
+        mask[bit >> 5] &= ~(1u << (bit & 31));
         JB_HIP(hipExtStreamCreateWithCUMask(&e->pstream[k], 8, mask));
     }
     const int ov = streams_overlap(e->pstream[0], e->pstream[1], scratch);

@@ -150,9 +150,14 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                     if prior.x_cond and (level + 1) in sample_levels:
                         need = (start + prior.n_ctx) // prior.cond_downsample
                         with cond:
-                            cond.wait_for(lambda: progress[level + 1] >= need or errors)
+                            cond.wait_for(lambda: progress[level + 1] >= need or errors or (level + 1) in finished)
                             if errors:
                                 return
+                            # the upper level is complete and still too short for this window: the sequential loop fails
+                            # the same way (prior.get_z_conds asserts the conditioning length, prior.py:158-166)
+                            assert progress[level + 1] >= need, (
+                                f"level {level}: the window at {start} is conditioned on {need} codes of level {level + 1}, which "
+                                f"has only {progress[level + 1]} -- sample_length is shorter than this level's context")
                             ev = ready_event.get(level + 1)
                         if ev is not None:
                             stream.wait_event(ev)
@@ -196,7 +201,9 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 callback = getattr(_sample, "level_done", None)
                 if on_gpu:
                     stream.synchronize()
-                finished.add(level)
+                with cond:
+                    finished.add(level)
+                    cond.notify_all()
                 if callable(callback):
                     callback(level)
                 # This level's audio (VQVAE.decode of its codes, sample.py:105) right away, on the level's stream, while the

@@ -162,6 +162,19 @@ def test_pipelined_levels_on_cpu(chunk):
         assert sorted(a.calls) == sorted(b.calls)
 
 
+def test_pipelined_levels_refuse_a_total_length_below_a_lower_context():
+    """A job shorter than a lower level's context (here level 1: 8192 tokens = 2048 top-level codes, the top level has 757)
+    fails in the sequential loop on get_z_conds' length assertion; the level pipeline must fail too, not wait for upper-level
+    codes that will never come."""
+    priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=757)
+    with pytest.raises(AssertionError):
+        S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
+    priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=757)
+    hps.keep_priors_resident, hps.pipeline_levels = True, True
+    with pytest.raises(AssertionError, match="shorter than this level's context"):
+        S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
+
+
 def test_primed_continue_and_partial_window():
     """continue_sample from existing codes (sample.py:131-134) and a short top level (sample_partial_window)."""
     n, top = 4, 8192 + 2048

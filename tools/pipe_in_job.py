@@ -1,13 +1,12 @@
 """Why are software-pipelined launches slow INSIDE the 3-level job?  (finding 3.)
 
-One process, one GPU call: a reference engine (random upsampler, short caches) is timed plain / pipelined BEFORE a short
-3-level job (1b_lyrics, 16 samples, --seconds of audio, level pipeline, level 0 pipelined while it runs alone), then the
-job's own level-0 engine and the reference engine are timed again in the state the job leaves the process in:
+One process, one GPU call: a short 3-level job (1b_lyrics, 16 samples, --seconds of audio, level pipeline, level 0 pipelined
+while it runs alone), then the job's own level-0 engine is timed in the state the job leaves the process in:
   A  the job's engine as it is (64- and 256-step calls, per-slot stamps), then its plain chain
   B  the same engine with a fresh pair of streams and fresh graphs
-  C  the reference engine created before the job (its streams are older than every stream of the job)
-  D  a reference engine created now
-Usage: JB_PIPE_TIMEOUT_MS=100 python tools/pipe_in_job.py [--seconds 1.5]"""
+  D  a reference engine (random upsampler, short caches) created now
+  E  the job's engine from a worker thread on a side stream
+Usage: JB_PIPE_TIMEOUT_MS=50 python -u tools/pipe_in_job.py [--seconds 6]"""
 import argparse
 import os
 import sys
@@ -59,18 +58,11 @@ def reference_engine(dev, seq_len=2048):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=1.5)
+    ap.add_argument("--seconds", type=float, default=6.0, help="at least 5.95: level 1 needs a full context")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     sr = 44100
     sample_length = int(a.seconds * sr) // 128 * 128
-
-    ref = reference_engine(dev)
-    ref.set_pipelined(False)
-    measure("before the job, reference engine, plain", ref, 1024, stamps=False)
-    assert ref.set_pipelined(True)
-    measure("before the job, reference engine", ref, 1024)
-    ref.set_pipelined(False)
 
     vq, priors = bench.build_models("1b_lyrics", sample_length, dev)
     hps = Hyperparams(n_samples=16, sample_length=sample_length, hop_fraction=[0.5, 0.5, 0.125], sr=sr, name="pipe_in_job",
@@ -90,21 +82,26 @@ def main():
 
     eng = priors[0].prior.bound_engine()
     print(f"job's level-0 engine: pipelined={eng.pipelined} error word {eng.pipe_error()}")
-    if not eng.pipelined:
+    if eng.pipelined:
+        print("   stamps of the job's last pipelined step:")
+        BE.report_stamps(eng, indent="      ")
+    else:
         print("   enabling:", eng.set_pipelined(True))
+    eng.clear_pipe_error()
     measure("A  job's engine as the job left it", eng, 4096)
+    eng.clear_pipe_error()
     eng.set_pipelined(False)
     measure("A' job's engine, plain chain", eng, 4096, stamps=False)
     print("   fresh streams + graphs:", eng.set_pipelined(True, fresh=True))
     measure("B  job's engine, fresh pair of streams", eng, 4096)
+    eng.clear_pipe_error()
     eng.set_pipelined(False)
-    assert ref.set_pipelined(True)
-    measure("C  reference engine made before the job", ref, 1024)
-    ref.set_pipelined(False)
     ref2 = reference_engine(dev)
     assert ref2.set_pipelined(True)
     measure("D  reference engine made now", ref2, 1024)
     ref2.set_pipelined(False)
+    ref2.set_pipelined(False)
+    measure("D' the same reference engine, plain chain", ref2, 1024, stamps=False)
     # the job's engine once more, from a thread of its own on a side stream (as the level pipeline calls it)
     import threading
     eng.set_pipelined(True)
