@@ -28,3 +28,15 @@ def tiny_hps():
     import json
     with open(os.path.join(GOLDEN, "tiny_hps.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _gpu_memory_share():
+    """JB_TEST_GPU_MEM_FRACTION=f: cap this process's share of the GPU's memory (torch's allocator raises instead of
+    exhausting the device) -- for running the GPU suite as several pytest-xdist workers on one GPU (`-n 2`, f = 0.45)."""
+    f = os.environ.get("JB_TEST_GPU_MEM_FRACTION")
+    if f:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_per_process_memory_fraction(float(f), 0)
+    yield
