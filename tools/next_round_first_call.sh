@@ -1,21 +1,21 @@
 #!/bin/bash
-# First GPU call of the next round (run through gpurun from the repo root; ~9 minutes of box time):
-#   1. the whole GPU suite on the tree the round starts from (the wide-value tree was validated file by file, never in
-#      one run: profiles/README.md, r02_wide_* rows);
-#   2. the PMC passes on the dominant kernel in its wide-value shapes (roofline.traffic is null until this exists);
-#   3. the driver's bench command against a short wall budget (first full-length measurement of the wide-value tree).
-# Then (separate, ~1 minute): `git checkout wip/pipelined-launch -- tools/pipelined_launch_probe.hip`, build it with hipcc and run
-# it -- DESIGN.md section 8 item 1 says what its numbers decide.
-# Outputs land in gpurun_out/; copy what is to be judged into profiles/ (r03_*).
+# First GPU calls of the next round (through gpurun from the repo root).  Outputs land in gpurun_out/; copy what is to be
+# judged into profiles/ (r04_*).  Always `python -u` and a `timeout` of your own: a call that runs into gpurun's limit is lost.
+#
+#   call A (~4 min): why are software-pipelined launches slow inside the three-level job?  (finding 3)
+#       JB_PIPE_TIMEOUT_MS=50 timeout 200 python -u tools/pipe_in_job.py --seconds 6 > gpurun_out/r04_pipe_in_job.log 2>&1
+#     reads: A (job's engine as left) vs A' (plain) vs B (fresh streams) vs D (new engine) vs E (worker thread), each with the
+#     per-call / per-step split and the per-slot stamps.  B fast -> create the pair when the level becomes the only one running;
+#     D slow too -> process state (count HSA queues: rocprofv3 --hsa-trace of a 64-step call); only A slow -> engine state.
+#   call B (~1.5 min): the prefill-GEMM candidate against the library kernel, bit-for-bit and timed
+#       hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I tools tools/gemm_glds_probe.hip -L jukebox_amd/csrc -ljukebox_hip \
+#             -Wl,-rpath,$PWD/jukebox_amd/csrc -o tools/gemm_glds_probe     (build HERE, the binary travels)
+#       timeout 120 tools/gemm_glds_probe > gpurun_out/r04_gemm_glds_probe.log 2>&1
+#     EQUAL + >= 800 TFLOP/s on the 32768-row shapes -> move the kernel into gemm.hip behind jb_gemm's flat fp16 path.
+#   call C (this script, ~11 min): the whole GPU suite in ONE process (two xdist workers were no faster: the long cases wait for
+#     the CPU oracle) and the driver's bench command against a short wall budget.
 export PYTHONPATH=$PWD TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 420 python -m pytest tests -q -x -m gpu > gpurun_out/r03_gpu_tests.log 2>&1; tail -3 gpurun_out/r03_gpu_tests.log
-for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf gpurun_out/pmc_$c
-    timeout 120 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python tools/pmc_target.py --wide > gpurun_out/pmc_$c.log 2>&1
-    find gpurun_out/pmc_$c -name "*counter_collection.csv" -exec cp {} gpurun_out/r03_pmc_${c}_counter_collection_wide.csv \;
-done
-python tools/pmc_summary.py gpurun_out/r03_pmc_FETCH_SIZE_counter_collection_wide.csv gpurun_out/r03_pmc_WRITE_SIZE_counter_collection_wide.csv \
-    gemv_lnf gpurun_out/r03_pmc_dominant_kernel_wide.json --wide | tail -8
-JB_BENCH_BUDGET_S=420 JB_BENCH_TIMELINE=1 timeout 560 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench_full_1gpu.json 2> gpurun_out/r03_bench_full_1gpu.err
-cut -c1-600 gpurun_out/r03_bench_full_1gpu.json
+timeout 700 python -u -m pytest tests -q -m gpu -p no:cacheprovider > gpurun_out/r04_gpu_tests.log 2>&1; tail -3 gpurun_out/r04_gpu_tests.log
+JB_BENCH_BUDGET_S=420 JB_BENCH_TIMELINE=1 timeout 560 python -u bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04_bench_full_1gpu.json 2> gpurun_out/r04_bench_full_1gpu.err
+cut -c1-600 gpurun_out/r04_bench_full_1gpu.json
