@@ -4,6 +4,9 @@
 #
 #   call A (~4 min): why are software-pipelined launches slow inside the three-level job?  (finding 3)
 #       JB_PIPE_TIMEOUT_MS=50 timeout 200 python -u tools/pipe_in_job.py --seconds 6 > gpurun_out/r04_pipe_in_job.log 2>&1
+#     and once more with GPU_MAX_HW_QUEUES=4 in front (the package raises the runtime's default of 4 to 8 -- jukebox_amd/__init__.py --
+#     which was only ever tested in tools/bench_engine.py, never inside the job: with two priority classes in use that is up to
+#     16 pooled hardware queues + the two CU-mask queues, close to what the hardware scheduler maps at once).
 #     reads: A (job's engine as left) vs A' (plain) vs B (fresh streams) vs D (new engine) vs E (worker thread), each with the
 #     per-call / per-step split and the per-slot stamps.  B fast -> create the pair when the level becomes the only one running;
 #     D slow too -> process state (count HSA queues: rocprofv3 --hsa-trace of a 64-step call); only A slow -> engine state.
