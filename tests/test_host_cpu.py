@@ -449,3 +449,62 @@ def test_engine_cache_is_bounded_lru(monkeypatch):
     monkeypatch.setenv("JB_ENGINE_CACHE_GB", "1")
     del prior.engine_cache_bytes
     assert prior.engine_cache_budget() == 1e9
+
+
+def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
+    """jb_engine_pipeline's host logic (no launch happens before the first decode): which engines are eligible (fp16, <= 16
+    samples, wide-value layers of one 480-channel head, key sets <= 128), ONE owner per process, release by switching off
+    or by destroying the engine, JB_PIPELINE_LAUNCHES=0 forbids, enable = 2 is accepted on an engine without streams."""
+    from jukebox_amd import _lib as L
+    from jukebox_amd import engine as E
+    from jukebox_amd import hip_ops as H
+
+    def fake_pack(w, K, J, sk, sj, dtype, out=None, offset_elems=0):
+        code = L.dtype_code(dtype)
+        n = L.lib().jb_packed_weight_bytes(K, J, code) // (2 if code == L.F16 else 4)
+        return out if out is not None else torch.zeros(n, dtype=dtype)
+
+    monkeypatch.setattr(H, "pack_weight", fake_pack)
+    monkeypatch.setattr(H, "make_sample_params", lambda *a, device="cpu", **k: torch.zeros(8, dtype=torch.int64))
+    for k in ("JB_WIDE_V", "JB_FOLD_LN", "JB_ATTN_SPLIT_OFF", "JB_PIPELINE_LAUNCHES"):
+        monkeypatch.delenv(k, raising=False)
+
+    def state(W, depth, bins, T):
+        S = W // 4
+        sd = {"x_emb.weight": torch.randn(bins, W), "pos_emb.pos_emb": torch.randn(T, W), "start_token": torch.randn(1, W)}
+        sd["x_out.weight"] = sd["x_emb.weight"]
+        for d in range(depth):
+            p = f"transformer._attn_mods.{d}."
+            for nm, shape in (("attn.c_attn", (W, 3 * S)), ("attn.c_proj", (S, W)), ("mlp.c_fc", (W, W)), ("mlp.c_proj", (W, W))):
+                sd[p + nm + ".w"], sd[p + nm + ".b"] = torch.randn(*shape) * 0.02, torch.zeros(shape[1])
+            for ln in ("ln_0", "ln_1"):
+                sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(W), torch.zeros(W)
+        return sd
+
+    def engine(W=1920, heads=1, fp16=True, n_batch=4, T=512, blocks=8):
+        e = E.PriorEngine(state(W, 2, 64, T), "", n_batch=n_batch, seq_len=T, bins=64, width=W, depth=2, heads=heads,
+                          attn_order=2, blocks=blocks, y_cond=False, fp16=fp16, device="cpu")
+        e.set_cond(None, None)
+        return e
+
+    a, b = engine(), engine()
+    assert not a.pipelined and not b.pipelined                     # opt-in: nothing asks by default
+    assert a.set_pipelined(True) is True and a.pipelined
+    assert b.set_pipelined(True) is False and not b.pipelined      # one owner per process
+    assert a.set_pipelined(False) is False
+    assert b.set_pipelined(True) is True
+    assert a.set_pipelined(True) is False
+    b.close()                                                      # destroying the owner releases the right
+    assert a.set_pipelined(True, fresh=True) is True               # enable = 2 on an engine that never made its streams
+    a.set_pipelined(False)
+    for kw in (dict(heads=2, W=256), dict(fp16=False), dict(n_batch=32), dict(T=16384, blocks=64)):   # last: 256-key block sets
+        e = engine(**kw)
+        assert e.set_pipelined(True) is False and not e.pipelined, kw
+        e.close()
+    monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "0")
+    assert a.set_pipelined(True) is False
+    monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1")                # every eligible engine asks as it is created; the first wins
+    c, d = engine(), engine()
+    assert c.pipelined and not d.pipelined
+    for e in (a, c, d):
+        e.close()
