@@ -3,7 +3,11 @@
 # judged into profiles/ (r04_*).  Always `python -u` and a `timeout` of your own: a call that runs into gpurun's limit is lost.
 #
 #   call A (~4 min): why are software-pipelined launches slow inside the three-level job?  (finding 3)
-#       JB_PIPE_TIMEOUT_MS=50 timeout 200 python -u tools/pipe_in_job.py --seconds 6 > gpurun_out/r04_pipe_in_job.log 2>&1
+#       AMD_LOG_LEVEL=2 JB_PIPE_TIMEOUT_MS=50 timeout 200 python -u tools/pipe_in_job.py --seconds 6 > gpurun_out/r04_pipe_in_job.log 2>&1
+#     (AMD_LOG_LEVEL=2: the runtime's warnings -- grep the log for "Packet capture failed" / "Failed to allocate kernel argument
+#     pool": hipGraphLaunch has a slow per-node path when an executable graph could not get its pre-built packets, and the
+#     in-job numbers -- 2.96 ms per step = 290 x 10 us, whatever the GPU does -- look like a host-bound enqueue.  The tool prints the
+#     host's enqueue time next to the total: equal -> the graph launches are the bottleneck, not the GPU.)
 #     and once more with GPU_MAX_HW_QUEUES=4 in front (the package raises the runtime's default of 4 to 8 -- jukebox_amd/__init__.py --
 #     which was only ever tested in tools/bench_engine.py, never inside the job: with two priority classes in use that is up to
 #     16 pooled hardware queues + the two CU-mask queues, close to what the hardware scheduler maps at once).

@@ -28,19 +28,23 @@ from jukebox_amd.hparams import Hyperparams  # noqa: E402
 
 
 def ms_per_step(eng, t0, n):
+    """(ms per step until the GPU is done, ms per step the HOST spent enqueueing)"""
     torch.cuda.synchronize()
     t = time.perf_counter()
     eng.decode(t0, n, use_graph=True)
+    t_host = time.perf_counter()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t) / n * 1e3
+    return (time.perf_counter() - t) / n * 1e3, (t_host - t) / n * 1e3
 
 
 def measure(tag, eng, t0, stamps=True):
     eng.decode(t0, 8, use_graph=True)                 # setup / capture outside the timed calls
-    a, b = ms_per_step(eng, t0, 64), ms_per_step(eng, t0, 256)
+    (a, ha), (b, hb) = ms_per_step(eng, t0, 64), ms_per_step(eng, t0, 256)
     per_step = (b * 256 - a * 64) / 192
-    print(f"{tag}: pipelined={eng.pipelined}  64-step call {a:.3f} ms/step, 256-step call {b:.3f} ms/step -> {per_step:.3f} ms/step + "
-          f"{(a - per_step) * 64:.1f} ms per call; error word {eng.pipe_error()}", flush=True)
+    # host enqueue ~ total: the graph launches themselves are the bottleneck (hipGraphLaunch off its pre-built-packet path?)
+    print(f"{tag}: pipelined={eng.pipelined}  64-step call {a:.3f} ms/step (host enqueue {ha:.3f}), 256-step call {b:.3f} ms/step "
+          f"(host enqueue {hb:.3f}) -> {per_step:.3f} ms/step + {(a - per_step) * 64:.1f} ms per call; error word {eng.pipe_error()}",
+          flush=True)
     if stamps and eng.pipelined:
         BE.report_stamps(eng, indent="      ")
 
