@@ -335,7 +335,9 @@ int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* str
  * launches they wait for -- one pipelined engine at a time (enable = 0 or jb_engine_destroy releases the right).  The two
  * streams must feed different hardware queues; the first pipelined decode checks that with a two-kernel handshake and
  * keeps the plain chain otherwise.  enable = 2 is enable = 1 with a fresh pair of streams and freshly captured graphs at
- * the next decode (the engine must be idle).  Replaces the same reference code as jb_engine_decode. */
+ * the next decode (the engine must be idle).  enable = 3 changes nothing about the launches: it only makes the next graph-replayed
+ * decode create the pair of streams and capture the two graphs (a later enable = 1 then finds them made -- for callers that
+ * switch the launches on in the middle of a job).  Replaces the same reference code as jb_engine_decode. */
 int jb_engine_pipeline(void* handle, int enable);
 /* Measurement aid: n_steps passes over all layers launching only the LayerNorm-fused projections (attn.c_attn and
  * mlp.c_fc -- the dominant kernel of the decode step) with their real arguments, back to back on `stream`, bracketed

@@ -30,6 +30,7 @@ struct JbEngine {
     // software-pipelined launches (jb_engine_pipeline): the launches of a step alternate between the caller's stream and a
     // second stream of the same priority, as two single-stream graphs that are replayed side by side
     bool pipelined = false;
+    bool prepare_pipe = false;              // make the pair of streams and the two graphs at the next decode, whatever form it takes
     hipStream_t pstream[2] = {nullptr, nullptr};                   // the engine's own pair (setup_pipeline_streams)
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     hipGraph_t pgraph[2] = {nullptr, nullptr};
@@ -285,6 +286,10 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     // waits for -- in particular the attention launch, 198 registers per lane: one workgroup per otherwise empty compute
     // unit -- must still find room.  One waiter leaves >= 76 compute units free of waiters; the waiters of two engines can
     // cover all 256, and then neither producer is ever placed (seen in the 3-level job: every slot timed out).
+    if (enable == 3) {            // streams and graphs early, launches stay as they are (the owner is not asked for)
+        e->prepare_pipe = true;
+        return JB_OK;
+    }
     std::lock_guard<std::mutex> lock(g_pipe_mutex);
     if (enable) {
         if (g_pipe_owner && g_pipe_owner != e) JB_UNSUPPORTED("another engine of this process runs pipelined launches (one at a time: "
@@ -371,27 +376,35 @@ static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mu
     return JB_OK;
 }
 
+// The engine's pair of streams and its two parity graphs (once).
+static int prepare_pipeline(JbEngine* e) {
+    const int n_slots = jb_engine_launches_per_step(e);
+    JB_REQUIRE(n_slots % 2 == 0, "pipelined launches need an even number of launches per step");
+    if (e->pstream[0] && e->pexec[0] && e->pexec[1]) return JB_OK;
+    // one engine at a time: the handshake synchronises, and another thread's synchronous calls must not fall into this
+    // thread's capture
+    std::lock_guard<std::mutex> lock(g_pipe_mutex);
+    if (!e->pstream[0]) JB_TRY(setup_pipeline_streams(e));
+    if (!e->capture_stream) JB_HIP(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        if (e->pexec[k]) continue;
+        JB_HIP(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_step(e, e->capture_stream, k);
+        hipGraph_t gph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(e->capture_stream, &gph);
+        if (rc != JB_OK) { if (gph) (void)hipGraphDestroy(gph); return rc; }
+        if (ce != hipSuccess) { jb_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return JB_ERR_HIP; }
+        if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
+        e->pgraph[k] = gph;
+        JB_HIP(hipGraphInstantiate(&e->pexec[k], gph, nullptr, nullptr, 0));
+    }
+    return JB_OK;
+}
+
 // n_steps pipelined decode steps from the state jb_engine_decode has prepared on `s`.
 static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s) {
     const int n_slots = jb_engine_launches_per_step(e);
-    JB_REQUIRE(n_slots % 2 == 0, "pipelined launches need an even number of launches per step");
-    if (!e->pstream[0] || !e->pexec[0]) {
-        // one engine at a time: the handshake synchronises, and another thread's synchronous calls must not fall into this
-        // thread's capture
-        std::lock_guard<std::mutex> lock(g_pipe_mutex);
-        if (!e->pstream[0]) JB_TRY(setup_pipeline_streams(e));
-        if (!e->capture_stream) JB_HIP(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) {
-            JB_HIP(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
-            const int rc = enqueue_step(e, e->capture_stream, k);
-            hipGraph_t gph = nullptr;
-            const hipError_t ce = hipStreamEndCapture(e->capture_stream, &gph);
-            if (rc != JB_OK) { if (gph) (void)hipGraphDestroy(gph); return rc; }
-            if (ce != hipSuccess) { jb_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return JB_ERR_HIP; }
-            e->pgraph[k] = gph;
-            JB_HIP(hipGraphInstantiate(&e->pexec[k], gph, nullptr, nullptr, 0));
-        }
-    }
+    JB_TRY(prepare_pipeline(e));
     // completion counts and tickets start from zero in every call (the engine's streams are idle here: the previous call
     // joined them into the caller's stream)
     JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));
@@ -420,6 +433,11 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
     if (!use_graph) {
         for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
         return JB_OK;
+    }
+    if (e->prepare_pipe) {                // asked for early (jb_engine_pipeline(handle, 3)): an engine that cannot have them stays plain
+        e->prepare_pipe = false;
+        const int rc = prepare_pipeline(e);
+        if (rc != JB_OK && rc != JB_ERR_UNSUPPORTED) return rc;
     }
     if (e->pipelined) {
         const int rc = decode_pipelined(e, n_steps, s);

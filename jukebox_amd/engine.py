@@ -319,6 +319,13 @@ class PriorEngine:
         self.pipelined = bool(on)
         return self.pipelined
 
+    def prepare_pipelined(self):
+        """Have the next decode make the engine's pair of streams and its two graphs, without switching the launches over
+        (for a sampler that will switch them on mid-job); False for engines that cannot have pipelined launches."""
+        if self.handle is None or os.environ.get("JB_PIPELINE_LAUNCHES", "") == "0":
+            return False
+        return L.lib().jb_engine_pipeline(self.handle, 3) == 0
+
     def pipe_stamps(self):
         """JB_PIPE_DEBUG=1: (n_slots, 4) int64 ticks of the 100 MHz clock of the last pipelined step: poll entered, producer
         seen, completion published."""

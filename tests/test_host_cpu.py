@@ -489,6 +489,7 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
 
     a, b = engine(), engine()
     assert not a.pipelined and not b.pipelined                     # opt-in: nothing asks by default
+    assert a.prepare_pipelined() is True and not a.pipelined       # early streams / graphs: a request, not a switch
     assert a.set_pipelined(True) is True and a.pipelined
     assert b.set_pipelined(True) is False and not b.pipelined      # one owner per process
     assert a.set_pipelined(False) is False
@@ -499,7 +500,7 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
     a.set_pipelined(False)
     for kw in (dict(heads=2, W=256), dict(fp16=False), dict(n_batch=32), dict(T=16384, blocks=64)):   # last: 256-key block sets
         e = engine(**kw)
-        assert e.set_pipelined(True) is False and not e.pipelined, kw
+        assert e.set_pipelined(True) is False and not e.pipelined and e.prepare_pipelined() is False, kw
         e.close()
     monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "0")
     assert a.set_pipelined(True) is False

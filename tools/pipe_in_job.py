@@ -63,6 +63,8 @@ def reference_engine(dev, seq_len=2048):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=6.0, help="at least 5.95: level 1 needs a full context")
+    ap.add_argument("--late", action="store_true", help="do NOT make the level-0 engine's streams and graphs at its first decode "
+                    "(the sampler's default since round 3): they are made when the launches are switched on, mid-job")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     sr = 44100
@@ -73,6 +75,8 @@ def main():
                       keep_priors_resident=True, pipeline_levels=True, seed=0)
     labels = bench.synthetic_labels(priors, 16, 180 * sr, dev)
     sk = S.default_sampling_kwargs("1b_lyrics")
+    if a.late:
+        PriorEngine.prepare_pipelined = lambda self: False
     t = time.perf_counter()
     try:
         S.ancestral_sample(labels, sk, priors, hps, save=False, device=dev)
