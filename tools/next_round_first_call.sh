@@ -11,6 +11,8 @@
 #     and once more with GPU_MAX_HW_QUEUES=4 in front (the package raises the runtime's default of 4 to 8 -- jukebox_amd/__init__.py --
 #     which was only ever tested in tools/bench_engine.py, never inside the job: with two priority classes in use that is up to
 #     16 pooled hardware queues + the two CU-mask queues, close to what the hardware scheduler maps at once).
+#     and with --late (streams and graphs made when the launches are switched on, as in this round's slow runs; without it
+#     they are made at the engine's first decode, as in the one fast run).
 #     reads: A (job's engine as left) vs A' (plain) vs B (fresh streams) vs D (new engine) vs E (worker thread), each with the
 #     per-call / per-step split and the per-slot stamps.  B fast -> create the pair when the level becomes the only one running;
 #     D slow too -> process state (count HSA queues: rocprofv3 --hsa-trace of a 64-step call); only A slow -> engine state.
