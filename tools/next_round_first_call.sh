@@ -21,6 +21,11 @@
 #             -Wl,-rpath,$PWD/jukebox_amd/csrc -o tools/gemm_glds_probe     (build HERE, the binary travels)
 #       timeout 120 tools/gemm_glds_probe > gpurun_out/r04_gemm_glds_probe.log 2>&1
 #     EQUAL + >= 800 TFLOP/s on the 32768-row shapes -> move the kernel into gemm.hip behind jb_gemm's flat fp16 path.
+#   call B' (~2 min): the transpose pattern's prefill attention with 16-byte tile copies -- local branch wip/prefill-attn-vec (one file):
+#       git checkout wip/prefill-attn-vec -- jukebox_amd/csrc/attention.hip && python -m jukebox_amd.csrc.build
+#       timeout 200 python -u -m pytest tests/test_hip_kernels.py tests/test_hip_engine.py -q -m gpu -k "prefill or engine" ; python -u tools/bench_prefill.py
+#     keep it if the tests pass and the window's prefill gets shorter (attn_prefill_kernel<f16,30>: 96 calls x 1.18 ms in
+#     profiles/r03_full_job_kernel_stats.csv), `git checkout main -- jukebox_amd/csrc/attention.hip` otherwise.
 #   call C (this script, ~11 min): the whole GPU suite in ONE process (two xdist workers were no faster: the long cases wait for
 #     the CPU oracle) and the driver's bench command against a short wall budget.
 export PYTHONPATH=$PWD TMPDIR=/tmp
