@@ -20,7 +20,9 @@
 #       hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I tools tools/gemm_glds_probe.hip -L jukebox_amd/csrc -ljukebox_hip \
 #             -Wl,-rpath,$PWD/jukebox_amd/csrc -o tools/gemm_glds_probe     (build HERE, the binary travels)
 #       timeout 120 tools/gemm_glds_probe > gpurun_out/r04_gemm_glds_probe.log 2>&1
-#     EQUAL + >= 800 TFLOP/s on the 32768-row shapes -> move the kernel into gemm.hip behind jb_gemm's flat fp16 path.
+#     EQUAL + >= 800 TFLOP/s on the 32768-row shapes -> the kernel inside jb_gemm is ready on the local branch wip/gemm-glds
+#     (git checkout wip/gemm-glds -- jukebox_amd/csrc/gemm.hip; JB_GEMM_GLDS=1 selects it): prefill tests + tools/bench_prefill.py
+#     with and without the variable, then make it the default for flat fp16 problems.
 #   call B' (~2 min): the transpose pattern's prefill attention with 16-byte tile copies -- local branch wip/prefill-attn-vec (one file):
 #       git checkout wip/prefill-attn-vec -- jukebox_amd/csrc/attention.hip && python -m jukebox_amd.csrc.build
 #       timeout 200 python -u -m pytest tests/test_hip_kernels.py tests/test_hip_engine.py -q -m gpu -k "prefill or engine" ; python -u tools/bench_prefill.py
