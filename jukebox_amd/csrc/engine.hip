@@ -355,12 +355,20 @@ static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mu
     unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(jb_engine_launches_per_step(e)) - JB_PIPE_PAD + 8;
     // every pair of the process gets two masks nobody else has (each leaves out ONE compute unit of 256): should the runtime
     // key hardware queues by mask, two engines' pairs still never meet in one queue
+    // JB_PIPE_RESERVE_CUS=n (experiment, multiple of 8, <= 128): the pair additionally stays off the last n / 8 compute units
+    // of every XCD (mask bit i is compute unit i / 8 of XCD i % 8), so that a waiting launch of this engine can never hold
+    // the compute units another engine's launches need -- the condition under which a level could keep pipelined launches
+    // while the other levels of the job still run.
     static int g_pairs = 0;
     const int pair = g_pairs++;
+    int reserve = getenv("JB_PIPE_RESERVE_CUS") ? atoi(getenv("JB_PIPE_RESERVE_CUS")) : 0;
+    reserve = reserve < 0 ? 0 : (reserve > 128 ? 128 : reserve / 8 * 8);
+    const int usable = 256 - reserve;
     uint32_t mask[8];
     for (int k = 0; k < 2; ++k) {
-        for (int w = 0; w < 8; ++w) mask[w] = 0xffffffffu;
-        const int bit = 255 - (2 * pair + k) % 256;
+        for (int w = 0; w < 8; ++w) mask[w] = 0u;
+        for (int b = 0; b < usable; ++b) mask[b >> 5] |= 1u << (b & 31);
+        const int bit = usable - 1 - (2 * pair + k) % usable;
         mask[bit >> 5] &= ~(1u << (bit & 31));
         JB_HIP(hipExtStreamCreateWithCUMask(&e->pstream[k], 8, mask));
     }

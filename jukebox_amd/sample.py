@@ -228,7 +228,12 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # (DESIGN.md section 4.2); not understood yet, so the job keeps the plain launch chain by default.
     lowest = min(sample_levels)
     if _want_pipelined_launches(hps) and getattr(priors[lowest], "prior", None) is not None:
-        priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
+        if os.environ.get("JB_PIPELINE_WHEN", "alone") == "always":
+            # experiment: from the level's first step on.  Only sensible together with JB_PIPE_RESERVE_CUS (the engine's pair of
+            # streams leaves that many compute units to the other levels' launches; jb_engine_pipeline).
+            priors[lowest].prior.pipeline_launches = True
+        else:
+            priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
     # (level, window start, seconds into the job at which the window's sampling began / ended) per window: diagnostics

@@ -16,6 +16,10 @@
 #     reads: A (job's engine as left) vs A' (plain) vs B (fresh streams) vs D (new engine) vs E (worker thread), each with the
 #     per-call / per-step split and the per-slot stamps.  B fast -> create the pair when the level becomes the only one running;
 #     D slow too -> process state (count HSA queues: rocprofv3 --hsa-trace of a 64-step call); only A slow -> engine state.
+#   call A' (~2.5 min each, only once call A says the launches are fast inside the job): the 6-second bench with
+#       JB_PIPELINE_LAUNCHES=1                                              (level 0 pipelined while it runs alone)
+#       JB_PIPELINE_LAUNCHES=1 JB_PIPELINE_WHEN=always JB_PIPE_RESERVE_CUS=64  (from its first step, 8 CUs per XCD left to levels 2 / 1)
+#     against 79.8 s plain; level 0 alone is 163 of the 242 s of the 20-second job, level 0 altogether 206 s.
 #   call B (~1.5 min): the prefill-GEMM candidate against the library kernel, bit-for-bit and timed
 #       hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I tools tools/gemm_glds_probe.hip -L jukebox_amd/csrc -ljukebox_hip \
 #             -Wl,-rpath,$PWD/jukebox_amd/csrc -o tools/gemm_glds_probe     (build HERE, the binary travels)
