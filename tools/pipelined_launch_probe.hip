@@ -119,6 +119,30 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
             }
             if (tid == 0) s_i = i;
         }
+    } else if constexpr (V == 4) {
+        // V4: 8 shard tickets; the last arriver of a shard stores ONE BYTE of the slot's 8-byte flag word (write-through, each byte
+        // written once per run); the consumer polls that one word and wants every shard's byte at the run's number mod 256.
+        // Against V1 this drops the serialisation of 120-192 returning atomics on one word, against the engine's two-level
+        // ticket the second atomic round trip.
+        if (tid == 0) {
+            const unsigned i = ld_flag(a.flags + j * PAD + 1);               // full count of this slot's runs (same-stream order)
+            if constexpr (WAIT) {
+                const int prev = j == 0 ? K - 1 : j - 1;
+                const unsigned n_shards = a.G < 8 ? (unsigned)a.G : 8u;
+                const u64 keep = n_shards == 8 ? ~0ull : ((1ull << (8 * n_shards)) - 1ull);
+                const u64 want = (0x0101010101010101ull * (u64)((j == 0 ? i : i + 1) & 0xffu)) & keep;
+                const u64* word = reinterpret_cast<const u64*>(a.flags + prev * PAD + 2);
+                unsigned spins = 0;
+                while ((ld8<1>(word) & keep) != want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22) || ld_flag(a.abort_flag)) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            s_i = i;
+        }
     } else if (tid == 0) {
         const unsigned i = ld_flag(a.flags + j * PAD);
         if constexpr (WAIT) {
@@ -180,6 +204,17 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
         }
     } else if constexpr (V == 2) {
         if (tid == 0) __hip_atomic_store(a.rows + (size_t)j * 256 + wg, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if constexpr (V == 4) {
+        if (tid == 0) {
+            const unsigned shard = (unsigned)wg & 7u, members = ((unsigned)a.G - shard + 7u) >> 3;
+            unsigned* tk = a.rows + (size_t)j * 256 + shard * 16;            // the shard's ticket, 64 bytes from its neighbours
+            if (__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (shard == 0) __hip_atomic_store(a.flags + j * PAD + 1, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<unsigned char*>(a.flags + j * PAD + 2) + shard, (unsigned char)((i + 1) & 0xffu),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     } else if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(a.tickets + j * PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == (unsigned)a.G - 1) {
@@ -221,7 +256,8 @@ int main(int argc, char** argv) {
     const Mode modes[] = {{1, false, 0, "graph 1 stream, no wait"}, {1, true, 0, "graph 1 stream, wait"},
                           {2, true, 1, "eager 2 streams, wait"},
                           {2, true, 2, "2 graphs on 2 streams, wait"}, {3, true, 2, "3 graphs on 3 streams, wait"}};
-    for (const Shape& sh : shapes) for (int v = 1; v <= 3; ++v) for (const Mode& m : modes) {
+    const int v_lo = argc > 2 ? atoi(argv[2]) : 1, v_hi = argc > 3 ? atoi(argv[3]) : 4;     // protocol variants to run
+    for (const Shape& sh : shapes) for (int v = v_lo; v <= v_hi; ++v) for (const Mode& m : modes) {
         Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G, rows};
         if (a.w_phase_u4 == 0) a.w_phase_u4 = (size_t)sh.G;      // one dummy vector per workgroup
         CK(hipMemcpy(act, h.data(), N_EL * 2, hipMemcpyHostToDevice));
@@ -231,7 +267,8 @@ int main(int argc, char** argv) {
         auto launch_j = [&](int j, hipStream_t s) {
             if (v == 1) { if (m.wait) launch<1, true>(a, j, s); else launch<1, false>(a, j, s); }
             else if (v == 2) { if (m.wait) launch<2, true>(a, j, s); else launch<2, false>(a, j, s); }
-            else { if (m.wait) launch<3, true>(a, j, s); else launch<3, false>(a, j, s); }
+            else if (v == 3) { if (m.wait) launch<3, true>(a, j, s); else launch<3, false>(a, j, s); }
+            else { if (m.wait) launch<4, true>(a, j, s); else launch<4, false>(a, j, s); }
         };
         float ms = 0.f;
         if (m.kind == 0) {
