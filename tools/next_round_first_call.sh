@@ -23,7 +23,9 @@
 #   call A'' (~1 min): completion protocol V4 of tools/pipelined_launch_probe.hip (8 shard tickets, the shard's last arriver stores one
 #     BYTE of the slot's 8-byte flag word, the consumer polls that word) against V1 (one ticket, one flag):
 #       tools/pipelined_launch_probe 40 1 1 | grep "2 graphs"; tools/pipelined_launch_probe 40 4 4 | grep "2 graphs"
-#     V4 below V1's 4.63-4.74 us per phase -> replace the engine's two-level ticket (jb_pipe_publish: 1.9 us of a launch's 4.8).
+#     V4 below V1's 4.63-4.74 us per phase -> replace the engine's two-level ticket (jb_pipe_publish: 1.9 us of a launch's 4.8):
+#     the engine form is on the local branch wip/pipe-v4 (common.h + engine.hip; engines of >= 8 samples) --
+#     `tools/bench_engine.py up --pipelined 1` against 1.585 ms, then test_pipelined_launches_equal_the_plain_chain.
 #   call B (~1.5 min): the prefill-GEMM candidate against the library kernel, bit-for-bit and timed
 #       hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I tools tools/gemm_glds_probe.hip -L jukebox_amd/csrc -ljukebox_hip \
 #             -Wl,-rpath,$PWD/jukebox_amd/csrc -o tools/gemm_glds_probe     (build HERE, the binary travels)
