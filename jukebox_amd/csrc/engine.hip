@@ -410,7 +410,7 @@ static int prepare_pipeline(JbEngine* e) {
 }
 
 // n_steps pipelined decode steps from the state jb_engine_decode has prepared on `s`.
-static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s) {
+static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s, bool use_graph = true) {
     const int n_slots = jb_engine_launches_per_step(e);
     JB_TRY(prepare_pipeline(e));
     // completion counts and tickets start from zero in every call (the engine's streams are idle here: the previous call
@@ -419,7 +419,10 @@ static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s) {
     JB_HIP(hipEventRecord(e->ev_fork, s));
     for (int k = 0; k < 2; ++k) JB_HIP(hipStreamWaitEvent(e->pstream[k], e->ev_fork, 0));
     for (int i = 0; i < n_steps; ++i)
-        for (int k = 0; k < 2; ++k) JB_HIP(hipGraphLaunch(e->pexec[k], e->pstream[k]));
+        for (int k = 0; k < 2; ++k) {
+            if (use_graph) JB_HIP(hipGraphLaunch(e->pexec[k], e->pstream[k]));
+            else JB_TRY(enqueue_step(e, e->pstream[k], k));        // diagnostics: the same launches without the graph executor
+        }
     for (int k = 0; k < 2; ++k) {
         JB_HIP(hipEventRecord(e->ev_join[k], e->pstream[k]));
         JB_HIP(hipStreamWaitEvent(s, e->ev_join[k], 0));
@@ -439,6 +442,7 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
     for (const jb_layer& L : e->layers) e->v_rows_stale = e->v_rows_stale || layer_wide(e->cfg, L);
     JB_TRY(enqueue_embed(e, t0, s));         // later positions are embedded by the sampler of the step before
     if (!use_graph) {
+        if (e->pipelined && e->pexec[0]) return decode_pipelined(e, n_steps, s, false);
         for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
         return JB_OK;
     }

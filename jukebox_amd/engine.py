@@ -301,6 +301,8 @@ class PriorEngine:
         self.pipelined = False
         if want and not self.only_encode and os.environ.get("JB_PIPELINE_LAUNCHES", "") != "0":
             self.pipelined = L.lib().jb_engine_pipeline(self.handle, 1) == 0
+        if getattr(self, "_want_prepare", False):          # asked for before the handle existed, or the handle was rebuilt
+            L.lib().jb_engine_pipeline(self.handle, 3)
 
     def set_pipelined(self, on, fresh=False):
         """Switch software-pipelined launches of the decode step on / off; returns whether they are on (they stay off for
@@ -322,8 +324,11 @@ class PriorEngine:
     def prepare_pipelined(self):
         """Have the next decode make the engine's pair of streams and its two graphs, without switching the launches over
         (for a sampler that will switch them on mid-job); False for engines that cannot have pipelined launches."""
-        if self.handle is None or os.environ.get("JB_PIPELINE_LAUNCHES", "") == "0":
+        if self.only_encode or os.environ.get("JB_PIPELINE_LAUNCHES", "") == "0":
             return False
+        self._want_prepare = True              # survives _create (the handle is made by the first set_cond, and re-made when the
+        if self.handle is None:                # conditioning mode changes)
+            return True
         return L.lib().jb_engine_pipeline(self.handle, 3) == 0
 
     def pipe_stamps(self):

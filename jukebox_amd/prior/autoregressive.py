@@ -142,9 +142,8 @@ class ConditionalAutoregressive2D(nn.Module):
         runs alone)."""
         want = getattr(self, "pipeline_launches", None)
         if callable(want):
-            if not getattr(eng, "_pipe_prepared", False):      # they will be switched on mid-job: streams and graphs now
-                eng._pipe_prepared = True
-                eng.prepare_pipelined()
+            if not getattr(eng, "_pipe_prepared", False):      # they will be switched on mid-job: streams and graphs at the first decode
+                eng._pipe_prepared = bool(eng.prepare_pipelined())
             want = want()
         if want is not None and eng.pipelined != bool(want):
             eng.set_pipelined(bool(want))

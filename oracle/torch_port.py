@@ -16,7 +16,7 @@ from .transformer import attn_func_of_layer, decode_key_index, rounded_prime_len
 
 class TorchDecodeStack:
     def __init__(self, sd, prefix, n_in, n_ctx, n_head, n_depth, attn_order=0, blocks=None, m_attn=0.25, prime_len=None,
-                 n_batch=1):
+                 n_batch=1, encoder_kv=None):
         g = lambda name: torch.as_tensor(np.asarray(sd[prefix + name], dtype=np.float32))
         self.n_in, self.n_ctx, self.H, self.L = n_in, n_ctx, n_head, n_depth
         self.S = int(m_attn * n_in)
@@ -30,9 +30,16 @@ class TorchDecodeStack:
                 wa="attn.c_attn.w", ba="attn.c_attn.b", wp="attn.c_proj.w", bp="attn.c_proj.b", g0="ln_0.weight",
                 b0="ln_0.bias", wf="mlp.c_fc.w", bf="mlp.c_fc.b", w2="mlp.c_proj.w", b2="mlp.c_proj.b", g1="ln_1.weight",
                 b1="ln_1.bias").items()})
-        cap = lambda d: self.prime_r if self.funcs[d] == 7 else n_ctx
+        cap = lambda d: self.prime_r if self.funcs[d] == 7 else (0 if self.funcs[d] == 6 else n_ctx)
         self.K = [torch.zeros(n_batch, cap(d), self.S) for d in range(n_depth)]
         self.V = [torch.zeros(n_batch, cap(d), self.S) for d in range(n_depth)]
+        # cross-attention layers (attn_func 6): key / value = c_enc_kv(encoder_kv), once (decode_qkv, factored_attention.py:273-280)
+        if 6 in self.funcs:
+            ekv = torch.as_tensor(np.asarray(encoder_kv, dtype=np.float32))
+            for d in range(n_depth):
+                if self.funcs[d] == 6:
+                    kv = torch.matmul(ekv, g(f"_attn_mods.{d}.attn.c_enc_kv.w")) + g(f"_attn_mods.{d}.attn.c_enc_kv.b")
+                    self.K[d], self.V[d] = kv[..., :self.S].contiguous(), kv[..., self.S:].contiguous()
         self.t = 0
 
     @torch.no_grad()
@@ -46,10 +53,13 @@ class TorchDecodeStack:
             func = self.funcs[d]
             h = F.layer_norm(x, (self.n_in,), p["g0"], p["b0"], 1e-5)
             qkv = torch.addmm(p["ba"], h, p["wa"])
-            q, k, v = qkv[:, :S], qkv[:, S:2 * S], qkv[:, 2 * S:]
-            if t < self.K[d].shape[1]:
-                self.K[d][:, t], self.V[d][:, t] = k, v
-            idx = decode_key_index(func, t, self.bc, self.prime_r)
+            if func == 6:                                # the query only; every encoder position is a key (decode_attn :226-228)
+                q, idx = qkv, np.arange(self.K[d].shape[1])
+            else:
+                q, k, v = qkv[:, :S], qkv[:, S:2 * S], qkv[:, 2 * S:]
+                if t < self.K[d].shape[1]:
+                    self.K[d][:, t], self.V[d][:, t] = k, v
+                idx = decode_key_index(func, t, self.bc, self.prime_r)
             if idx is None:
                 a = torch.zeros(N, S)
             else:

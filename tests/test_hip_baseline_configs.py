@@ -109,18 +109,24 @@ def test_config3_1b_top_prior_geometry():
 #   (b) DECODE at the real index ranges, all N = 16 samples: the torch port of the oracle's decode step
 #       (oracle/torch_port.py, pinned to the numpy oracle) starts from the k/v caches (a) has validated and must produce
 #       the engine's logits and greedy tokens for 64 consecutive positions.
-def _random_prior_state(gen, W, depth, bins, seq, heads, y_cond, scale=0.02):
+def _random_prior_state(gen, W, depth, bins, seq, heads, y_cond, scale=0.02, funcs=None, untied_out=False):
+    """funcs: attn_func per layer (cross-attention layers -- 6 -- project the query only and carry c_enc_kv,
+    factored_attention.py:48-53); untied_out: a logits head of its own (merged_decoder, autoregressive.py:87-93)."""
     S = W // 4
     r = lambda *shape, sc=scale: torch.randn(*shape, device="cuda", generator=gen) * sc
     sd = {"x_emb.weight": r(bins, W, sc=0.05), "pos_emb.pos_emb": r(seq, W, sc=0.01)}
-    sd["x_out.weight"] = sd["x_emb.weight"]
+    sd["x_out.weight"] = r(bins, W, sc=0.05) if untied_out else sd["x_emb.weight"]
     if not y_cond:
         sd["start_token"] = r(1, W, sc=0.01)
     for d in range(depth):
         p = f"transformer._attn_mods.{d}."
-        sd[p + "attn.c_attn.w"], sd[p + "attn.c_proj.w"] = r(W, 3 * S), r(S, W)
+        cross = funcs is not None and funcs[d] == 6
+        j_attn = S if cross else 3 * S
+        sd[p + "attn.c_attn.w"], sd[p + "attn.c_proj.w"] = r(W, j_attn), r(S, W)
+        if cross:
+            sd[p + "attn.c_enc_kv.w"], sd[p + "attn.c_enc_kv.b"] = r(W, 2 * S), r(2 * S, sc=0.01)
         sd[p + "mlp.c_fc.w"], sd[p + "mlp.c_proj.w"] = r(W, W), r(W, W)
-        for nm, n in (("attn.c_attn.b", 3 * S), ("attn.c_proj.b", W), ("mlp.c_fc.b", W), ("mlp.c_proj.b", W)):
+        for nm, n in (("attn.c_attn.b", j_attn), ("attn.c_proj.b", W), ("mlp.c_fc.b", W), ("mlp.c_proj.b", W)):
             sd[p + nm] = r(n, sc=0.01)
         for ln in ("ln_0", "ln_1"):
             sd[p + ln + ".weight"] = 1 + r(W, sc=0.05)
@@ -141,17 +147,31 @@ def _embed_np(sd_np, tokens, t0, n_t, x_cond, start):
     return x.astype(np.float32)
 
 
-def _full_size_case(tag, W, depth, heads, attn_order, blocks, seq, bins, prime_len, y_cond, t0, n_steps, N=16, seed=3):
-    from jukebox_amd.engine import PriorEngine
+def _full_size_case(tag, W, depth, heads, attn_order, blocks, seq, bins, prime_len, y_cond, t0, n_steps, N=16, seed=3,
+                    enc_len=0, merged_decoder=False):
+    """Result line of every case: (a) sample 0's prefill against the numpy oracle, every layer's k / v rows at every position
+    (cross-attention layers: the c_enc_kv projection of the encoder states); the other samples through bit-exact batch-slot
+    invariance; (b) n_steps greedy decode steps of ALL samples against the torch port of the oracle's decode step.  The torch
+    port's self-attention caches are SEEDED with the engine's own prefill rows -- the rows (a) has just validated for sample 0
+    and slot invariance for the rest -- so (b) checks the decode step, not the prefill a second time.
+    enc_len > 0: cross-attention layers (attn_func 6) read `enc_len` encoder states (N, enc_len, W); merged_decoder: untied
+    logits head and no conditioning added behind the transformer (prior_5b_lyrics, autoregressive.py:87-93)."""
+    from jukebox_amd.engine import PriorEngine, attn_funcs
     from oracle.torch_port import TorchDecodeStack
     from oracle.transformer import Transformer as OracleTransformer
     gen = torch.Generator(device="cuda").manual_seed(seed)
-    sd = _random_prior_state(gen, W, depth, bins, seq, heads, y_cond)
+    funcs = attn_funcs(attn_order, depth)
+    assert (6 in funcs) == (enc_len > 0)
+    sd = _random_prior_state(gen, W, depth, bins, seq, heads, y_cond, funcs=funcs, untied_out=merged_decoder)
     eng = PriorEngine(sd, "", n_batch=N, seq_len=seq, bins=bins, width=W, depth=depth, heads=heads, attn_order=attn_order,
-                      blocks=blocks, prime_len=prime_len, y_cond=y_cond, fp16=False, want_preds=True, chunk_cap=512)
+                      blocks=blocks, prime_len=prime_len, y_cond=y_cond, fp16=False, want_preds=True, chunk_cap=512,
+                      encoder_dims=enc_len, add_cond_after=not merged_decoder)
     x_cond = torch.randn(N, seq, W, device="cuda", generator=gen) * 0.05 if y_cond else None
     yc = torch.randn(N, 1, W, device="cuda", generator=gen) * 0.05 if y_cond else None
+    enc = torch.randn(N, enc_len, W, device="cuda", generator=gen) if enc_len else None
     eng.set_cond(x_cond, yc)
+    if enc is not None:
+        eng.set_encoder_kv(enc)
     eng.set_sampling(temp=1.0, top_k=1)
     tokens = torch.randint(0, bins if prime_len is None else 79, (N, t0), device="cuda", generator=gen)
     eng.tokens[:, :t0] = tokens
@@ -166,10 +186,13 @@ def _full_size_case(tag, W, depth, heads, attn_order, blocks, seq, bins, prime_l
     start = yc.cpu().numpy().reshape(N, W) if y_cond else sd_np["start_token"].reshape(1, W)
 
     # (a) prefill of sample 0 at every position, every layer
-    tr = OracleTransformer(tr_sd, "", W, seq, heads, depth, attn_order=attn_order, blocks=blocks, prime_len=prime_len)
+    enc_np = enc.cpu().numpy() if enc is not None else None
+    tr = OracleTransformer(tr_sd, "", W, seq, heads, depth, attn_order=attn_order, blocks=blocks, prime_len=prime_len,
+                           encoder_dims=enc_len or None)
     for c0 in range(0, t0, 1024):
         n = min(1024, t0 - c0)
-        tr.forward(_embed_np(sd_np, z[:1], c0, n, None if xc_np is None else xc_np[:1], start[:1]), t0=c0)
+        tr.forward(_embed_np(sd_np, z[:1], c0, n, None if xc_np is None else xc_np[:1], start[:1]),
+                   encoder_kv=None if enc_np is None else enc_np[:1], t0=c0)
     worst = 0.0
     for d in range(depth):
         cap = tr.k[d].shape[1]
@@ -187,6 +210,8 @@ def _full_size_case(tag, W, depth, heads, attn_order, blocks, seq, bins, prime_l
         nm = min(t0, eng.kcaches[depth // 2].shape[1])
         mid_k = eng.kcaches[depth // 2][:, :nm].clone()
         eng.set_cond(None if x_cond is None else torch.roll(x_cond, roll, 0), None if yc is None else torch.roll(yc, roll, 0))
+        if enc is not None:
+            eng.set_encoder_kv(torch.roll(enc, roll, 0))
         eng.tokens[:, :t0] = torch.roll(tokens, roll, 0)
         eng.prefill(0, t0)
         torch.cuda.synchronize()
@@ -195,13 +220,18 @@ def _full_size_case(tag, W, depth, heads, attn_order, blocks, seq, bins, prime_l
         assert torch.equal(eng.kcaches[depth // 2][:, :nm], torch.roll(mid_k, roll, 0)), (tag, "prefill depends on the batch slot (mid k)")
         del last_k, last_v, mid_k
         eng.set_cond(x_cond, yc)
+        if enc is not None:
+            eng.set_encoder_kv(enc)
         eng.tokens[:, :t0] = tokens
         eng.prefill(0, t0)                       # back to the original placement for the decode check below
         torch.cuda.synchronize()
 
     # (b) decode of all samples from the validated caches
-    st = TorchDecodeStack(tr_sd, "", W, seq, heads, depth, attn_order=attn_order, blocks=blocks, prime_len=prime_len, n_batch=N)
+    st = TorchDecodeStack(tr_sd, "", W, seq, heads, depth, attn_order=attn_order, blocks=blocks, prime_len=prime_len, n_batch=N,
+                          encoder_kv=enc_np)
     for d in range(depth):
+        if funcs[d] == 6:
+            continue                             # the port projects the encoder states itself
         n = min(st.K[d].shape[1], t0)
         st.K[d][:, :n] = eng.kcaches[d][:, :n].cpu()
         st.V[d][:, :n] = eng.vcaches[d][:, :n].cpu()
@@ -211,7 +241,7 @@ def _full_size_case(tag, W, depth, heads, attn_order, blocks, seq, bins, prime_l
         t = t0 + i
         x = _embed_np(sd_np, z, t, 1, xc_np, start)              # the engine's own tokens: teacher-forced on its stream
         h = st.forward(x).numpy().reshape(N, W)
-        if xc_np is not None:
+        if xc_np is not None and not merged_decoder:
             h = h + xc_np[:, t]                                    # add_cond_after_transformer
         logits = h @ w_out.T
         err = np.abs(preds[:, i] - logits).max() / max(1.0, np.abs(logits).max())
@@ -311,6 +341,106 @@ def test_config5_5b_geometry_fast_paths():
     print("5b geometry, fp16 vs fp32 (max |dlogit|, mean |dlogit|, top-1 agreement), logit std %.3f:" % p32.std(), stats)
     (mx_f, mean_f, ag_f), (mx_r, mean_r, ag_r) = stats["fast"], stats["reference-ordered"]
     assert mx_f <= 1.5 * mx_r + 1e-3 and mean_f <= 1.25 * mean_r + 1e-4 and ag_f >= ag_r - 0.02, stats
+
+
+def test_config3_1b_lyrics_top_prior_second_window():
+    """BASELINE config 3 / 4, the top prior's SECOND window of the 20-second job (sample.py:17-88 with hop 768: start 746,
+    conditioned on 5398 music tokens): the 384 lyric + 5398 primed positions are prefilled in chunks, then the window is
+    decoded from position 5782 on -- the dense layer 47 reads > 5700 keys through the key-split attention and the merging
+    attn.c_proj (`gemv_merge_kernel`), the block patterns sit in block rows 56+ of block_ctx 102, the prime layers read
+    their 448 keys.  Full depth 72, N = 16, fp32."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _full_size_case("1b_lyrics_top_window2", W=2048, depth=72, heads=2, attn_order=12, blocks=64, seq=6528, bins=2127,
+                    prime_len=384, y_cond=True, t0=384 + 5398, n_steps=64, seed=11)
+
+
+def test_config5_5b_lyrics_order10_cross_attention():
+    """BASELINE config 5's decoder as it is built (prior_5b_lyrics, hparams.py:127-156: attn_order 10 -- nine self-attention
+    layers, then seven groups of nine + one cross-attention layer (attn_func 6) -- width 4800, 8 heads of 150, merged_decoder
+    (untied logits head, no conditioning behind the transformer), 512 lyric-encoder states, 3 samples per GPU) at depth 29 =
+    layers 0..28, which holds the cross-attention layers 18 and 28:
+      * fp32 engine vs the oracle: c_enc_kv projections + prefill of 700 positions (every layer's k / v rows), then 48 greedy
+        steps of all samples vs the torch port (cross-attention included);
+      * the fp16 engine on its fast paths (folded LayerNorm also in front of the S-wide query projection of the cross layers,
+        MFMA attention with ragged 150-channel heads over 512 encoder keys) teacher-forced on the fp32 stream."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from jukebox_amd.engine import PriorEngine, attn_funcs
+    h = setup_hparams("prior_5b_lyrics", {})
+    assert (h.prior_width, h.heads, h.blocks, h.n_ctx, h.attn_order, h.prior_depth, h.n_tokens) == (4800, 8, 128, 8192, 10, 79, 512)
+    W, depth, heads, seq, bins, N, t0, n_steps, enc_len = 4800, 29, 8, 8192, 2048, 3, 700, 48, 512
+    funcs = attn_funcs(10, depth)
+    assert [d for d, f in enumerate(funcs) if f == 6] == [18, 28]
+    _full_size_case("5b_order10", W=W, depth=depth, heads=heads, attn_order=10, blocks=128, seq=seq, bins=bins, prime_len=None,
+                    y_cond=True, t0=t0, n_steps=n_steps, N=N, seed=7, enc_len=enc_len, merged_decoder=True)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    sd = _random_prior_state(gen, W, depth, bins, seq, heads, True, funcs=funcs, untied_out=True)
+    x_cond = torch.randn(N, seq, W, device="cuda", generator=gen) * 0.05
+    yc = torch.randn(N, 1, W, device="cuda", generator=gen) * 0.05
+    enc = torch.randn(N, enc_len, W, device="cuda", generator=gen)
+    prefix = torch.randint(0, bins, (N, t0), device="cuda", generator=gen)
+
+    def make(fp16):
+        e = PriorEngine(sd, "", n_batch=N, seq_len=seq, bins=bins, width=W, depth=depth, heads=heads, attn_order=10, blocks=128,
+                        y_cond=True, fp16=fp16, want_preds=True, chunk_cap=512, encoder_dims=enc_len, add_cond_after=False)
+        e.set_cond(x_cond, yc)
+        e.set_encoder_kv(enc)
+        e.set_sampling(temp=1.0, top_k=1)
+        e.tokens[:, :t0] = prefix
+        e.prefill(0, t0)
+        return e
+
+    e32 = make(False)
+    e32.decode(t0, n_steps)
+    torch.cuda.synchronize()
+    z32, p32 = e32.tokens[:, :t0 + n_steps].clone(), e32.preds[:, t0:t0 + n_steps].cpu().numpy()
+    e32.close()
+    e16 = make(True)
+    assert bool(e16.layers_c[18].w_attn_f), "the cross-attention layer's query projection should take the folded-LayerNorm path"
+    for i in range(n_steps):
+        e16.tokens[:, :t0 + i] = z32[:, :t0 + i]
+        e16.decode(t0 + i, 1)
+    torch.cuda.synchronize()
+    p16 = e16.preds[:, t0:t0 + n_steps].cpu().numpy()
+    e16.close()
+    err = np.abs(p16 - p32)
+    agree = float((p16.argmax(-1) == p32.argmax(-1)).mean())
+    print("5b order 10, fp16 vs fp32: max |dlogit| %.4f mean %.4f top-1 agreement %.3f (logit std %.3f)"
+          % (err.max(), err.mean(), agree, p32.std()))
+    assert err.max() < 0.12 * max(1.0, float(np.abs(p32).max())) and err.mean() < 0.02 * max(1.0, float(p32.std())) and agree >= 0.95
+
+
+def test_config5_5b_lyrics_lyric_encoder_geometry():
+    """The lyric encoder of prior_5b_lyrics at its real size (prior.py:104-117,285-292 with hparams.py:139-146: width 1280,
+    depth 18, 4 heads of 80 channels, attn_order 2, blocks 32 over 512 tokens, 80 bins, only_encode): one prefill pass over
+    the 512 lyric tokens, final activations against the numpy oracle -- fp32 <= 2e-4 relative, fp16 engine <= 2e-2."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from jukebox_amd.engine import PriorEngine
+    from oracle.transformer import Transformer as OracleTransformer
+    h = setup_hparams("prior_5b_lyrics", {})
+    assert (h.prime_width, h.prime_depth, h.prime_heads, h.prime_attn_order, h.prime_blocks, h.n_tokens, h.n_vocab) == \
+        (1280, 18, 4, 2, 32, 512, 80)
+    W, depth, heads, seq, bins, N = 1280, 18, 4, 512, 80, 3
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    sd = _random_prior_state(gen, W, depth, bins, seq, heads, False, scale=0.04)
+    tokens = torch.randint(0, bins, (N, seq), device="cuda", generator=gen)
+    sd_np = {k: v.cpu().numpy() for k, v in sd.items()}
+    tr_sd = {k[len("transformer."):]: v for k, v in sd_np.items() if k.startswith("transformer.")}
+    tr = OracleTransformer(tr_sd, "", W, seq, heads, depth, attn_order=2, blocks=32)
+    want = tr.forward(_embed_np(sd_np, tokens.cpu().numpy(), 0, seq, None, sd_np["start_token"].reshape(1, W)), t0=0)
+    for fp16, tol in ((False, 2e-4), (True, 2e-2)):
+        eng = PriorEngine(sd, "", n_batch=N, seq_len=seq, bins=bins, width=W, depth=depth, heads=heads, attn_order=2, blocks=32,
+                          y_cond=False, fp16=fp16, only_encode=True, chunk_cap=512)
+        eng.set_cond(None, None)
+        eng.tokens[:, :seq] = tokens
+        eng.prefill(0, seq)
+        torch.cuda.synchronize()
+        got = eng.hidden[:, :seq].cpu().numpy()
+        eng.close()
+        err = float(np.abs(got - want).max() / max(1.0, np.abs(want).max()))
+        assert err < tol, ("lyric encoder", "fp16" if fp16 else "fp32", err)
 
 
 def test_config4_upsampler_conditioner_full_size():

@@ -347,6 +347,70 @@ def test_attn_decode_5b_head_size(H, func):
         assert np.abs(got - want).max() < 4e-3 * max(1.0, np.abs(want).max()), (func, t)
 
 
+@pytest.mark.parametrize("name,dt,tol", [("f32", torch.float32, 1e-5), ("f16", torch.float16, 4e-3)])
+@pytest.mark.parametrize("H_,d,keys", [(8, 150, 512), (4, 80, 512), (2, 16, 24), (1, 480, 100)])
+def test_attn_cross_attention(H, name, dt, tol, H_, d, keys):
+    """attn_func 6 (decode_attn, factored_attention.py:226-228): every query -- the single one of a decode step and each of
+    a prefill chunk -- reads ALL encoder positions, no mask, whatever its own position.  8 x 150 channels over 512 keys is
+    prior_5b_lyrics' cross-attention (hparams.py:127-153: n_tokens 512), 4 x 80 its lyric encoder's head size."""
+    rng = np.random.default_rng(600 + d)
+    N, S = 3, H_ * d
+    fp16 = dt == torch.float16
+    r = (lambda x: h16(x)) if fp16 else (lambda x: x)
+    K = r(rng.standard_normal((N, keys, S)).astype(np.float32))
+    V = r(rng.standard_normal((N, keys, S)).astype(np.float32))
+    kc, vc = dev(K, dt), dev(V, dt)
+    sc2 = np.float32(1.0 / math.sqrt(d))
+
+    def ref(q, rounded):
+        rr = r if rounded else (lambda x: x)
+        out = np.zeros_like(q)
+        for h in range(H_):
+            sl = slice(h * d, (h + 1) * d)
+            w = rr(rr(np.einsum("nqd,nkd->nqk", q[..., sl], K[..., sl])) * sc2)
+            out[..., sl] = rr(np.einsum("nqk,nkd->nqd", rr(O.softmax(w, -1)), V[..., sl]))
+        return out
+
+    for t in (0, 5, 700):
+        q = r(rng.standard_normal((N, 1, S)).astype(np.float32))
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        got = H.attn_decode(6, dev(q[:, 0], dt), kc, vc, H_, 64, t_dev, 8192).float().cpu().numpy()
+        want = ref(q, fp16)[:, 0]
+        assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), ("decode", t)
+    for t0, nq in ((0, 40), (100, 7), (640, 130)):
+        q = r(rng.standard_normal((N, nq, S)).astype(np.float32))
+        got = H.attn_prefill(6, dev(q, dt), kc, vc, H_, 64, t0).float().cpu().numpy()
+        want = ref(q, False)
+        assert np.abs(got - want).max() < (6e-3 if fp16 else 2e-5) * max(1.0, np.abs(want).max()), ("prefill", t0, nq)
+
+
+@pytest.mark.parametrize("name,dt,tol", [("f32", torch.float32, 2e-5), ("f16", torch.float16, 6e-3)])
+@pytest.mark.parametrize("func", [1, 2, 3])
+def test_attn_lyric_encoder_head_size(H, name, dt, tol, func):
+    """The lyric encoder of prior_5b_lyrics (hparams.py:139-146: prime_width 1280, prime_heads 4 -> 4 heads of 80 channels,
+    prime_blocks 32 over n_tokens 512 -> block_ctx 16, prime_attn_order 2): 80 is not a multiple of the 32-wide k-tile.
+    Full-sequence prefill (the encoder is only ever run as one pass) and, for completeness, single decode queries."""
+    rng = np.random.default_rng(800 + func)
+    N, T, bc, H_, d = 3, 512, 16, 4, 80
+    S = H_ * d
+    fp16 = dt == torch.float16
+    r = (lambda x: h16(x)) if fp16 else (lambda x: x)
+    K = r(rng.standard_normal((N, T, S)).astype(np.float32))
+    V = r(rng.standard_normal((N, T, S)).astype(np.float32))
+    kc, vc = dev(K, dt), dev(V, dt)
+    for t0, nq in ((0, 512), (0, 100), (37, 300)):
+        q = r(rng.standard_normal((N, nq, S)).astype(np.float32))
+        got = H.attn_prefill(func, dev(q, dt), kc, vc, H_, bc, t0).float().cpu().numpy()
+        want = _np_attention(func, q, K, V, H_, bc, None, list(range(t0, t0 + nq)), False)
+        assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (func, t0, nq)
+    for t in (0, 15, 16, 100, 511):
+        q = r(rng.standard_normal((N, 1, S)).astype(np.float32))
+        t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
+        got = H.attn_decode(func, dev(q[:, 0], dt), kc, vc, H_, bc, t_dev, T).float().cpu().numpy()
+        want = _np_attention(func, q, K, V, H_, bc, None, [t], fp16)[:, 0]
+        assert np.abs(got - want).max() < (4e-3 if fp16 else 1e-5) * max(1.0, np.abs(want).max()), (func, t)
+
+
 @pytest.mark.parametrize("func", [1, 2, 3])
 def test_attn_decode_upsampler_shape(H, func):
     """fp16 MFMA decode attention at the upsamplers' head size (1 head of 480) and block length 128 (one workgroup per

@@ -27,11 +27,11 @@ from jukebox_amd.engine import PriorEngine  # noqa: E402
 from jukebox_amd.hparams import Hyperparams  # noqa: E402
 
 
-def ms_per_step(eng, t0, n):
+def ms_per_step(eng, t0, n, use_graph=True):
     """(ms per step until the GPU is done, ms per step the HOST spent enqueueing)"""
     torch.cuda.synchronize()
     t = time.perf_counter()
-    eng.decode(t0, n, use_graph=True)
+    eng.decode(t0, n, use_graph=use_graph)
     t_host = time.perf_counter()
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3, (t_host - t) / n * 1e3
@@ -45,6 +45,14 @@ def measure(tag, eng, t0, stamps=True):
     print(f"{tag}: pipelined={eng.pipelined}  64-step call {a:.3f} ms/step (host enqueue {ha:.3f}), 256-step call {b:.3f} ms/step "
           f"(host enqueue {hb:.3f}) -> {per_step:.3f} ms/step + {(a - per_step) * 64:.1f} ms per call; error word {eng.pipe_error()}",
           flush=True)
+    n_long = min(1536, eng.T - t0)
+    (d, hd) = ms_per_step(eng, t0, n_long)            # a call far longer than any hardware queue: does the rate hold when the rings are full?
+    print(f"      {n_long}-step call {d:.3f} ms/step (host enqueue {hd:.3f})", flush=True)
+    if eng.pipelined:
+        # the same launches on the same pair of streams WITHOUT the graph executor: fast here and slow above -> hipGraphLaunch
+        eng.decode(t0, 4, use_graph=False)
+        (c, hc) = ms_per_step(eng, t0, 128, use_graph=False)
+        print(f"      eager launches on the pair of streams: {c:.3f} ms/step (host enqueue {hc:.3f}); error word {eng.pipe_error()}", flush=True)
     if stamps and eng.pipelined:
         BE.report_stamps(eng, indent="      ")
 

@@ -28,7 +28,9 @@
 #include <hip/hip_fp16.h>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <vector>
+#include "../jukebox_amd/csrc/aql.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 constexpr int N_EL = 16 * 1920;            // halfs per activation block
@@ -318,6 +320,76 @@ int main(int argc, char** argv) {
                ms * 1e3 / ((double)R * K), errs, ab);
         fflush(stdout);
         if (ab) { printf("aborted: a poll timed out -- stopping\n"); return 2; }
+    }
+    // ---- the same chain through a hardware queue of our own (jukebox_amd/csrc/aql.h): pre-built AQL packets, one memcpy into the
+    // ring + one doorbell per replay.  barrier = 1: the packet processor keeps stream order (today's chain without HIP);
+    // barrier = 0: packet j+1 is dispatched as soon as packet j's workgroups are placed -- pipelined launches in ONE queue.
+    // acquire / release: the cache actions the packet processor performs around each dispatch (2 = agent scope as HIP's launches,
+    // 0 = none: V1 / V4 move their activations with sc1 accesses and need none).  `lds`: extra LDS per workgroup, i.e. how many
+    // launches can be resident at once (the depth of the run-ahead).
+    {
+        jb_aql::Queue Q;
+        if (!Q.create(0, 16384)) { printf("aql: %s\n", Q.error.c_str()); return 0; }
+        struct AqlMode { int v; bool wait; bool barrier; int acq, rel; unsigned lds; const char* name; };
+        const AqlMode am[] = {
+            {1, false, true, 2, 2, 0, "aql barrier=1 acq/rel agent, no wait"},
+            {1, true, true, 2, 2, 0, "aql barrier=1 acq/rel agent, wait"},
+            {1, true, false, 2, 2, 0, "aql barrier=0 acq/rel agent"},
+            {1, true, false, 2, 0, 0, "aql barrier=0 acq agent rel none"},
+            {1, true, false, 0, 0, 0, "aql barrier=0 no fences"},
+            {1, true, false, 0, 0, 40960, "aql barrier=0 no fences lds 40K"},
+            {1, true, false, 0, 0, 81920, "aql barrier=0 no fences lds 80K"},
+            {1, true, false, 2, 2, 81920, "aql barrier=0 agent lds 80K"},
+            {4, true, false, 2, 2, 0, "aql barrier=0 acq/rel agent"},
+            {4, true, false, 0, 0, 0, "aql barrier=0 no fences"},
+            {4, true, false, 0, 0, 81920, "aql barrier=0 no fences lds 80K"},
+        };
+        for (const Shape& sh : shapes) for (const AqlMode& m : am) {
+            Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G, rows};
+            if (a.w_phase_u4 == 0) a.w_phase_u4 = (size_t)sh.G;
+            CK(hipMemcpy(act, h.data(), N_EL * 2, hipMemcpyHostToDevice));
+            CK(hipMemset(flags, 0, K * PAD * 4)); CK(hipMemset(tickets, 0, K * PAD * 4)); CK(hipMemset(err, 0, 4)); CK(hipMemset(abortf, 0, 4));
+            CK(hipMemset(rows, 0, (size_t)K * 256 * 4));
+            CK(hipDeviceSynchronize());
+            const void* fn = m.v == 1 ? (m.wait ? (const void*)&phase_kernel<1, true> : (const void*)&phase_kernel<1, false>)
+                                      : (const void*)&phase_kernel<4, true>;
+            jb_aql::Kernel kd;
+            if (!Q.lookup(fn, &kd)) { printf("aql: %s\n", Q.error.c_str()); return 0; }
+            const size_t ka = (kd.kernarg_size + 63) & ~(size_t)63;
+            std::vector<uint8_t> img(ka * K, 0);
+            uint8_t* dargs; CK(hipMalloc(&dargs, ka * K));
+            std::vector<hsa_kernel_dispatch_packet_t> pk(K);
+            std::vector<uint16_t> hd(K);
+            for (int j = 0; j < K; ++j) {
+                uint8_t* im = img.data() + (size_t)j * ka;
+                memcpy(im, &a, sizeof(Args)); memcpy(im + sizeof(Args), &j, sizeof(int));
+                jb_aql::Queue::fill_implicit(im, kd, sizeof(Args) + sizeof(int), dim3(sh.G), dim3(THREADS));
+                pk[j] = jb_aql::Queue::packet(kd, dim3(sh.G), dim3(THREADS), m.lds, dargs + (size_t)j * ka);
+                hd[j] = jb_aql::header(m.barrier, m.acq, m.rel);
+            }
+            CK(hipMemcpy(dargs, img.data(), ka * K, hipMemcpyHostToDevice));
+            CK(hipDeviceSynchronize());
+            std::vector<uint16_t> hd_first = hd;
+            hd_first[0] = jb_aql::header(true, 2, 2);
+            Q.arm(); Q.submit(pk.data(), hd_first.data(), K, true);        // warm-up replay
+            if (!Q.wait(5000000000ull)) { printf("aql: warm-up replay timed out (%s)\n", m.name); return 2; }
+            Q.arm();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < R; ++r) Q.submit(pk.data(), r == 0 ? hd_first.data() : hd.data(), K, r == R - 1);
+            const auto t_enq = std::chrono::steady_clock::now();
+            const bool fin = Q.wait(20000000000ull);
+            const auto t1 = std::chrono::steady_clock::now();
+            CK(hipDeviceSynchronize());
+            unsigned errs = 0, ab = 0;
+            CK(hipMemcpy(&errs, err, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ab, abortf, 4, hipMemcpyDeviceToHost));
+            const double us = std::chrono::duration<double, std::micro>(t1 - t0).count(), ue = std::chrono::duration<double, std::micro>(t_enq - t0).count();
+            printf("%-30s G=%3d V%d %-36s %6.2f us/phase  host enqueue %5.2f us/phase (kernarg %u B, lds %u; checksum errors %u, aborted %u%s)\n",
+                   sh.what, sh.G, m.v, m.name, us / ((double)R * K), ue / ((double)R * K), kd.kernarg_size, kd.group_size + m.lds, errs, ab,
+                   fin ? "" : ", TIMED OUT");
+            fflush(stdout);
+            CK(hipFree(dargs));
+            if (ab || !fin) { printf("aborted: a poll timed out -- stopping\n"); return 2; }
+        }
     }
     return 0;
 }
