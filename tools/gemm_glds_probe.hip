@@ -169,6 +169,117 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_glds_kernel(Param
     }
 }
 
+// The same structure with the tile as a parameter: WM x WN waves, each MT x 4 MFMA tiles (16 MT rows x 64 columns); two LDS
+// buffers.  <4,2,2> is the 128 x 128 kernel above; <8,2,4> is a 256 x 256 tile on 8 waves (128 KiB of LDS, one workgroup per
+// CU: 12 fragment reads per 32 MFMAs instead of 8 per 16, half the LDS-DMA bytes per flop); <4,4,2> a 256 x 128 tile on 8 waves.
+template <int MT, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 1) void gemm_glds_tile_kernel(Params p) {
+    using namespace gi;
+    constexpr int NWV = WM * WN, TBM = WM * MT * 16, TBJT = WN * 4;
+    constexpr int AP = TBM / 8, WT = TBJT * 2, A_B = AP * 1024, STAGE = A_B + WT * 1024;
+    constexpr int APW = AP / NWV, WTW = WT / NWV;
+    static_assert(AP % NWV == 0 && WT % NWV == 0, "pieces must divide among the waves");
+    const int MBt = (int)((p.m_total + TBM - 1) / TBM), NBt = (p.njt + TBJT - 1) / TBJT;
+    int mp, nt;
+    if (!tile_of_block((int)blockIdx.x, MBt, NBt, &mp, &nt)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wave_m = wave / WN, wave_n = wave % WN;
+    const long long m0 = (long long)mp * TBM;
+    const int jt0 = nt * TBJT;
+    const f16* a_src[APW];
+    const f16* w_src[WTW];
+#pragma unroll
+    for (int u = 0; u < APW; ++u) {
+        long long row = m0 + (wave * APW + u) * 8 + a_src_row(lane);
+        row = row < p.m_total ? row : p.m_total - 1;
+        a_src[u] = p.A + row * p.lda + a_src_seg(lane) * 8;
+    }
+#pragma unroll
+    for (int u = 0; u < WTW; ++u) {
+        const int jt = (wave * WTW + u) >> 1;
+        const int jtg = jt0 + jt < p.njt ? jt0 + jt : p.njt - 1;
+        w_src[u] = p.W + ((long long)jtg * p.nkt) * 512 + lane * 8;
+    }
+    const int ksteps = (p.nkt + 1) >> 1;
+    auto issue = [&](int s, int buf) {
+        unsigned char* st = s_raw + buf * STAGE;
+        const bool tail = 2 * s + 1 >= p.nkt;
+#pragma unroll
+        for (int u = 0; u < APW; ++u) {
+            const f16* src = a_src[u] + (long long)s * KSTEP;
+            if (tail && a_src_seg(lane) >= 4) src -= 32;
+            glds16(src, st + (wave * APW + u) * 1024);
+        }
+#pragma unroll
+        for (int u = 0; u < WTW; ++u) {
+            const int ks = (wave * WTW + u) & 1;
+            const int kt = (tail && ks) ? 2 * s : 2 * s + ks;
+            glds16(w_src[u] + (long long)kt * 512, st + A_B + (wave * WTW + u) * 1024);
+        }
+    };
+    f32x4 acc[4][MT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue(0, 0);
+    for (int s = 0; s < ksteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < ksteps) issue(s + 1, (s + 1) & 1);
+        const unsigned char* st = s_raw + (s & 1) * STAGE;
+        const int n_ks = 2 * s + 1 < p.nkt ? 2 : 1;
+        for (int ks = 0; ks < n_ks; ++ks) {
+            f16x8 af[MT], wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const f16x8*>(st + A_B + (((wave_n * 4 + j) * 2 + ks) << 10) + (lane << 4));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                af[mt] = *reinterpret_cast<const f16x8*>(st + a_byte(wave_m * (MT * 16) + mt * 16 + (lane & 15), frag_seg(ks, lane)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[mt], acc[j][mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long long row = m0 + wave_m * (MT * 16) + mt * 16 + (lane & 15);
+        if (row >= p.m_total) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jb = (jt0 + wave_n * 4 + j) * 16 + (lane >> 4) * 4;
+            if (jb >= p.J) continue;
+            f16 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[j][mt][r];
+                if (p.bias && jb + r < p.J) x += (float)(f16)p.bias[jb + r];
+                v[r] = (f16)x;
+            }
+            f16* dst = p.out + row * p.ldo + jb;
+            if (jb + 3 < p.J) {
+                *reinterpret_cast<f16x4*>(dst) = f16x4{v[0], v[1], v[2], v[3]};
+            } else {
+                for (int r = 0; r < 4 && jb + r < p.J; ++r) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+template <int MT, int WM, int WN>
+static void launch_tile(const Params& p, hipStream_t s) {
+    static bool configured = false;
+    constexpr int TBM = WM * MT * 16, TBJT = WN * 4;
+    const size_t lds = 2 * (size_t)((TBM / 8) * 1024 + TBJT * 2 * 1024);
+    if (!configured) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_tile_kernel<MT, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int MBt = (int)((p.m_total + TBM - 1) / TBM), NBt = (p.njt + TBJT - 1) / TBJT;
+    gemm_glds_tile_kernel<MT, WM, WN><<<(MBt + 7) / 8 * 8 * NBt, WM * WN * 64, lds, s>>>(p);
+    HIP_OK(hipGetLastError());
+}
+
 template <int NBUF>
 static void launch(const Params& p, hipStream_t s) {
     static bool configured = false;
@@ -260,6 +371,19 @@ static int run_shape(long long M, int K, int J) {
         std::printf("M=%lld K=%d J=%d  128x128 tile, LDS-DMA staging, %d LDS buffer%s                    %8.1f us  %7.1f TFLOP/s   %s (elements differing "
                     "from the library: %lld, worst relative error vs fp64 on 2048 samples: %.2e)\n",
                     M, K, J, nbuf, nbuf == 1 ? " " : "s", t * 1e3, flop / (t * 1e-3) / 1e12, ok ? "EQUAL" : "MISMATCH", differ, worst);
+    }
+    for (int var = 0; var < 3; ++var) {
+        const char* names[3] = {"128x128 / 4 waves (template)", "256x256 / 8 waves", "256x128 / 8 waves"};
+        auto go = [&] { if (var == 0) launch_tile<4, 2, 2>(p, nullptr); else if (var == 1) launch_tile<8, 2, 4>(p, nullptr); else launch_tile<4, 4, 2>(p, nullptr); };
+        HIP_OK(hipMemset(o_new, 0xff, (size_t)M * J * 2));
+        const double t = time_ms(go, 20);
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(r_new.data(), o_new, r_new.size() * 2, hipMemcpyDeviceToHost));
+        long long differ = 0;
+        for (size_t i = 0; i < r_new.size(); ++i) differ += (__builtin_bit_cast(unsigned short, r_new[i]) != __builtin_bit_cast(unsigned short, r_lib[i]));
+        bad += differ != 0;
+        std::printf("M=%lld K=%d J=%d  %-30s LDS-DMA, 2 LDS buffers              %8.1f us  %7.1f TFLOP/s   %s (elements differing from the library: %lld)\n",
+                    M, K, J, names[var], t * 1e3, flop / (t * 1e-3) / 1e12, differ == 0 ? "EQUAL" : "MISMATCH", differ);
     }
     HIP_OK(hipFree(dA)); HIP_OK(hipFree(dW)); HIP_OK(hipFree(dP)); HIP_OK(hipFree(db)); HIP_OK(hipFree(o_lib)); HIP_OK(hipFree(o_new));
     return bad;
