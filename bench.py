@@ -416,6 +416,11 @@ def main():
     step_ms = (time.perf_counter() - ts) / n_probe * 1e3
     breakdown["level0_decode_ms_per_token_step"] = round(step_ms, 4)
     breakdown["launches_per_token_step"] = eng.launches_per_step
+    # the launch form the level-0 engine ended the job in, and the job's own in-situ comparison of the two forms (ms per step
+    # of 384 pipelined / 128 plain steps of its first window alone: ConditionalAutoregressive2D._decode)
+    breakdown["level0_launch_form"] = "pipelined" if eng.pipelined else "plain chain"
+    if getattr(priors[0].prior, "pipeline_report", None):
+        breakdown["level0_in_situ_comparison_ms_per_step"] = priors[0].prior.pipeline_report
     tl = getattr(S._sample_levels_pipelined, "timeline", None)
     if tl and os.environ.get("JB_BENCH_TIMELINE") == "1":        # per-window schedule of the last step (diagnostics)
         breakdown["timeline"] = [list(x) for x in tl]
@@ -452,14 +457,13 @@ def main():
 
 
 if __name__ == "__main__":
-    try:
-        main()
-    finally:
-        # leave the process group in order: a rank that simply exits while its peers are still inside a collective makes
-        # the backend's worker threads abort ("terminate called without an active exception")
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            try:
-                torch.distributed.barrier()
-                torch.distributed.destroy_process_group()
-            except Exception:   # noqa: BLE001 -- shutting down
-                pass
+    main()
+    # leave the process group in order: a rank that simply exits while its peers are still inside a collective makes the
+    # backend's worker threads abort ("terminate called without an active exception").  Only on the success path: a rank that
+    # raised must not enter a barrier its peers are not in (they sit in another collective and would hang until the timeout).
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        try:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        except Exception:   # noqa: BLE001 -- shutting down
+            pass

@@ -304,8 +304,8 @@ typedef struct jb_engine_cfg {
      * branch-free path (the packed weight image is zero-padded to whole k-tiles anyway). */
     int att_ld;
     /* optional: (10 * launches_per_step + 1) * 32 zero-initialised words for software-pipelined launches
-     * (jb_engine_pipeline): per launch slot a completion count (32 words apart) and nine ticket counters; the last 32-word
-     * group starts with an error word (slot + 1 of a launch whose wait for its producer timed out; 0 = none; never reset by
+     * (jb_engine_pipeline): per launch slot a 32-word group with its completion count and one flag byte per ticket shard,
+     * then per slot nine 32-word groups of ticket counters; the last 32-word group starts with an error word (slot + 1 of a launch whose wait for its producer timed out; 0 = none; never reset by
      * the library). */
     unsigned* pipe_words;
 } jb_engine_cfg;
@@ -324,21 +324,23 @@ int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
  * (wide-value layers have no attn.c_proj launch: 4 per layer; jb_engine_launches_per_step reports the count).
  * use_graph != 0 captures one step into a hipGraph on first use and replays it. */
 int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
-/* Software-pipelined launches of the decode step (graph replay only): the launches of a step alternate between the
- * caller's stream and an internal stream of the same priority, so launch j+1 is dispatched -- and requests its weight
- * stream, whose addresses never depend on activations -- while launch j still runs; what it reads from launch j it reads
- * after polling j's completion word, through write-through stores / L1-bypassing loads.  Same kernels' arithmetic in the
- * same order: tokens and logits are bit-identical to the plain chain.  enable != 0 returns JB_ERR_UNSUPPORTED unless every
- * launch of this engine's step has a pipelined form (cfg.pipe_words given, fp16, <= 16 samples, every layer a wide-value
- * layer of one 480-channel head, width and n_mlp of 33..64 k-tiles: the 1b upsamplers), and while ANOTHER engine of the
- * process has them on: a waiting launch occupies compute units, and the waiters of two engines can leave no room for the
- * launches they wait for -- one pipelined engine at a time (enable = 0 or jb_engine_destroy releases the right).  The two
- * streams must feed different hardware queues; the first pipelined decode checks that with a two-kernel handshake and
- * keeps the plain chain otherwise.  enable = 2 is enable = 1 with a fresh pair of streams and freshly captured graphs at
- * the next decode (the engine must be idle).  enable = 3 changes nothing about the launches: it only makes the next graph-replayed
- * decode create the pair of streams and capture the two graphs (a later enable = 1 then finds them made -- for callers that
- * switch the launches on in the middle of a job).  Replaces the same reference code as jb_engine_decode. */
+/* Software-pipelined launches of the decode step (graph replay only): the launches of a step alternate between two streams
+ * of the engine's own (each on a hardware queue of its own), so launch j+1 is dispatched -- and requests its weight stream,
+ * whose addresses never depend on activations -- while launch j still runs; what it reads from launch j it reads after
+ * polling j's completion word, through write-through stores / L1-bypassing loads.  Same kernels' arithmetic in the same
+ * order: tokens and logits are bit-identical to the plain chain.  A pipelined jb_engine_decode is HOST-SYNCHRONOUS: it
+ * drains the caller's stream, runs the steps on the pair and returns when they are done (no queue of the process holds a
+ * waiting packet meanwhile).  enable != 0 returns JB_ERR_UNSUPPORTED unless every launch of this engine's step has a
+ * pipelined form (cfg.pipe_words given, fp16, 8..16 samples, every layer a wide-value layer of one 480-channel head, width
+ * and n_mlp of 33..64 k-tiles: the 1b upsamplers), and while ANOTHER engine of the process has them on: a waiting launch
+ * occupies compute units, and the waiters of two engines can leave no room for the launches they wait for -- one pipelined
+ * engine at a time (enable = 0 or jb_engine_destroy releases the right).  The two streams must feed different hardware
+ * queues; the first pipelined decode checks that with a two-kernel handshake and keeps the plain chain otherwise
+ * (jb_engine_pipelined then reports 0).  enable = 2 is enable = 1 with a fresh pair of streams and freshly captured
+ * graphs at the next decode (the engine must be idle).  Replaces the same reference code as jb_engine_decode. */
 int jb_engine_pipeline(void* handle, int enable);
+/* 1 while the engine's decode steps run as pipelined launches, else 0 (also after a fallback to the plain chain). */
+int jb_engine_pipelined(void* handle);
 /* Measurement aid: n_steps passes over all layers launching only the LayerNorm-fused projections (attn.c_attn and
  * mlp.c_fc -- the dominant kernel of the decode step) with their real arguments, back to back on `stream`, bracketed
  * by one HIP event pair.  Synchronises.  out[0] = average microseconds per launch, out[1] = launches timed,

@@ -107,6 +107,7 @@ _SIGS = {
     "jb_engine_probe_projection": (i32, [vp, i32, i32, vp, C.POINTER(C.c_double)]),
     "jb_engine_launches_per_step": (i32, [vp]),
     "jb_engine_pipeline": (i32, [vp, i32]),
+    "jb_engine_pipelined": (i32, [vp]),
     "jb_engine_step_bytes": (C.c_double, [vp, i32]),
 }
 EXPORTS = tuple(_SIGS)

@@ -203,19 +203,29 @@ __device__ __forceinline__ void jb_st_sc1(f16* base, int64_t el, f16 v) {
     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), jb_rsrc(base), (int)(el * 2), 0, 16);
 }
 
+// Completion protocol V4 (tools/pipelined_launch_probe.hip, V4): the slot's 32-word group holds  [0] the full count of its
+// runs (read only by the slot's own next run: same-stream order)  [2..3] eight flag BYTES, one per ticket shard.  The last
+// arriver of a shard stores its byte = (run + 1) mod 256 write-through; the consumer polls the 8-byte word until every
+// shard's byte shows its producer's run.  One returning atomic per workgroup and one byte store per shard instead of the
+// second-level ticket and the flag store.
 // Own completion count: every thread asks for it next to its first requests (a broadcast load).
 __device__ __forceinline__ unsigned jb_pipe_own(const JbPipe& P) { return jb_ld_word(P.runs + P.slot * JB_PIPE_PAD); }
+__device__ __forceinline__ unsigned long long jb_ld_word8(const unsigned* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // Wait for the producer launch; ends in a workgroup barrier.
 __device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own) {
     if (threadIdx.x == 0) {
-        const unsigned need = P.slot == 0 ? own : own + 1;
-        const unsigned* w = P.runs + P.prev * JB_PIPE_PAD;
+        // every launch of a step has >= 8 workgroups (the sampler: one per sample row -- fewer than 8 rows would need `keep`
+        // narrowed to the shards that exist; jb_engine_pipeline refuses engines of fewer than 8 samples in this form)
+        const unsigned long long want = 0x0101010101010101ull * (unsigned long long)((P.slot == 0 ? own : own + 1) & 0xffu);
+        const unsigned* w = P.runs + P.prev * JB_PIPE_PAD + 2;
         const bool stamp = P.dbg && blockIdx.x == 0 && blockIdx.y == 0;
         if (stamp) P.dbg[P.slot * 4] = wall_clock64();
-        if (jb_ld_word(w) < need) {
+        if (jb_ld_word8(w) != want) {
             const long long t0 = wall_clock64();
             unsigned spins = 0;
-            while (jb_ld_word(w) < need) {
+            while (jb_ld_word8(w) != want) {
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 255u) == 0) {
                     // the error word is sticky: once ONE wait of this engine has timed out, the tokens are void and the
@@ -239,13 +249,13 @@ __device__ __forceinline__ void jb_pipe_publish(const JbPipe& P, unsigned own) {
         const unsigned n_wg = gridDim.x * gridDim.y * gridDim.z;
         const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), shard = b & 7u;
         const unsigned members = (n_wg - shard + 7u) >> 3, n_shards = n_wg < 8u ? n_wg : 8u;
+        (void)n_shards;
         if (__hip_atomic_fetch_add(tk + shard * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
             jb_st_word(tk + shard * JB_PIPE_PAD, 0u);
-            if (__hip_atomic_fetch_add(tk + 8 * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_shards - 1) {
-                jb_st_word(tk + 8 * JB_PIPE_PAD, 0u);
-                jb_st_word(P.runs + P.slot * JB_PIPE_PAD, own + 1);
-                if (P.dbg) P.dbg[P.slot * 4 + 2] = wall_clock64();
-            }
+            if (shard == 0) jb_st_word(P.runs + P.slot * JB_PIPE_PAD, own + 1);
+            __hip_atomic_store(reinterpret_cast<unsigned char*>(P.runs + P.slot * JB_PIPE_PAD + 2) + shard, (unsigned char)((own + 1) & 0xffu),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (P.dbg && shard == 0) P.dbg[P.slot * 4 + 2] = wall_clock64();
         }
     }
 }

@@ -27,12 +27,10 @@ struct JbEngine {
     // wide-value layers append k and v' (not v) in the decode step: until the next window's prefill starts again at
     // position 0, the v rows of decoded positions are stale and a prefill that would attend to them is refused
     bool v_rows_stale = false;
-    // software-pipelined launches (jb_engine_pipeline): the launches of a step alternate between the caller's stream and a
-    // second stream of the same priority, as two single-stream graphs that are replayed side by side
+    // software-pipelined launches (jb_engine_pipeline): the launches of a step alternate between two streams of the engine's
+    // own, as two single-stream graphs that are replayed side by side
     bool pipelined = false;
-    bool prepare_pipe = false;              // make the pair of streams and the two graphs at the next decode, whatever form it takes
     hipStream_t pstream[2] = {nullptr, nullptr};                   // the engine's own pair (setup_pipeline_streams)
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     hipGraph_t pgraph[2] = {nullptr, nullptr};
     hipGraphExec_t pexec[2] = {nullptr, nullptr};
 };
@@ -99,11 +97,8 @@ extern "C" int jb_engine_destroy(void* handle) {
         if (e->pexec[k]) (void)hipGraphExecDestroy(e->pexec[k]);
         if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
     }
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    for (int k = 0; k < 2; ++k) {
-        if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+    for (int k = 0; k < 2; ++k)
         if (e->pstream[k]) (void)hipStreamDestroy(e->pstream[k]);
-    }
     {
         std::lock_guard<std::mutex> lock(g_pipe_mutex);
         if (g_pipe_owner == e) g_pipe_owner = nullptr;
@@ -267,10 +262,11 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
 }
 
 // Software-pipelined launches of the decode step.  Available where every launch of the step has a
-// pipelined form: fp16, <= 16 samples, wide-value layers throughout (one head of 480 channels), widths of 33..64 k-tiles.
+// pipelined form: fp16, 8..16 samples (every launch has >= 8 workgroups: one flag byte per ticket shard, common.h), wide-value
+// layers throughout (one head of 480 channels), widths of 33..64 k-tiles.
 static bool pipeline_eligible(const JbEngine* e) {
     const jb_engine_cfg& c = e->cfg;
-    if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || c.n_head != 1 || c.n_state != 480 || !c.x_out_packed) return false;
+    if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || c.n_batch < 8 || c.n_head != 1 || c.n_state != 480 || !c.x_out_packed) return false;
     if (c.width % 32 || c.n_mlp % 32 || c.width / 32 < 33 || c.width / 32 > 64 || c.n_mlp / 32 < 33 || c.n_mlp / 32 > 64) return false;
     for (const jb_layer& L : e->layers)
         if (!layer_wide(c, L) || !L.w_fc_f || layer_max_keys(c, L) > 128) return false;     // one 16-key tile per attention wave
@@ -281,15 +277,12 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     JB_REQUIRE(handle, "null engine");
     JbEngine* e = (JbEngine*)handle;
     if (enable && !pipeline_eligible(e)) JB_UNSUPPORTED("this engine's decode step has launches without a pipelined form (needs pipe_words, "
-                                                        "fp16, <= 16 samples, wide-value layers of one 480-channel head, 33..64 k-tiles)");
+                                                        "fp16, 8..16 samples, wide-value layers of one 480-channel head, 33..64 k-tiles)");
     // ONE pipelined engine per process.  Its waiting launch holds up to 180 workgroup slots while it spins; the producer it
     // waits for -- in particular the attention launch, 198 registers per lane: one workgroup per otherwise empty compute
     // unit -- must still find room.  One waiter leaves >= 76 compute units free of waiters; the waiters of two engines can
     // cover all 256, and then neither producer is ever placed (seen in the 3-level job: every slot timed out).
-    if (enable == 3) {            // streams and graphs early, launches stay as they are (the owner is not asked for)
-        e->prepare_pipe = true;
-        return JB_OK;
-    }
+    JB_REQUIRE(enable >= 0 && enable <= 2, "enable must be 0, 1 or 2");
     std::lock_guard<std::mutex> lock(g_pipe_mutex);
     if (enable) {
         if (g_pipe_owner && g_pipe_owner != e) JB_UNSUPPORTED("another engine of this process runs pipelined launches (one at a time: "
@@ -299,12 +292,9 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
             for (int k = 0; k < 2; ++k) {
                 if (e->pexec[k]) (void)hipGraphExecDestroy(e->pexec[k]);
                 if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
-                if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
                 if (e->pstream[k]) (void)hipStreamDestroy(e->pstream[k]);
-                e->pexec[k] = nullptr; e->pgraph[k] = nullptr; e->ev_join[k] = nullptr; e->pstream[k] = nullptr;
+                e->pexec[k] = nullptr; e->pgraph[k] = nullptr; e->pstream[k] = nullptr;
             }
-            if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-            e->ev_fork = nullptr;
         }
     } else if (g_pipe_owner == e) {
         g_pipe_owner = nullptr;
@@ -312,6 +302,8 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     e->pipelined = enable != 0;
     return JB_OK;
 }
+
+extern "C" int jb_engine_pipelined(void* handle) { return handle && ((JbEngine*)handle)->pipelined ? 1 : 0; }
 
 // Pipelined launches wait on each other ACROSS streams, and HIP multiplexes streams onto a few in-order hardware queues
 // (GPU_MAX_HW_QUEUES, 4 by default): a waiting launch that sits in the same hardware queue AHEAD of its producer -- or, with
@@ -353,24 +345,23 @@ static int streams_overlap(hipStream_t a, hipStream_t b, unsigned* scratch /* de
 // pair is still verified with the handshake above.  The caller's stream only forks to and joins from them with events.
 static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mutex
     unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(jb_engine_launches_per_step(e)) - JB_PIPE_PAD + 8;
-    // every pair of the process gets two masks nobody else has (each leaves out ONE compute unit of 256): should the runtime
-    // key hardware queues by mask, two engines' pairs still never meet in one queue
-    // JB_PIPE_RESERVE_CUS=n (experiment, multiple of 8, <= 128): the pair additionally stays off the last n / 8 compute units
-    // of every XCD (mask bit i is compute unit i / 8 of XCD i % 8), so that a waiting launch of this engine can never hold
-    // the compute units another engine's launches need -- the condition under which a level could keep pipelined launches
-    // while the other levels of the job still run.
+    // every pair of the process gets two masks nobody else has (each leaves out ONE compute unit): should the runtime key
+    // hardware queues by mask, two engines' pairs still never meet in one queue
     static int g_pairs = 0;
     const int pair = g_pairs++;
-    int reserve = getenv("JB_PIPE_RESERVE_CUS") ? atoi(getenv("JB_PIPE_RESERVE_CUS")) : 0;
-    reserve = reserve < 0 ? 0 : (reserve > 128 ? 128 : reserve / 8 * 8);
-    const int usable = 256 - reserve;
-    uint32_t mask[8];
+    int dev = 0;
+    JB_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    JB_HIP(hipGetDeviceProperties(&prop, dev));
+    const int n_cu = prop.multiProcessorCount;                   // 256 on MI355X; one mask bit per compute unit
+    JB_REQUIRE(n_cu >= 8 && n_cu <= 1024, "unexpected compute-unit count");
+    std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32);
     for (int k = 0; k < 2; ++k) {
-        for (int w = 0; w < 8; ++w) mask[w] = 0u;
-        for (int b = 0; b < usable; ++b) mask[b >> 5] |= 1u << (b & 31);
-        const int bit = usable - 1 - (2 * pair + k) % usable;
+        std::fill(mask.begin(), mask.end(), 0u);
+        for (int b = 0; b < n_cu; ++b) mask[b >> 5] |= 1u << (b & 31);
+        const int bit = n_cu - 1 - (2 * pair + k) % n_cu;
         mask[bit >> 5] &= ~(1u << (bit & 31));
-        JB_HIP(hipExtStreamCreateWithCUMask(&e->pstream[k], 8, mask));
+        JB_HIP(hipExtStreamCreateWithCUMask(&e->pstream[k], (uint32_t)mask.size(), mask.data()));
     }
     const int ov = streams_overlap(e->pstream[0], e->pstream[1], scratch);
     if (ov != 1) {
@@ -378,9 +369,6 @@ static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mu
         if (ov < 0) return ov;
         JB_UNSUPPORTED("the two streams of the pipelined launches share a hardware queue");
     }
-    JB_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-    JB_HIP(hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming));
-    JB_HIP(hipEventCreateWithFlags(&e->ev_join[1], hipEventDisableTiming));
     return JB_OK;
 }
 
@@ -409,24 +397,24 @@ static int prepare_pipeline(JbEngine* e) {
     return JB_OK;
 }
 
-// n_steps pipelined decode steps from the state jb_engine_decode has prepared on `s`.
+// n_steps pipelined decode steps from the state jb_engine_decode has prepared on `s`.  HOST-SYNCHRONOUS: the caller's
+// stream is drained first and the call returns when the pair has finished, so no queue of the process ever holds a packet
+// that WAITS (an event wait is a barrier packet; one that stays pending for the seconds a window takes -- the join of the
+// round-3 form sat in the caller's queue for the whole call -- cost the pair's launches 18 us dispatch stalls for the first
+// ~130 steps of every call whenever its hardware queue shared a pipe with one of the pair's: profiles/r04_pipe_in_job.log,
+// cases B / E against A / D).  The calling thread belongs to this level anyway.
 static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s, bool use_graph = true) {
     const int n_slots = jb_engine_launches_per_step(e);
     JB_TRY(prepare_pipeline(e));
-    // completion counts and tickets start from zero in every call (the engine's streams are idle here: the previous call
-    // joined them into the caller's stream)
+    // completion counts, flag bytes and tickets start from zero in every call
     JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));
-    JB_HIP(hipEventRecord(e->ev_fork, s));
-    for (int k = 0; k < 2; ++k) JB_HIP(hipStreamWaitEvent(e->pstream[k], e->ev_fork, 0));
+    JB_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < n_steps; ++i)
         for (int k = 0; k < 2; ++k) {
             if (use_graph) JB_HIP(hipGraphLaunch(e->pexec[k], e->pstream[k]));
             else JB_TRY(enqueue_step(e, e->pstream[k], k));        // diagnostics: the same launches without the graph executor
         }
-    for (int k = 0; k < 2; ++k) {
-        JB_HIP(hipEventRecord(e->ev_join[k], e->pstream[k]));
-        JB_HIP(hipStreamWaitEvent(s, e->ev_join[k], 0));
-    }
+    for (int k = 0; k < 2; ++k) JB_HIP(hipStreamSynchronize(e->pstream[k]));
     return JB_OK;
 }
 
@@ -446,15 +434,13 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
         for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
         return JB_OK;
     }
-    if (e->prepare_pipe) {                // asked for early (jb_engine_pipeline(handle, 3)): an engine that cannot have them stays plain
-        e->prepare_pipe = false;
-        const int rc = prepare_pipeline(e);
-        if (rc != JB_OK && rc != JB_ERR_UNSUPPORTED) return rc;
-    }
     if (e->pipelined) {
         const int rc = decode_pipelined(e, n_steps, s);
         if (rc != JB_ERR_UNSUPPORTED || e->pstream[0]) return rc;
-        e->pipelined = false;             // no hardware queue of its own for the side stream: the plain chain from here on
+        // no hardware queue of its own for the side stream: the plain chain from here on, and another engine may have them
+        e->pipelined = false;
+        std::lock_guard<std::mutex> lock(g_pipe_mutex);
+        if (g_pipe_owner == e) g_pipe_owner = nullptr;
     }
     if (!e->graph_exec) {
         // One eager step first, so that every kernel's dynamic-LDS attribute is configured outside of capture;

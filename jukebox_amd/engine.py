@@ -209,8 +209,8 @@ class PriorEngine:
         if any(splits(lay) for lay in pk.layers):
             self.att_parts = e(N, 4, S)
             self.att_ml = e(N, self.H, 4, 2, dtype=torch.float32)
-        # completion words of software-pipelined launches (jb_engine_pipeline): counts + tickets per launch slot, error word last
-        # (+ room for the JB_PIPE_DEBUG stamps: 4 x int64 per slot behind the error group)
+        # completion words of software-pipelined launches (jb_engine_pipeline): count + flag bytes + tickets per launch slot, error
+        # word last (+ room for the JB_PIPE_DEBUG stamps: 4 x int64 per slot behind the error group)
         self.pipe_words = torch.zeros((10 * (5 * self.depth + 2) + 1) * 32 + (5 * self.depth + 2) * 8, dtype=torch.int32, device=dev)
         self.pipelined = False
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
@@ -301,8 +301,6 @@ class PriorEngine:
         self.pipelined = False
         if want and not self.only_encode and os.environ.get("JB_PIPELINE_LAUNCHES", "") != "0":
             self.pipelined = L.lib().jb_engine_pipeline(self.handle, 1) == 0
-        if getattr(self, "_want_prepare", False):          # asked for before the handle existed, or the handle was rebuilt
-            L.lib().jb_engine_pipeline(self.handle, 3)
 
     def set_pipelined(self, on, fresh=False):
         """Switch software-pipelined launches of the decode step on / off; returns whether they are on (they stay off for
@@ -320,16 +318,6 @@ class PriorEngine:
         L.check(rc)
         self.pipelined = bool(on)
         return self.pipelined
-
-    def prepare_pipelined(self):
-        """Have the next decode make the engine's pair of streams and its two graphs, without switching the launches over
-        (for a sampler that will switch them on mid-job); False for engines that cannot have pipelined launches."""
-        if self.only_encode or os.environ.get("JB_PIPELINE_LAUNCHES", "") == "0":
-            return False
-        self._want_prepare = True              # survives _create (the handle is made by the first set_cond, and re-made when the
-        if self.handle is None:                # conditioning mode changes)
-            return True
-        return L.lib().jb_engine_pipeline(self.handle, 3) == 0
 
     def pipe_stamps(self):
         """JB_PIPE_DEBUG=1: (n_slots, 4) int64 ticks of the 100 MHz clock of the last pipelined step: poll entered, producer
@@ -370,6 +358,17 @@ class PriorEngine:
 
     def decode(self, t0, n_steps, use_graph=True):
         L.check(L.lib().jb_engine_decode(self.handle, t0, n_steps, int(use_graph), L.stream()))
+        if self.pipelined:                     # the library keeps the plain chain when the pair cannot have queues of its own
+            self.pipelined = bool(L.lib().jb_engine_pipelined(self.handle))
+
+    def timed_decode(self, t0, n_steps):
+        """decode + wait: seconds per step as the host sees them (the in-situ comparison of the two launch forms)."""
+        import time
+        torch.cuda.current_stream(self.device).synchronize()
+        t = time.perf_counter()
+        self.decode(t0, n_steps)
+        torch.cuda.current_stream(self.device).synchronize()
+        return (time.perf_counter() - t) / max(n_steps, 1)
 
     def probe_projection(self, t0, n_steps):
         """(avg_us_per_launch, launches, avg_algorithmic_bytes) of the LN-fused projection kernel, timed in situ."""

@@ -138,15 +138,50 @@ class ConditionalAutoregressive2D(nn.Module):
 
     def _apply_pipeline(self, eng):
         """Software-pipelined launches as the sampler asks for them: `pipeline_launches` is None (leave the engine alone), a
-        bool, or a callable that is asked again before every chunk of decode steps (the level pipeline: only while the level
-        runs alone)."""
+        bool, or a callable that is asked again before every decode call (the level pipeline: only while the level runs
+        alone).  A verdict of the in-situ comparison (`_decode`) against them is final for the engine."""
         want = getattr(self, "pipeline_launches", None)
         if callable(want):
-            if not getattr(eng, "_pipe_prepared", False):      # they will be switched on mid-job: streams and graphs at the first decode
-                eng._pipe_prepared = bool(eng.prepare_pipelined())
             want = want()
+        if want and getattr(eng, "_pipe_verdict", None) is False:
+            want = False
         if want is not None and eng.pipelined != bool(want):
             eng.set_pipelined(bool(want))
+
+    def _decode(self, eng, t0, n_steps):
+        """eng.decode, with the two launch forms compared IN SITU the first time an engine runs pipelined launches: the same
+        process has measured them at 1.6 ms per step (the pair of streams made early) and at 3.0 ms + 0.18 s per call (made
+        late, a waiting packet in a neighbouring hardware queue: DESIGN.md section 4.2), against 1.87 ms for the plain chain.
+        Both forms produce the same tokens bit for bit, so the window's first steps are the measurement: 384 pipelined steps,
+        128 plain ones, and the engine keeps pipelined launches only if they were >= 3 % faster -- once more on a fresh pair of
+        streams before giving them up.  The verdict holds for the engine's lifetime (`pipeline_report` keeps the numbers)."""
+        if not eng.pipelined or getattr(eng, "_pipe_verdict", None) is not None or n_steps < 1024:
+            eng.decode(t0, n_steps)
+            return
+        report = dict(pipelined_ms=[], plain_ms=None, kept=False)
+        pos, end = t0, t0 + n_steps
+        for attempt in range(2):
+            eng.decode(pos, 16)                # the pair of streams and its graphs are made here, outside the timed steps
+            pos += 16
+            if not eng.pipelined or eng.pipe_error():
+                break
+            report["pipelined_ms"].append(round(eng.timed_decode(pos, 384) * 1e3, 4))
+            pos += 384
+            if not eng.pipelined or eng.pipe_error():
+                break
+            if report["plain_ms"] is None:
+                eng.set_pipelined(False)
+                report["plain_ms"] = round(eng.timed_decode(pos, 128) * 1e3, 4)
+                pos += 128
+            if report["pipelined_ms"][-1] < 0.97 * report["plain_ms"]:
+                report["kept"] = True
+                break
+            if attempt == 0 and not eng.set_pipelined(True, fresh=True):
+                break
+        eng._pipe_verdict = report["kept"]
+        eng.set_pipelined(report["kept"])
+        self.pipeline_report = report
+        eng.decode(pos, end - pos)
 
     def packed(self, fp16):
         """This prior's weights in MFMA order for one engine dtype (built on first use, dropped when the module moves)."""
@@ -248,7 +283,7 @@ class ConditionalAutoregressive2D(nn.Module):
             eng.prefill(0, n_prime)
         tap = getattr(self, "decode_tap", None)
         if tap is None:
-            eng.decode(n_prime, sample_tokens - n_prime)
+            self._decode(eng, n_prime, sample_tokens - n_prime)
         else:
             # (every, fn): hand the token buffer to fn after every `every` enqueued decode steps, so that a consumer on
             # another stream can start on a partial window (jukebox_amd.sample._sample_levels_pipelined)
@@ -257,7 +292,7 @@ class ConditionalAutoregressive2D(nn.Module):
             while pos < sample_tokens:
                 n = min(int(every), sample_tokens - pos)
                 self._apply_pipeline(eng)
-                eng.decode(pos, n)
+                self._decode(eng, pos, n)
                 fn(eng.tokens, pos, pos + n)
                 pos += n
         x = eng.tokens[:, :sample_tokens].clone()

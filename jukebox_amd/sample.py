@@ -222,18 +222,14 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # Software-pipelined launches for the lowest level (the long pole) ONLY WHILE IT RUNS ALONE.  Its waiting launches keep
     # most compute units occupied for good; a concurrent level's attention launch (216 registers per lane: an otherwise
     # empty compute unit per workgroup) then hardly ever finds room -- measured on the 6-second job: 80 s plain, 176 s with
-    # level 0 pipelined from the start (level 1 at 1700 instead of 6300 tokens/s).  The engine checks before every chunk.
-    # OPT-IN (hps.pipeline_launches / JB_PIPELINE_LAUNCHES=1): even so the same job measured 84.5 s against 79.8 s plain --
-    # inside the multi-stream job the pipelined step ran at 5.8 ms instead of the 1.6 ms it takes in a process of its own
-    # (DESIGN.md section 4.2); not understood yet, so the job keeps the plain launch chain by default.
+    # level 0 pipelined from the start (level 1 at 1700 instead of 6300 tokens/s).  The engine is asked before every window;
+    # its pair of streams is made when the launches are switched on, not earlier: two more hardware queues in the process
+    # -- even idle ones -- slowed the concurrent levels' plain chains 2.5x (profiles/r04_pipe_in_job.log: first level-0 window
+    # 47.8 s instead of 18.7 s).  The first pipelined window compares the two launch forms in situ and keeps the faster
+    # (ConditionalAutoregressive2D._decode).
     lowest = min(sample_levels)
     if _want_pipelined_launches(hps) and getattr(priors[lowest], "prior", None) is not None:
-        if os.environ.get("JB_PIPELINE_WHEN", "alone") == "always":
-            # experiment: from the level's first step on.  Only sensible together with JB_PIPE_RESERVE_CUS (the engine's pair of
-            # streams leaves that many compute units to the other levels' launches; jb_engine_pipeline).
-            priors[lowest].prior.pipeline_launches = True
-        else:
-            priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
+        priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
     # (level, window start, seconds into the job at which the window's sampling began / ended) per window: diagnostics
@@ -260,9 +256,12 @@ def _shard_labels(labels, lo, hi):
 
 
 def _want_pipelined_launches(hps):
-    """Software-pipelined launches of the decode step are opt-in for the sampler: hps.pipeline_launches or
-    JB_PIPELINE_LAUNCHES=1 (-15 % per token step for an engine that has the GPU to itself)."""
-    return bool(hps.get("pipeline_launches", False)) or os.environ.get("JB_PIPELINE_LAUNCHES", "") == "1"
+    """Software-pipelined launches of the decode step (-14 % per token step for an engine that has the
+    GPU to itself, bit-identical tokens) are the sampler's default for a level that runs alone; hps.pipeline_launches = False
+    or JB_PIPELINE_LAUNCHES=0 keeps the plain launch chain."""
+    if os.environ.get("JB_PIPELINE_LAUNCHES", "") == "0":
+        return False
+    return bool(hps.get("pipeline_launches", True))
 
 
 def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, device="cuda"):
@@ -318,8 +317,7 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
             finally:
                 if ar(prior) is not None:
                     ar(prior).pipeline_launches = False        # the next level's engine may take them over
-                    eng = ar(prior).bound_engine() if hasattr(ar(prior), "bound_engine") else None
-                    if eng is not None:
+                    for eng in list(getattr(ar(prior), "_engines", {}).values()):     # (split-batch tails included)
                         eng.set_pipelined(False)
         if not hps.get("keep_priors_resident", False):
             prior.cpu()                          # sample.py:104: drops the engine's device copies

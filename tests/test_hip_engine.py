@@ -244,7 +244,8 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch):
             eng.tokens[:, :200] = prime
             eng.prefill(0, 200)
             t = 200
-            for n_steps in (1, 7, 64, 150, 3):                 # several calls: the completion words restart in each
+            for n_steps in (1, 7, 64, 150, 3, 300):            # several calls: the completion words restart in each; 300 > 256: the
+                                                               # flag bytes (run count mod 256) wrap inside one call
                 eng.decode(t, n_steps)
                 t += n_steps
             torch.cuda.synchronize()

@@ -451,10 +451,62 @@ def test_engine_cache_is_bounded_lru(monkeypatch):
     assert prior.engine_cache_budget() == 1e9
 
 
+def test_in_situ_choice_between_the_launch_forms():
+    """ConditionalAutoregressive2D._decode: the first window an engine runs with pipelined launches measures both forms on
+    its own steps (16 untimed + 384 timed pipelined steps, 128 plain ones) and keeps pipelined launches only when they are
+    >= 3 % faster, retrying once on a fresh pair of streams; every position of the window is decoded exactly once, in order,
+    and the verdict holds for the engine's later windows."""
+    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
+
+    class FakeEngine:
+        def __init__(self, rates):                      # rates: ms per step of successive pipelined measurements
+            self.rates, self.pipelined, self.calls, self.fresh = list(rates), True, [], 0
+        def pipe_error(self):
+            return 0
+        def set_pipelined(self, on, fresh=False):
+            self.pipelined = bool(on)
+            self.fresh += bool(fresh)
+            return self.pipelined
+        def decode(self, t0, n):
+            self.calls.append((t0, n, self.pipelined))
+        def timed_decode(self, t0, n):
+            self.decode(t0, n)
+            return (self.rates.pop(0) if self.pipelined else 1.87) * 1e-3
+
+    class Host:
+        _decode = AR._decode
+        _apply_pipeline = AR._apply_pipeline
+
+    def covered(eng, t0, n):
+        pos = t0
+        for c0, cn, _ in eng.calls:
+            assert c0 == pos
+            pos += cn
+        assert pos == t0 + n
+
+    for rates, kept, fresh in (([1.61], True, 0), ([2.95, 1.60], True, 1), ([2.95, 3.0], False, 1)):
+        h, eng = Host(), FakeEngine(rates)
+        h._decode(eng, 4096, 4096)
+        covered(eng, 4096, 4096)
+        assert eng._pipe_verdict is kept and eng.pipelined is kept and eng.fresh == fresh, rates
+        assert h.pipeline_report["kept"] is kept and h.pipeline_report["plain_ms"] == 1.87
+        assert eng.calls[-1][2] is kept                       # the rest of the window runs in the chosen form
+        n_calls = len(eng.calls)
+        h.pipeline_launches = lambda: True                    # next window: the sampler asks again, the verdict stands
+        h._apply_pipeline(eng)
+        assert eng.pipelined is kept
+        h._decode(eng, 4096, 4096)
+        assert len(eng.calls) == n_calls + 1                  # one call, nothing measured again
+    short = FakeEngine([])
+    Host()._decode(short, 0, 700)                             # too short to measure on: decoded as asked
+    assert short.calls == [(0, 700, True)] and not hasattr(short, "_pipe_verdict")
+
+
 def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
-    """jb_engine_pipeline's host logic (no launch happens before the first decode): which engines are eligible (fp16, <= 16
+    """jb_engine_pipeline's host logic (no launch happens before the first decode): which engines are eligible (fp16, 8..16
     samples, wide-value layers of one 480-channel head, key sets <= 128), ONE owner per process, release by switching off
-    or by destroying the engine, JB_PIPELINE_LAUNCHES=0 forbids, enable = 2 is accepted on an engine without streams."""
+    or by destroying the engine, JB_PIPELINE_LAUNCHES=0 forbids, enable = 2 is accepted on an engine without streams,
+    jb_engine_pipelined reports the effective state."""
     from jukebox_amd import _lib as L
     from jukebox_amd import engine as E
     from jukebox_amd import hip_ops as H
@@ -481,7 +533,7 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
                 sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(W), torch.zeros(W)
         return sd
 
-    def engine(W=1920, heads=1, fp16=True, n_batch=4, T=512, blocks=8):
+    def engine(W=1920, heads=1, fp16=True, n_batch=8, T=512, blocks=8):
         e = E.PriorEngine(state(W, 2, 64, T), "", n_batch=n_batch, seq_len=T, bins=64, width=W, depth=2, heads=heads,
                           attn_order=2, blocks=blocks, y_cond=False, fp16=fp16, device="cpu")
         e.set_cond(None, None)
@@ -489,8 +541,8 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
 
     a, b = engine(), engine()
     assert not a.pipelined and not b.pipelined                     # opt-in: nothing asks by default
-    assert a.prepare_pipelined() is True and not a.pipelined       # early streams / graphs: a request, not a switch
-    assert a.set_pipelined(True) is True and a.pipelined
+    assert a.set_pipelined(True) is True and a.pipelined and L.lib().jb_engine_pipelined(a.handle) == 1
+    assert L.lib().jb_engine_pipelined(b.handle) == 0 and L.lib().jb_engine_pipeline(a.handle, 3) != 0     # modes 0 / 1 / 2 only
     assert b.set_pipelined(True) is False and not b.pipelined      # one owner per process
     assert a.set_pipelined(False) is False
     assert b.set_pipelined(True) is True
@@ -498,9 +550,10 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
     b.close()                                                      # destroying the owner releases the right
     assert a.set_pipelined(True, fresh=True) is True               # enable = 2 on an engine that never made its streams
     a.set_pipelined(False)
-    for kw in (dict(heads=2, W=256), dict(fp16=False), dict(n_batch=32), dict(T=16384, blocks=64)):   # last: 256-key block sets
+    # fewer than 8 samples: the sampler launch would have fewer workgroups than ticket shards; last: 256-key block sets
+    for kw in (dict(heads=2, W=256), dict(fp16=False), dict(n_batch=32), dict(n_batch=4), dict(T=16384, blocks=64)):
         e = engine(**kw)
-        assert e.set_pipelined(True) is False and not e.pipelined and e.prepare_pipelined() is False, kw
+        assert e.set_pipelined(True) is False and not e.pipelined, kw
         e.close()
     monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "0")
     assert a.set_pipelined(True) is False

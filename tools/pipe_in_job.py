@@ -12,7 +12,6 @@ import os
 import sys
 import time
 
-os.environ["JB_PIPELINE_LAUNCHES"] = "1"
 os.environ["JB_PIPE_DEBUG"] = "1"
 os.environ.setdefault("JB_PIPE_TIMEOUT_MS", "100")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -71,8 +70,6 @@ def reference_engine(dev, seq_len=2048):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=6.0, help="at least 5.95: level 1 needs a full context")
-    ap.add_argument("--late", action="store_true", help="do NOT make the level-0 engine's streams and graphs at its first decode "
-                    "(the sampler's default since round 3): they are made when the launches are switched on, mid-job")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     sr = 44100
@@ -83,8 +80,6 @@ def main():
                       keep_priors_resident=True, pipeline_levels=True, seed=0)
     labels = bench.synthetic_labels(priors, 16, 180 * sr, dev)
     sk = S.default_sampling_kwargs("1b_lyrics")
-    if a.late:
-        PriorEngine.prepare_pipelined = lambda self: False
     t = time.perf_counter()
     try:
         S.ancestral_sample(labels, sk, priors, hps, save=False, device=dev)
@@ -96,6 +91,7 @@ def main():
         print("   ", [round(v, 2) if isinstance(v, float) else v for v in x])
     print(f"memory allocated {torch.cuda.memory_allocated() / 1e9:.1f} GB", flush=True)
 
+    print("in-situ comparison of the launch forms (level 0, first window alone):", getattr(priors[0].prior, "pipeline_report", None))
     eng = priors[0].prior.bound_engine()
     print(f"job's level-0 engine: pipelined={eng.pipelined} error word {eng.pipe_error()}")
     if eng.pipelined:
