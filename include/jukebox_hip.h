@@ -95,6 +95,9 @@ int jb_gemm(const jb_gemm_args* args /* host */, void* stream);
 /* Flat problems (one tap, unit strides) of at least `min_rows` output rows use the LDS-staged 256x128-tile kernel
  * (default 1024; < 0: never). */
 void jb_tune_gemm_lds(int min_rows);
+/* fp16 problems of one tap at unit strides (rows = (sequence, position), any pitch between sequences) with at least
+ * `min_rows` output rows use the LDS-DMA 128x128-tile kernel (default 256; < 0: never).  Bit-identical to the other kernels. */
+void jb_tune_gemm_glds(int min_rows);
 
 /* Weight-streaming skinny GEMM for the decode step (n_rows <= 64): out = act(LN?(x) @ W + b) (+ res),
  * one workgroup per 16 output columns, waves split K.  With ln_gamma != NULL the LayerNorm of

@@ -90,6 +90,7 @@ _SIGS = {
     "jb_tune_attn_decode_split": (None, [i32, i32]),
     "jb_tune_attn_decode_split_min_keys": (None, [i32]),
     "jb_tune_gemm_lds": (None, [i32]),
+    "jb_tune_gemm_glds": (None, [i32]),
     "jb_tune_attn_prefill_v2": (None, [i32]),
     "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "jb_attn_probs": (i32, [i32, i32, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -145,6 +146,8 @@ def lib():
             l.jb_tune_attn_prefill_v2(int(env("JB_PREFILL_V2")))
         if env("JB_GEMM_LDS_MIN_ROWS") is not None:
             l.jb_tune_gemm_lds(int(env("JB_GEMM_LDS_MIN_ROWS")))
+        if env("JB_GEMM_GLDS_MIN_ROWS") is not None:
+            l.jb_tune_gemm_glds(int(env("JB_GEMM_GLDS_MIN_ROWS")))
         _lib = l
     return _lib
 

@@ -527,17 +527,14 @@ extern "C" int jb_engine_prefill(void* handle, int t0, int n_t, void* stream) {
             }
             JB_TRY(jb_gemm(&g, s));
             if (L.vcache_w && p0 < L.cache_cap) {
-                // wide-value layer: v' = v·Wp for the decode steps, from the v rows just cached.  One flat GEMM per sample
-                // (its rows are contiguous in both caches): 4x fewer FLOPs than carrying Wv·Wp as extra c_attn columns
-                // (measured: +104 ms per 4096 x 16-token window that way).
+                // wide-value layer: v' = v·Wp for the decode steps, from the v rows just cached: 4x fewer FLOPs than carrying
+                // Wv·Wp as extra c_attn columns (measured: +104 ms per 4096 x 16-token window that way).
                 const int Cn = (C < L.cache_cap - p0) ? C : L.cache_cap - p0;
-                for (int n = 0; n < N; ++n) {
-                    const int64_t row = (int64_t)n * L.cache_cap + p0;
-                    jb_gemm_args gv;
-                    base(gv, (const f16*)L.vcache + row * S, S, S, L.w_proj, nullptr, W, (f16*)L.vcache_w + row * W, W);
-                    gv.n_seq = 1; gv.t_in = gv.t_out = Cn; gv.in_seq_stride = gv.out_seq_stride = Cn;
-                    JB_TRY(jb_gemm(&gv, s));
-                }
+                // one launch for all samples: rows (sample, position), a sample's rows cache_cap apart in both caches
+                jb_gemm_args gv;
+                base(gv, (const f16*)L.vcache + (int64_t)p0 * S, S, S, L.w_proj, nullptr, W, (f16*)L.vcache_w + (int64_t)p0 * W, W);
+                gv.t_in = gv.t_out = Cn; gv.in_seq_stride = gv.out_seq_stride = L.cache_cap;
+                JB_TRY(jb_gemm(&gv, s));
             }
             JB_TRY(jb_attn_prefill(c.dtype, L.attn_func, c.c_q, L.kcache, L.vcache, L.cache_cap, c.c_att, N, H, d,
                                    c.block_ctx, p0, C, s));

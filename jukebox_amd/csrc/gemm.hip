@@ -391,6 +391,103 @@ __global__ __launch_bounds__(256, 2) void gemm_lds_kernel(GemmParams p) {
     }
 }
 
+// The prefill projections (flat fp16 problems: one tap, unit strides) since round 4: 128 x 128 output tile, 64 channels per
+// K-step, BOTH operands brought into LDS by LDS-DMA (`global_load_lds_dwordx4`, no register staging, no ds_write pass):
+// activations as 8-row x 128-byte pieces into an XOR-swizzled image (gemm_glds_index.h: what the DMA deposits lane-linearly is
+// what the operand reads expect, every ds_read_b128 bank-conflict free -- checked exhaustively on the CPU by
+// tests/test_gemm_glds_index.py), weights straight from the packed MFMA-order image, one 1-KiB tile per instruction.  4 waves
+// as 2 x 2, each 64 rows x 64 columns; ONE 32-KiB LDS stage and three workgroups per CU: the other resident workgroups cover
+// a workgroup's load phase (measured, tools/gemm_glds_probe.hip on the prefill's shapes, M = 32768: 716 / 745 / 672 TFLOP/s
+// at K = 1920 and J = 1440 / 1920 / 2880 against 520 / 526 / 534 for gemm_lds_kernel, 496 against 209 at K = 480; two LDS
+// stages with one barrier per K-step: 620 / 632 / 594; a 256 x 256 tile on 8 waves: 726 / 704 / 710 and 387 at K = 480 --
+// profiles/r04_gemm_glds_probe.log).  XCD-aware tile order: a 128-row panel's column tiles run on one XCD, whose L2 fetches
+// the panel from HBM once.  Same MFMA, same k order per output element as gemm_lds_kernel: bit-identical results.
+// Rows are (sequence, position) pairs with their own pitches on both sides, so the per-sample v·Wp of the wide-value
+// cache is one launch (rows of a sample contiguous in the cache, samples cache_cap rows apart).
+#include "gemm_glds_index.h"
+__device__ __forceinline__ void jb_glds16(const void* src, unsigned char* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+__global__ __launch_bounds__(256, 3) void gemm_glds_kernel(GemmParams p, int MB, int NB) {
+    using namespace gi;
+    using T = f16;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char s_glds[];
+    int mp, nt;
+    if (!tile_of_block((int)blockIdx.x, MB, NB, &mp, &nt)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wave_m = wave >> 1, wave_n = wave & 1;
+    const int64_t m0 = (int64_t)mp * BM;
+    const int jt0 = nt * BJT;
+    const T* a_src[4];
+    const T* w_src[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int64_t q = m0 + (wave * 4 + u) * 8 + a_src_row(lane);
+        q = q < p.m_total ? q : p.m_total - 1;                    // rows past the end are never stored
+        const int64_t n = q / p.t_out, t = q - n * p.t_out;
+        a_src[u] = (const T*)p.A + (n * p.in_seq_stride + t) * p.lda + a_src_seg(lane) * 8;
+        const int jt = (wave * 4 + u) >> 1;
+        w_src[u] = (const T*)p.W + ((int64_t)min(jt0 + jt, p.njt - 1) * p.nkt) * 512 + lane * 8;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ksteps = (p.nkt + 1) >> 1;
+    for (int s = 0; s < ksteps; ++s) {
+        const bool tail = 2 * s + 1 >= p.nkt;                    // odd number of k-tiles: the step's second half does not exist
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const T* src = a_src[u] + (int64_t)s * KSTEP;
+            if (tail && a_src_seg(lane) >= 4) src -= 32;          // folded onto the first half (those slots are never read)
+            jb_glds16(src, s_glds + (wave * 4 + u) * 1024);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ks = u & 1, kt = (tail && ks) ? 2 * s : 2 * s + ks;
+            jb_glds16(w_src[u] + (int64_t)kt * 512, s_glds + A_BYTES + (wave * 4 + u) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's share of the step has landed ...
+        __syncthreads();                                            // ... everybody's has
+        const int n_ks = tail ? 1 : 2;
+        for (int ks = 0; ks < n_ks; ++ks) {
+            f16x8 af[4], wf[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const f16x8*>(s_glds + a_byte(frag_row(wave_m, mt, lane), frag_seg(ks, lane)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const f16x8*>(s_glds + w_byte(wave_n * 4 + j, ks, lane));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[j][mt] = jb_mfma(wf[j], af[mt], acc[j][mt]);
+        }
+        __syncthreads();                                            // nobody still reads the stage the next step overwrites
+    }
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int64_t q = m0 + wave_m * 64 + mt * 16 + c;
+        if (q >= p.m_total) continue;
+        const int n = (int)(q / p.t_out), t = (int)(q - (int64_t)n * p.t_out);
+        const int64_t orow = (int64_t)n * p.out_seq_stride + t;
+        int64_t cache_row = -1;
+        if (p.epi.qkv_split) {
+            const int ct = p.cache_t0 + t;
+            if (ct < p.epi.cache_cap) cache_row = (int64_t)n * p.epi.cache_cap + ct;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jb = (jt0 + wave_n * 4 + j) * 16 + g * 4;
+            if (jb < p.epi.J) epilogue_store<T>(p.epi, acc[j][mt], orow, jb, cache_row);
+        }
+    }
+}
+
+// the flat fp16 problems of >= this many rows take gemm_glds_kernel (< 0: never); jb_tune_gemm_glds
+static int g_gemm_glds_min_rows = 256;
+extern "C" void jb_tune_gemm_glds(int min_rows) { g_gemm_glds_min_rows = min_rows; }
+
 // rows from which jb_gemm takes the LDS-staged kernel for flat problems (< 0: never); jb_tune_gemm_lds
 static int g_gemm_lds_min_rows = 1024;
 extern "C" void jb_tune_gemm_lds(int min_rows) { g_gemm_lds_min_rows = min_rows; }
@@ -432,6 +529,24 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool flat = a->n_taps == 1 && a->shift[0] == 0 && a->in_stride == 1 && a->out_stride == 1 && a->out_offset == 0 &&
                       a->t_in == a->t_out && a->in_seq_stride == a->t_in && a->out_seq_stride == a->t_out && !a->pre_relu;
+    // one tap at unit strides, rows = (sequence, position) with a pitch per sequence on either side
+    const bool seq_flat = a->n_taps == 1 && a->shift[0] == 0 && a->in_stride == 1 && a->out_stride == 1 && a->out_offset == 0 &&
+                          a->t_in == a->t_out && !a->pre_relu;
+    if (seq_flat && fast && a->dtype == JB_F16 && g_gemm_glds_min_rows >= 0 && p.m_total >= g_gemm_glds_min_rows &&
+        (a->in_seq_stride * a->lda) % 8 == 0) {
+        static bool configured[64] = {};
+        int dev = 0;
+        JB_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !configured[dev]) {      // a static request below 64 KiB needs no opt-in; kept for symmetry
+            JB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       gi::STAGE_BYTES));
+            configured[dev] = true;
+        }
+        const int MB = (int)((p.m_total + gi::BM - 1) / gi::BM), NB = (p.njt + gi::BJT - 1) / gi::BJT;
+        gemm_glds_kernel<<<(MB + 7) / 8 * 8 * NB, 256, gi::STAGE_BYTES, st>>>(p, MB, NB);
+        JB_CHECK_LAUNCH();
+        return JB_OK;
+    }
     if (flat && fast && g_gemm_lds_min_rows >= 0 && p.m_total >= g_gemm_lds_min_rows) {
         dim3 lgrid((unsigned)((p.m_total + 255) / 256), (unsigned)((p.njt + 7) / 8));
         const size_t lds = 2 * (size_t)(256 * (KT + E) + 8 * 64 * E) * esz;

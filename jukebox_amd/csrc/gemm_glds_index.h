@@ -1,5 +1,5 @@
-// Index arithmetic of the prefill-GEMM candidate in tools/gemm_glds_probe.hip (128 x 128 output tile, 64 channels per
-// K-step, both operands brought into LDS by LDS-DMA, `global_load_lds_dwordx4`).  Kept apart from the kernel so that the CPU
+// Index arithmetic of gemm_glds_kernel (gemm.hip; stand-alone form: tools/gemm_glds_probe.hip): 128 x 128 output tile, 64
+// channels per K-step, both operands brought into LDS by LDS-DMA (`global_load_lds_dwordx4`).  Kept apart from the kernel so that the CPU
 // suite can check it exhaustively (tests/test_gemm_glds_index.py compiles this header with g++).
 //
 // An LDS-DMA instruction writes lane i's 16 bytes to  base + 16 * i  -- the LDS image is lane-linear per instruction, only

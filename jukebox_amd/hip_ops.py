@@ -102,10 +102,12 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
 
 
 def gemm(A, pw, bias=None, out=None, res=None, n_seq=1, t_in=None, t_out=None, shifts=(0,), in_stride=1,
-         out_stride=1, out_offset=0, out_rows_per_seq=None, pre_relu=False, act=L.ACT_NONE, res_scale=1.0):
-    """Sequence/tap GEMM (see jb_gemm).  A: (n_seq*t_in, lda>=K); returns (n_seq*out_rows_per_seq, J)."""
+         out_stride=1, out_offset=0, out_rows_per_seq=None, pre_relu=False, act=L.ACT_NONE, res_scale=1.0, in_seq_pitch=None):
+    """Sequence/tap GEMM (see jb_gemm).  A: (n_seq*t_in, lda>=K); returns (n_seq*out_rows_per_seq, J).
+    in_seq_pitch: rows between the starts of two sequences in A when they are not packed (t_in must then be given)."""
     _chk_cuda(A, bias, out, res)
     rows_in = A.shape[0]
+    assert in_seq_pitch is None or t_in is not None
     t_in = t_in if t_in is not None else rows_in // n_seq
     t_out = t_out if t_out is not None else t_in
     orps = out_rows_per_seq if out_rows_per_seq is not None else t_out * out_stride
@@ -119,7 +121,7 @@ def gemm(A, pw, bias=None, out=None, res=None, n_seq=1, t_in=None, t_out=None, s
     a.out, a.ldo = out.data_ptr(), out.stride(0)
     a.res, a.ldr = L.ptr(res), (res.stride(0) if res is not None else 0)
     a.n_seq, a.t_in, a.t_out = n_seq, t_in, t_out
-    a.in_seq_stride, a.out_seq_stride = t_in, orps
+    a.in_seq_stride, a.out_seq_stride = (t_in if in_seq_pitch is None else in_seq_pitch), orps
     a.K, a.J = pw.K, pw.J
     if len(shifts) != pw.taps:
         raise L.JukeboxHipError(f"{len(shifts)} shifts for a weight with {pw.taps} taps")

@@ -1,4 +1,4 @@
-"""CPU suite: the index arithmetic of the prefill-GEMM candidate (tools/gemm_glds_index.h, used by tools/gemm_glds_probe.hip)
+"""CPU suite: the index arithmetic of the prefill-GEMM candidate (jukebox_amd/csrc/gemm_glds_index.h, used by gemm_glds_kernel in gemm.hip and by tools/gemm_glds_probe.hip)
 checked exhaustively with a g++-compiled harness -- no GPU involved:
   * what the LDS-DMA instructions deposit (lane-linear) is what the operand reads expect, every (row, segment) exactly once;
   * every ds_read_b128 of an MFMA operand is bank-conflict free for the lane groups MI355X services together
@@ -87,6 +87,6 @@ def test_gemm_glds_index_arithmetic(tmp_path):
     src = tmp_path / "harness.cpp"
     src.write_text(HARNESS)
     exe = tmp_path / "harness"
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "tools"), str(src), "-o", str(exe)])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "jukebox_amd", "csrc"), str(src), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr

@@ -99,6 +99,7 @@ def test_gemm_lds_flat(H, name, dt, tol, M, K, J):
     R = r(rng.standard_normal((M, J)).astype(np.float32))
     pw = H.pack_conv1d_w(dev(W), dt)
     L.lib().jb_tune_gemm_lds(1)
+    L.lib().jb_tune_gemm_glds(-1)                         # this test is about the register-staged kernel
     try:
         got = H.gemm(dev(A, dt), pw, bias=dev(b), act=L.ACT_QUICK_GELU).float().cpu().numpy()
         assert relerr(got, O.quick_gelu(r(A @ W + r(b)), fp16=f16)) < tol
@@ -121,6 +122,57 @@ def test_gemm_lds_flat(H, name, dt, tol, M, K, J):
             assert float(kc[:, :t0].abs().max()) == 0 and float(kc[:, t0 + M // 4:].abs().max()) == 0
     finally:
         L.lib().jb_tune_gemm_lds(1024)
+        L.lib().jb_tune_gemm_glds(256)
+
+
+@pytest.mark.parametrize("M,K,J", [(1300, 256, 264), (600, 96, 72), (256, 32, 128), (2048, 1920, 480), (4096, 480, 1920),
+                                   (3000, 160, 200), (8192, 1920, 1440)])
+def test_gemm_glds(H, M, K, J):
+    """The prefill's fp16 GEMM since round 4 (gemm_glds_kernel: 128 x 128 tile, both operands by LDS-DMA into a swizzled LDS
+    image): bit-identical to the register-staged LDS kernel and to the direct-from-L1 kernel (same MFMA, same k order per
+    output element, same rounding points) on ragged rows / columns, odd and even numbers of k-tiles, with every epilogue
+    (bias + quick_gelu, bias + residual, the q / k-cache / v-cache split) and with sequences that are NOT packed in the input
+    (rows of a sequence contiguous, sequences a pitch apart: the per-sample v.Wp of the wide-value cache as one launch)."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(M + K + J)
+    dt = torch.float16
+    A = h16(rng.standard_normal((M, K)).astype(np.float32))
+    W = h16((rng.standard_normal((K, J)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(J).astype(np.float32)
+    R = h16(rng.standard_normal((M, J)).astype(np.float32))
+    pw = H.pack_conv1d_w(dev(W), dt)
+    Ad, Rd, bd = dev(A, dt), dev(R, dt), dev(b)
+    n_seq, t = 4, M // 4
+    pitch = t + 7
+    Ap = torch.zeros((n_seq * pitch, K), dtype=dt, device="cuda")
+    Ap.view(n_seq, pitch, K)[:, :t] = Ad[:n_seq * t].view(n_seq, t, K)
+
+    def run():
+        out = [H.gemm(Ad, pw, bias=bd, act=L.ACT_QUICK_GELU), H.gemm(Ad, pw, bias=bd, res=Rd),
+               H.gemm(Ap, pw, n_seq=n_seq, t_in=t, in_seq_pitch=pitch)]
+        if J % 3 == 0:
+            S, cap, t0 = J // 3, t + 9, 5
+            kc = torch.zeros((n_seq, cap, S), dtype=dt, device="cuda")
+            vc = torch.zeros((n_seq, cap, S), dtype=dt, device="cuda")
+            out += [H.gemm_qkv(Ad[:n_seq * t], pw, bd, n_seq, t, S, kc, vc, t0), kc, vc]
+        return [o.float().cpu().numpy() for o in out]
+
+    try:
+        L.lib().jb_tune_gemm_glds(1)
+        new = run()
+        L.lib().jb_tune_gemm_glds(-1)
+        L.lib().jb_tune_gemm_lds(1)
+        lds = run()
+        L.lib().jb_tune_gemm_lds(-1)
+        l1 = run()
+    finally:
+        L.lib().jb_tune_gemm_lds(1024)
+        L.lib().jb_tune_gemm_glds(256)
+    for a, b_, c in zip(new, lds, l1):
+        assert np.array_equal(a, b_) and np.array_equal(a, c)
+    assert relerr(new[0], O.quick_gelu(h16(A @ W + h16(b)), fp16=True)) < 4e-3
+    assert relerr(new[1], h16(R + h16(A @ W + h16(b)))) < 4e-3
+    assert relerr(new[2], h16(A[:n_seq * t] @ W)) < 4e-3
 
 
 def test_conv_stack_ops_fp32(H):

@@ -7,7 +7,7 @@
 // tile and 16-byte LDS-DMA staging reaches 874-912 TFLOP/s at 4096^3.  This file is that structure on OUR data layout:
 //   * 128 x 128 output tile, 4 waves as 2 x 2, each 64 rows x 64 columns = acc[4][4] of 16x16x32 MFMA tiles (64 VGPRs);
 //   * 64 channels per K-step; both operands by `global_load_lds_dwordx4`: activations as 8-row x 128-byte pieces into an
-//     XOR-swizzled image (tools/gemm_glds_index.h; operand reads conflict free, checked on the CPU by
+//     XOR-swizzled image (jukebox_amd/csrc/gemm_glds_index.h; operand reads conflict free, checked on the CPU by
 //     tests/test_gemm_glds_index.py), weights straight from the packed MFMA-order image (one 1-KiB tile per instruction);
 //   * NBUF = 1: load, barrier, multiply, barrier (32 KiB of LDS: the other resident workgroups of the CU cover the load);
 //     NBUF = 2: the next K-step's loads are issued before the multiply (64 KiB), one barrier per K-step;
@@ -28,7 +28,7 @@
 #include <random>
 #include <vector>
 
-#include "gemm_glds_index.h"
+#include "../jukebox_amd/csrc/gemm_glds_index.h"
 #include "jukebox_hip.h"
 
 typedef _Float16 f16;
