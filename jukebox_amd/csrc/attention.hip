@@ -988,24 +988,28 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(int func, const T* __r
 
 // Default for fp16 (jb_tune_attn_prefill_v2(0) restores the kernel above): the prefill attention with the staging fixed.
 // attn_prefill_kernel runs one wave per 16-query tile and copies every K / V tile into its private LDS with 2-byte
-// loads; at the upsamplers' sizes that is 4 TFLOP/s.  Here a workgroup of 4 waves owns 4 consecutive query tiles of one
-// (sample, head) -- which share almost all of their keys under the dense / block / prev / prime / cross patterns -- and
-// stages each 32-key K and V tile ONCE, with 16-byte loads by all 256 threads; every wave then runs the same
-// MFMA / online-softmax body as above on its own tile.  fp16, d_head and n_state multiples of 8; the transpose pattern
-// (whose query tiles are residue classes) stays on the kernel above.
+// loads; at the upsamplers' sizes that is 4 TFLOP/s.  Here a workgroup of 4 waves owns 4 query tiles of one (sample, head)
+// that share their keys -- 64 consecutive positions under the dense / block / prev / prime / cross patterns, 64 consecutive
+// members of one residue class mod block_ctx under the transpose pattern (round 4: its one-wave launches were 1.18 ms against
+// 0.11 ms for the other patterns) -- and stages each 32-key K and V tile ONCE, with 16-byte loads by all 256 threads; every
+// wave then runs the MFMA / online-softmax body on its own tile.  Round 4: operands leave LDS as vectors -- the Q and K
+// fragments are one ds_read_b128 each (rows padded by 16 bytes: conflict free), and V is staged TRANSPOSED ([channel][key],
+// 80-byte rows) so that the A operand of O^T += V^T P^T (8 keys of one channel) is two ds_read_b64 instead of eight 2-byte
+// reads.  fp16, d_head and n_state multiples of 8.
 template <int ND16>
 __global__ __launch_bounds__(256) void attn_prefill_v2_kernel(int func, const f16* __restrict__ q, const f16* __restrict__ kc,
                                                               const f16* __restrict__ vc, int cap, f16* __restrict__ out,
-                                                              int n_head, int d, int bc, int t0, int nq) {
+                                                              int n_head, int d, int bc, int t0, int nq, int wgs_per_class) {
     using V = f16x8;
     constexpr int E = 8, KT = 32, QW = 4;
     constexpr int DP = ND16 * 16;
     constexpr int LDR = DP + E;
+    constexpr int VP = KT + 8;                       // pitch of a transposed V row (keys of one channel), elements
     constexpr int NG = KT / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f16* sQ = reinterpret_cast<f16*>(smem_raw);      // [QW][16][LDR]
     f16* sK = sQ + QW * 16 * LDR;                    // [KT][LDR]
-    f16* sV = sK + KT * LDR;                         // [KT][LDR]
+    f16* sVt = sK + KT * LDR;                        // [DP][VP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -1013,26 +1017,39 @@ __global__ __launch_bounds__(256) void attn_prefill_v2_kernel(int func, const f1
     const int S = n_head * d;
     const int dv = d / E;                            // 16-byte vectors per row
 
-    // ---- queries of this workgroup (64 consecutive positions) and of this wave (16 of them) ----
-    const int wg_q0 = t0 + blockIdx.x * (QW * 16);
-    const int wg_qlast = min(wg_q0 + QW * 16, t0 + nq) - 1;        // >= wg_q0: the grid has no empty workgroups
-    const int qpos0 = wg_q0 + wave * 16;
-    const int nvalid = max(0, min(16, t0 + nq - qpos0));
-    const int my_q = qpos0 + c;
+    // ---- queries of this workgroup (64 of them, `qstep` positions apart) and of this wave (16 of them); candidate keys
+    // kstart + u * kstep, u < nkeys, cover all 64 queries ----
+    const int q_end = t0 + nq;                       // one past the last query position of the chunk
+    int wg_q0, qstep, kstart, kstep, nkeys;
+    if (func == JB_ATTN_TRANSPOSE_BLOCK) {
+        const int cls = blockIdx.x / wgs_per_class, it = blockIdx.x % wgs_per_class;
+        const int first = t0 + ((cls - t0 % bc) + bc) % bc;          // first position >= t0 in residue class cls
+        wg_q0 = first + it * (QW * 16) * bc; qstep = bc;
+        kstart = cls; kstep = bc;
+    } else {
+        wg_q0 = t0 + blockIdx.x * (QW * 16); qstep = 1;
+        kstart = 0; kstep = 1;
+    }
+    if (wg_q0 >= q_end) return;                      // (transpose: a class with fewer members than the grid allows for)
+    const int wg_nq = min(QW * 16, (q_end - 1 - wg_q0) / qstep + 1);
+    const int wg_qlast = wg_q0 + (wg_nq - 1) * qstep;
+    const int qpos0 = wg_q0 + wave * 16 * qstep;
+    const int nvalid = max(0, min(16, wg_nq - wave * 16));
+    const int my_q = qpos0 + c * qstep;
     const bool q_ok = c < nvalid;
-    int kstart, nkeys;                               // candidate keys kstart .. kstart + nkeys - 1 cover all 64 queries
-    if (func == JB_ATTN_DENSE) { kstart = 0; nkeys = wg_qlast + 1; }
+    if (func == JB_ATTN_TRANSPOSE_BLOCK) nkeys = wg_qlast / bc + 1;
+    else if (func == JB_ATTN_DENSE) nkeys = wg_qlast + 1;
     else if (func == JB_ATTN_BLOCK) { kstart = (wg_q0 / bc) * bc; nkeys = wg_qlast - kstart + 1; }
     else if (func == JB_ATTN_PREV_BLOCK) { kstart = max(wg_q0 / bc - 1, 0) * bc; nkeys = (wg_qlast / bc) * bc - kstart; }
-    else if (func == JB_ATTN_PRIME) { kstart = 0; nkeys = min(wg_qlast + 1, cap); }
-    else { kstart = 0; nkeys = cap; }
+    else if (func == JB_ATTN_PRIME) nkeys = min(wg_qlast + 1, cap);
+    else nkeys = cap;
 
     // ---- stage the 4 query tiles (zero rows / padding channels where there is no query) ----
     for (int idx = tid; idx < QW * 16 * (LDR / E); idx += 256) {
         const int r = idx / (LDR / E), i = idx - r * (LDR / E);
-        const int pos = wg_q0 + r;
+        const int pos = wg_q0 + r * qstep;
         V v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (pos < t0 + nq && i < dv) v = *reinterpret_cast<const V*>(q + ((int64_t)n * nq + (pos - t0)) * S + h * d + i * E);
+        if (r < wg_nq && i < dv) v = *reinterpret_cast<const V*>(q + ((int64_t)n * nq + (pos - t0)) * S + h * d + i * E);
         *reinterpret_cast<V*>(sQ + r * LDR + i * E) = v;
     }
 
@@ -1048,17 +1065,23 @@ __global__ __launch_bounds__(256) void attn_prefill_v2_kernel(int func, const f1
 
     for (int u0 = 0; u0 < nkeys; u0 += KT) {
         __syncthreads();                              // every wave is done with the previous K / V tile (and sQ is written)
+        // K rows as they are (one 16-byte vector per thread and pass, pad vector zeroed); V transposed: a thread takes 8
+        // channels of one key and scatters them to 8 channel rows -- key index fastest over the lanes, so that a wave's
+        // 2-byte stores fall into 16 consecutive dwords per channel row
         for (int idx = tid; idx < KT * (LDR / E); idx += 256) {
             const int r = idx / (LDR / E), i = idx - r * (LDR / E);
             const int u = u0 + r;
-            V kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (u < nkeys && i < dv) {
-                const int64_t off = (int64_t)(kstart + u) * S + i * E;
-                kv = *reinterpret_cast<const V*>(kbase + off);
-                vv = *reinterpret_cast<const V*>(vbase + off);
-            }
+            V kv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (u < nkeys && i < dv) kv = *reinterpret_cast<const V*>(kbase + (int64_t)(kstart + (int64_t)u * kstep) * S + i * E);
             *reinterpret_cast<V*>(sK + r * LDR + i * E) = kv;
-            *reinterpret_cast<V*>(sV + r * LDR + i * E) = vv;
+        }
+        for (int idx = tid; idx < KT * (DP / E); idx += 256) {
+            const int r = idx & (KT - 1), i = idx / KT;
+            const int u = u0 + r;
+            V vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (u < nkeys && i < dv) vv = *reinterpret_cast<const V*>(vbase + (int64_t)(kstart + (int64_t)u * kstep) * S + i * E);
+#pragma unroll
+            for (int e = 0; e < E; ++e) sVt[(i * E + e) * VP + r] = vv[e];
         }
         __syncthreads();
         if (nvalid <= 0) continue;                    // wave-uniform: this wave has no queries (tail of the chunk)
@@ -1066,22 +1089,17 @@ __global__ __launch_bounds__(256) void attn_prefill_v2_kernel(int func, const f1
         f32x4 sc[NG];
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) sc[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int dk = 0; dk < DP; dk += KT) {
-            if (dk >= d) break;
-            V qfrag, kfrag[NG];
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int ch = dk + g * E + e;
-                qfrag[e] = ch < DP ? sQw[c * LDR + ch] : (f16)0;
-            }
+        for (int dk = 0; dk < DP; dk += KT) {
+            // channels dk + g*8 .. + 7: inside the row (padding channels are staged as zeros, the 16-byte pad behind the row
+            // too) unless the whole vector lies past it (DP not a multiple of 32: the upper half of the last k-tile)
+            const bool in_row = dk + g * E < DP;
+            const int off = in_row ? dk + g * E : 0;
+            const V qfrag = keep_frag<f16>(in_row, *reinterpret_cast<const V*>(sQw + c * LDR + off));
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int ch = dk + g * E + e;
-                    kfrag[gi][e] = ch < DP ? sK[(gi * 16 + c) * LDR + ch] : (f16)0;
-                }
-                sc[gi] = jb_mfma(kfrag[gi], qfrag, sc[gi]);
+                const V kfrag = keep_frag<f16>(in_row, *reinterpret_cast<const V*>(sK + (gi * 16 + c) * LDR + off));
+                sc[gi] = jb_mfma(kfrag, qfrag, sc[gi]);
             }
         }
         float pv[NG][4];
@@ -1091,11 +1109,11 @@ __global__ __launch_bounds__(256) void attn_prefill_v2_kernel(int func, const f1
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int u = u0 + gi * 16 + g * 4 + r;
-                const int j = kstart + u;
+                const int j = kstart + u * kstep;
                 bool ok = q_ok && u < nkeys;
                 if (ok) {
                     switch (func) {
-                        case JB_ATTN_DENSE: case JB_ATTN_PRIME: ok = j <= my_q; break;
+                        case JB_ATTN_DENSE: case JB_ATTN_PRIME: case JB_ATTN_TRANSPOSE_BLOCK: ok = j <= my_q; break;
                         case JB_ATTN_BLOCK: ok = j <= my_q && (j / bc) == (my_q / bc); break;
                         case JB_ATTN_PREV_BLOCK: ok = (j / bc) == (my_q / bc) - 1; break;
                         default: break;
@@ -1122,15 +1140,16 @@ __global__ __launch_bounds__(256) void attn_prefill_v2_kernel(int func, const f1
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
-        V pfrag;
+        V pfrag;                                      // B operand: slot (g, e) <-> key g*4 + (e&3) + 16*(e>>2)
 #pragma unroll
         for (int e = 0; e < E; ++e) pfrag[e] = (f16)pv[e >> 2][e & 3];
 #pragma unroll
         for (int i = 0; i < ND16; ++i) {
             oacc[i] *= alpha;
-            V vfrag;
-#pragma unroll
-            for (int e = 0; e < E; ++e) vfrag[e] = sV[(g * 4 + (e & 3) + 16 * (e >> 2)) * LDR + i * 16 + c];
+            // A operand: channel row i*16 + c, the same slot <-> key map: keys g*4 .. +3 and 16 + g*4 .. +3 of the row
+            const f16* vrow = sVt + (i * 16 + c) * VP + g * 4;
+            const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow), hi = *reinterpret_cast<const f16x4*>(vrow + 16);
+            const V vfrag = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             oacc[i] = jb_mfma(vfrag, pfrag, oacc[i]);
         }
     }
@@ -1169,16 +1188,23 @@ extern "C" int jb_attn_prefill(int dtype, int attn_func, const void* q, const vo
     const int esz = dtype == JB_F16 ? 2 : 4, E = dtype == JB_F16 ? 8 : 4, KT = dtype == JB_F16 ? 32 : 16;
     dim3 grid(tiles, n_head, n_batch);
     hipStream_t s = (hipStream_t)stream;
-    if (g_prefill_v2 && dtype == JB_F16 && attn_func != JB_ATTN_TRANSPOSE_BLOCK && d_head % 8 == 0 && (n_head * d_head) % 8 == 0) {
+    if (g_prefill_v2 && dtype == JB_F16 && d_head % 8 == 0 && (n_head * d_head) % 8 == 0) {
+        // workgroups of 64 queries: consecutive positions, or (transpose) consecutive members of one residue class
+        int wpc = 1;
         dim3 g2((n_q + 63) / 64, n_head, n_batch);
+        if (attn_func == JB_ATTN_TRANSPOSE_BLOCK) {
+            const int per_class = (n_q + block_ctx - 1) / block_ctx;
+            wpc = (per_class + 63) / 64;
+            g2.x = block_ctx * wpc;
+        }
 #define JB_LAUNCH_PF2(ND)                                                                                            \
     do {                                                                                                            \
-        size_t lds2 = (size_t)(4 * 16 + 2 * 32) * (ND * 16 + 8) * 2;                                                \
+        size_t lds2 = ((size_t)(4 * 16 + 32) * (ND * 16 + 8) + (size_t)(ND * 16) * 40) * 2;                         \
         if (lds2 > 64 * 1024)                                                                                       \
             JB_HIP(hipFuncSetAttribute((const void*)attn_prefill_v2_kernel<ND>,                                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                    \
         attn_prefill_v2_kernel<ND><<<g2, 256, lds2, s>>>(attn_func, (const f16*)q, (const f16*)kcache, (const f16*)vcache, \
-                                                        cache_cap, (f16*)out, n_head, d_head, block_ctx, t0, n_q);  \
+                                                        cache_cap, (f16*)out, n_head, d_head, block_ctx, t0, n_q, wpc); \
     } while (0)
         if (nd16 <= 1) JB_LAUNCH_PF2(1);
         else if (nd16 <= 2) JB_LAUNCH_PF2(2);

@@ -646,8 +646,34 @@ def test_gemv_second_output(H, name, dt, tol):
         assert np.abs(out2.cpu().numpy() - want2).max() < 1e-6 * max(1.0, np.abs(want2).max())
 
 
+@pytest.mark.parametrize("H_,d,bc,T,spans", [(1, 480, 16, 2100, ((5, 2000), (0, 2048))), (2, 64, 8, 1200, ((3, 1100),)),
+                                             (1, 480, 64, 8192, ((4096, 2048),))])
+def test_attn_prefill_transpose_on_the_tiled_kernel(H, H_, d, bc, T, spans):
+    """Transpose pattern on the 4-wave prefill kernel (round 4): a workgroup owns 64 consecutive MEMBERS of one residue class
+    mod block_ctx; classes with more than 64 members in the chunk take several workgroups (125 / 138 members here), the last
+    case is the upsamplers' second prefill chunk (positions 4096 .. 6143, 32 members per class, up to 96 keys each).  Against
+    fp32 math on the half operands, and the one-wave kernel for the same call."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(T + d)
+    N, S = 2, H_ * d
+    K = h16(rng.standard_normal((N, T, S)).astype(np.float32))
+    V = h16(rng.standard_normal((N, T, S)).astype(np.float32))
+    kc, vc = dev(K, torch.float16), dev(V, torch.float16)
+    for t0, nq in spans:
+        q = h16(rng.standard_normal((N, nq, S)).astype(np.float32))
+        got = H.attn_prefill(2, dev(q, torch.float16), kc, vc, H_, bc, t0).float().cpu().numpy()
+        L.lib().jb_tune_attn_prefill_v2(0)
+        try:
+            one_wave = H.attn_prefill(2, dev(q, torch.float16), kc, vc, H_, bc, t0).float().cpu().numpy()
+        finally:
+            L.lib().jb_tune_attn_prefill_v2(1)
+        want = _np_attention(2, q, K, V, H_, bc, None, list(range(t0, t0 + nq)), False)
+        assert np.abs(got - want).max() < 6e-3 * max(1.0, np.abs(want).max()), (t0, nq)
+        assert np.abs(got - one_wave).max() < 6e-3 * max(1.0, np.abs(want).max()), (t0, nq)
+
+
 @pytest.mark.parametrize("v2", [1, 0])
-@pytest.mark.parametrize("func", [0, 1, 3, 7])
+@pytest.mark.parametrize("func", [0, 1, 2, 3, 7])
 @pytest.mark.parametrize("H_,d,bc", [(1, 480, 128), (2, 64, 8), (1, 120, 8)])
 def test_attn_prefill_v2(H, func, H_, d, bc, v2):
     """fp16 prefill attention: the default 4-wave kernel sharing vector-staged K/V tiles (jb_tune_attn_prefill_v2(1)) and
