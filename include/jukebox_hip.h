@@ -306,9 +306,9 @@ typedef struct jb_engine_cfg {
      * a pitch rounded up to the k-tile, the padding zeroed once by the caller, lets the decode step's attn.c_proj run its
      * branch-free path (the packed weight image is zero-padded to whole k-tiles anyway). */
     int att_ld;
-    /* optional: (10 * launches_per_step + 1) * 32 zero-initialised words for software-pipelined launches
-     * (jb_engine_pipeline): per launch slot a 32-word group with its completion count and one flag byte per ticket shard,
-     * then per slot nine 32-word groups of ticket counters; the last 32-word group starts with an error word (slot + 1 of a launch whose wait for its producer timed out; 0 = none; never reset by
+    /* optional: (18 * launches_per_step + 1) * 32 zero-initialised words for software-pipelined launches
+     * (jb_engine_pipeline): per launch slot a completion count (32 words apart), then per slot nine ticket counters and
+     * eight shard flags (32 words apart each); the last 32-word group starts with an error word (slot + 1 of a launch whose wait for its producer timed out; 0 = none; never reset by
      * the library). */
     unsigned* pipe_words;
 } jb_engine_cfg;
@@ -334,7 +334,7 @@ int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* str
  * order: tokens and logits are bit-identical to the plain chain.  A pipelined jb_engine_decode is HOST-SYNCHRONOUS: it
  * drains the caller's stream, runs the steps on the pair and returns when they are done (no queue of the process holds a
  * waiting packet meanwhile).  enable != 0 returns JB_ERR_UNSUPPORTED unless every launch of this engine's step has a
- * pipelined form (cfg.pipe_words given, fp16, 8..16 samples, every layer a wide-value layer of one 480-channel head, width
+ * pipelined form (cfg.pipe_words given, fp16, <= 16 samples, every layer a wide-value layer of one 480-channel head, width
  * and n_mlp of 33..64 k-tiles: the 1b upsamplers), and while ANOTHER engine of the process has them on: a waiting launch
  * occupies compute units, and the waiters of two engines can leave no room for the launches they wait for -- one pipelined
  * engine at a time (enable = 0 or jb_engine_destroy releases the right).  The two streams must feed different hardware

@@ -157,7 +157,8 @@ __device__ __forceinline__ float jb_load_any(const void* p, int dtype, int64_t i
 // while launch j still runs; the dependency itself is a completion word per launch slot:
 //   runs[slot]    how often the slot has completed since the words were last zeroed (written by its last workgroup),
 //   tickets[slot] arrivals of the current run: 8 shard counters (workgroup index mod 8; 120-180 arrivals on ONE word
-//                 serialise at ~12 ns each) + one counter of finished shards, each in its own 128-byte line.
+//                 serialise at ~12 ns each) + one counter of finished shards, each in its own 128-byte line (+ 8 shard flag
+//                 words for protocol 1, below).
 // A launch reads its own count i, then thread 0 of every workgroup polls the producer slot until it has completed i + 1
 // times (slot 0 follows the last slot of the previous step: i times), and only then reads what the producer wrote -- with
 // sc1 loads (L1 bypass; the producer stored write-through and drained before it took its ticket), no cache-wide
@@ -173,9 +174,10 @@ struct JbPipe {
     long long timeout;                               // poll bound in ticks of the 100 MHz clock (engine: 2 s, JB_PIPE_TIMEOUT_MS)
     long long* dbg;                                  // optional [slot][4] stamps of the 100 MHz clock (JB_PIPE_DEBUG): poll
                                                      // entered, producer seen, own completion published
+    int proto;                                       // completion protocol: 0 = two-level ticket + one flag, 1 = a flag word per shard
 };
 constexpr int JB_PIPE_PAD = 32;                      // words between two slots' completion words (128 bytes)
-constexpr int JB_PIPE_TICKET_WORDS = 9 * JB_PIPE_PAD;   // per slot: 8 shard tickets + the shard count
+constexpr int JB_PIPE_TICKET_WORDS = 17 * JB_PIPE_PAD;  // per slot: 8 shard tickets + the shard count + (protocol 1) 8 shard flags
 // words the caller provides: completion counts, tickets, one error word
 __host__ __device__ constexpr size_t jb_pipe_words(int n_slots) { return (size_t)n_slots * (JB_PIPE_PAD + JB_PIPE_TICKET_WORDS) + JB_PIPE_PAD; }
 
@@ -203,29 +205,42 @@ __device__ __forceinline__ void jb_st_sc1(f16* base, int64_t el, f16 v) {
     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), jb_rsrc(base), (int)(el * 2), 0, 16);
 }
 
-// Completion protocol V4 (tools/pipelined_launch_probe.hip, V4): the slot's 32-word group holds  [0] the full count of its
-// runs (read only by the slot's own next run: same-stream order)  [2..3] eight flag BYTES, one per ticket shard.  The last
-// arriver of a shard stores its byte = (run + 1) mod 256 write-through; the consumer polls the 8-byte word until every
-// shard's byte shows its producer's run.  One returning atomic per workgroup and one byte store per shard instead of the
-// second-level ticket and the flag store.
 // Own completion count: every thread asks for it next to its first requests (a broadcast load).
 __device__ __forceinline__ unsigned jb_pipe_own(const JbPipe& P) { return jb_ld_word(P.runs + P.slot * JB_PIPE_PAD); }
-__device__ __forceinline__ unsigned long long jb_ld_word8(const unsigned* p) {
-    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // Wait for the producer launch; ends in a workgroup barrier.
 __device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own) {
-    if (threadIdx.x == 0) {
-        // every launch of a step has >= 8 workgroups (the sampler: one per sample row -- fewer than 8 rows would need `keep`
-        // narrowed to the shards that exist; jb_engine_pipeline refuses engines of fewer than 8 samples in this form)
-        const unsigned long long want = 0x0101010101010101ull * (unsigned long long)((P.slot == 0 ? own : own + 1) & 0xffu);
-        const unsigned* w = P.runs + P.prev * JB_PIPE_PAD + 2;
-        const bool stamp = P.dbg && blockIdx.x == 0 && blockIdx.y == 0;
-        if (stamp) P.dbg[P.slot * 4] = wall_clock64();
-        if (jb_ld_word8(w) != want) {
+    if (P.proto == 1) {
+        // Protocol 1: the last arriver of each of the 8 ticket shards stores the run's number into the shard's own flag word
+        // (its own 128-byte line, written once per run); lanes 0..7 of the first wave poll one flag each.  No second-level
+        // ticket: one atomic round trip less per launch.  Every launch of the step has >= 8 workgroups (engines of >= 8 samples).
+        if (threadIdx.x < 64) {
+            const unsigned need = P.slot == 0 ? own : own + 1;
+            const unsigned* w = P.tickets + (size_t)P.prev * JB_PIPE_TICKET_WORDS + (9 + (threadIdx.x & 7)) * JB_PIPE_PAD;
+            const bool stamp = P.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0;
+            if (stamp) P.dbg[P.slot * 4] = wall_clock64();
             const long long t0 = wall_clock64();
             unsigned spins = 0;
-            while (jb_ld_word8(w) != want) {
+            while (!__all(threadIdx.x >= 8 || jb_ld_word(w) >= need)) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 255u) == 0) {
+                    if (jb_ld_word(P.err) != 0u) break;
+                    if (wall_clock64() - t0 > P.timeout) { if (threadIdx.x == 0) jb_st_word(P.err, (unsigned)P.slot + 1u); break; }
+                }
+            }
+            if (stamp) P.dbg[P.slot * 4 + 1] = wall_clock64();
+        }
+        __syncthreads();
+        return;
+    }
+    if (threadIdx.x == 0) {
+        const unsigned need = P.slot == 0 ? own : own + 1;
+        const unsigned* w = P.runs + P.prev * JB_PIPE_PAD;
+        const bool stamp = P.dbg && blockIdx.x == 0 && blockIdx.y == 0;
+        if (stamp) P.dbg[P.slot * 4] = wall_clock64();
+        if (jb_ld_word(w) < need) {
+            const long long t0 = wall_clock64();
+            unsigned spins = 0;
+            while (jb_ld_word(w) < need) {
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 255u) == 0) {
                     // the error word is sticky: once ONE wait of this engine has timed out, the tokens are void and the
@@ -249,13 +264,19 @@ __device__ __forceinline__ void jb_pipe_publish(const JbPipe& P, unsigned own) {
         const unsigned n_wg = gridDim.x * gridDim.y * gridDim.z;
         const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), shard = b & 7u;
         const unsigned members = (n_wg - shard + 7u) >> 3, n_shards = n_wg < 8u ? n_wg : 8u;
-        (void)n_shards;
         if (__hip_atomic_fetch_add(tk + shard * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
             jb_st_word(tk + shard * JB_PIPE_PAD, 0u);
-            if (shard == 0) jb_st_word(P.runs + P.slot * JB_PIPE_PAD, own + 1);
-            __hip_atomic_store(reinterpret_cast<unsigned char*>(P.runs + P.slot * JB_PIPE_PAD + 2) + shard, (unsigned char)((own + 1) & 0xffu),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (P.dbg && shard == 0) P.dbg[P.slot * 4 + 2] = wall_clock64();
+            if (P.proto == 1) {
+                if (shard == 0) {                      // the slot's own count: read by its next run only (same-stream order)
+                    jb_st_word(P.runs + P.slot * JB_PIPE_PAD, own + 1);
+                    if (P.dbg) P.dbg[P.slot * 4 + 2] = wall_clock64();
+                }
+                jb_st_word(tk + (9 + shard) * JB_PIPE_PAD, own + 1);
+            } else if (__hip_atomic_fetch_add(tk + 8 * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_shards - 1) {
+                jb_st_word(tk + 8 * JB_PIPE_PAD, 0u);
+                jb_st_word(P.runs + P.slot * JB_PIPE_PAD, own + 1);
+                if (P.dbg) P.dbg[P.slot * 4 + 2] = wall_clock64();
+            }
         }
     }
 }

@@ -189,10 +189,14 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
     const int n_slots = jb_engine_launches_per_step(e);
     int slot = 0;
+    // completion protocol (common.h): JB_PIPE_PROTO=1 -- a flag word per ticket shard, engines of >= 8 samples -- is the round-4
+    // experiment; 0 (two-level ticket, one flag) is what round 3 measured
+    const int proto_env = getenv("JB_PIPE_PROTO") ? atoi(getenv("JB_PIPE_PROTO")) : 0;      // read when a step is captured
     JbPipe pp{c.pipe_words, c.pipe_words ? c.pipe_words + (size_t)n_slots * JB_PIPE_PAD : nullptr,
               c.pipe_words ? c.pipe_words + jb_pipe_words(n_slots) - JB_PIPE_PAD : nullptr, 0, 0,
               (getenv("JB_PIPE_TIMEOUT_MS") ? atoll(getenv("JB_PIPE_TIMEOUT_MS")) : 2000ll) * 100000ll,
-              (c.pipe_words && getenv("JB_PIPE_DEBUG")) ? reinterpret_cast<long long*>(c.pipe_words + jb_pipe_words(n_slots)) : nullptr};
+              (c.pipe_words && getenv("JB_PIPE_DEBUG")) ? reinterpret_cast<long long*>(c.pipe_words + jb_pipe_words(n_slots)) : nullptr,
+              (proto_env == 1 && c.n_batch >= 8) ? 1 : 0};
     // the pipeline slot of the next launch, or NULL for the plain chain; `mine`: this call enqueues it
     bool mine = true;
     auto next = [&]() -> const JbPipe* {
@@ -262,11 +266,10 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
 }
 
 // Software-pipelined launches of the decode step.  Available where every launch of the step has a
-// pipelined form: fp16, 8..16 samples (every launch has >= 8 workgroups: one flag byte per ticket shard, common.h), wide-value
-// layers throughout (one head of 480 channels), widths of 33..64 k-tiles.
+// pipelined form: fp16, <= 16 samples, wide-value layers throughout (one head of 480 channels), widths of 33..64 k-tiles.
 static bool pipeline_eligible(const JbEngine* e) {
     const jb_engine_cfg& c = e->cfg;
-    if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || c.n_batch < 8 || c.n_head != 1 || c.n_state != 480 || !c.x_out_packed) return false;
+    if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || c.n_head != 1 || c.n_state != 480 || !c.x_out_packed) return false;
     if (c.width % 32 || c.n_mlp % 32 || c.width / 32 < 33 || c.width / 32 > 64 || c.n_mlp / 32 < 33 || c.n_mlp / 32 > 64) return false;
     for (const jb_layer& L : e->layers)
         if (!layer_wide(c, L) || !L.w_fc_f || layer_max_keys(c, L) > 128) return false;     // one 16-key tile per attention wave
@@ -277,7 +280,7 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     JB_REQUIRE(handle, "null engine");
     JbEngine* e = (JbEngine*)handle;
     if (enable && !pipeline_eligible(e)) JB_UNSUPPORTED("this engine's decode step has launches without a pipelined form (needs pipe_words, "
-                                                        "fp16, 8..16 samples, wide-value layers of one 480-channel head, 33..64 k-tiles)");
+                                                        "fp16, <= 16 samples, wide-value layers of one 480-channel head, 33..64 k-tiles)");
     // ONE pipelined engine per process.  Its waiting launch holds up to 180 workgroup slots while it spins; the producer it
     // waits for -- in particular the attention launch, 198 registers per lane: one workgroup per otherwise empty compute
     // unit -- must still find room.  One waiter leaves >= 76 compute units free of waiters; the waiters of two engines can
@@ -406,7 +409,7 @@ static int prepare_pipeline(JbEngine* e) {
 static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s, bool use_graph = true) {
     const int n_slots = jb_engine_launches_per_step(e);
     JB_TRY(prepare_pipeline(e));
-    // completion counts, flag bytes and tickets start from zero in every call
+    // completion counts and tickets start from zero in every call
     JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));
     JB_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < n_steps; ++i)

@@ -209,9 +209,9 @@ class PriorEngine:
         if any(splits(lay) for lay in pk.layers):
             self.att_parts = e(N, 4, S)
             self.att_ml = e(N, self.H, 4, 2, dtype=torch.float32)
-        # completion words of software-pipelined launches (jb_engine_pipeline): count + flag bytes + tickets per launch slot, error
-        # word last (+ room for the JB_PIPE_DEBUG stamps: 4 x int64 per slot behind the error group)
-        self.pipe_words = torch.zeros((10 * (5 * self.depth + 2) + 1) * 32 + (5 * self.depth + 2) * 8, dtype=torch.int32, device=dev)
+        # completion words of software-pipelined launches (jb_engine_pipeline): counts + tickets per launch slot, error word last
+        # (+ room for the JB_PIPE_DEBUG stamps: 4 x int64 per slot behind the error group)
+        self.pipe_words = torch.zeros((18 * (5 * self.depth + 2) + 1) * 32 + (5 * self.depth + 2) * 8, dtype=torch.int32, device=dev)
         self.pipelined = False
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -323,16 +323,16 @@ class PriorEngine:
         """JB_PIPE_DEBUG=1: (n_slots, 4) int64 ticks of the 100 MHz clock of the last pipelined step: poll entered, producer
         seen, completion published."""
         n = self.launches_per_step
-        base = (10 * n + 1) * 32
+        base = (18 * n + 1) * 32
         return self.pipe_words[base:base + n * 8].view(torch.int64).reshape(n, 4).cpu().numpy()
 
     def pipe_error(self):
         """0, or slot + 1 of a pipelined launch whose wait for its producer timed out (sticky)."""
-        return int(self.pipe_words[10 * self.launches_per_step * 32].item())
+        return int(self.pipe_words[18 * self.launches_per_step * 32].item())
 
     def clear_pipe_error(self):
         """Forget a recorded timeout (the engine must be idle).  Until then every pipelined wait gives up at once."""
-        self.pipe_words[10 * self.launches_per_step * 32] = 0
+        self.pipe_words[18 * self.launches_per_step * 32] = 0
 
     def close(self):
         if getattr(self, "handle", None):

@@ -16,8 +16,12 @@ from .transformer import attn_func_of_layer, decode_key_index, rounded_prime_len
 
 class TorchDecodeStack:
     def __init__(self, sd, prefix, n_in, n_ctx, n_head, n_depth, attn_order=0, blocks=None, m_attn=0.25, prime_len=None,
-                 n_batch=1, encoder_kv=None):
-        g = lambda name: torch.as_tensor(np.asarray(sd[prefix + name], dtype=np.float32))
+                 n_batch=1, encoder_kv=None, device="cpu"):
+        """device: where torch runs the port.  "cpu" is the CPU baseline's form; the GPU suite's full-size cases pass "cuda" --
+        torch's own fp32 kernels (rocBLAS / ATen), still an implementation independent of libjukebox_hip -- because 64 steps
+        of a 72-layer model at batch 16 cost minutes on the lease's host cores."""
+        self.device = torch.device(device)
+        g = lambda name: torch.as_tensor(np.asarray(sd[prefix + name], dtype=np.float32)).to(self.device)
         self.n_in, self.n_ctx, self.H, self.L = n_in, n_ctx, n_head, n_depth
         self.S = int(m_attn * n_in)
         self.bc = n_ctx // blocks if blocks else None
@@ -31,11 +35,11 @@ class TorchDecodeStack:
                 b0="ln_0.bias", wf="mlp.c_fc.w", bf="mlp.c_fc.b", w2="mlp.c_proj.w", b2="mlp.c_proj.b", g1="ln_1.weight",
                 b1="ln_1.bias").items()})
         cap = lambda d: self.prime_r if self.funcs[d] == 7 else (0 if self.funcs[d] == 6 else n_ctx)
-        self.K = [torch.zeros(n_batch, cap(d), self.S) for d in range(n_depth)]
-        self.V = [torch.zeros(n_batch, cap(d), self.S) for d in range(n_depth)]
+        self.K = [torch.zeros(n_batch, cap(d), self.S, device=self.device) for d in range(n_depth)]
+        self.V = [torch.zeros(n_batch, cap(d), self.S, device=self.device) for d in range(n_depth)]
         # cross-attention layers (attn_func 6): key / value = c_enc_kv(encoder_kv), once (decode_qkv, factored_attention.py:273-280)
         if 6 in self.funcs:
-            ekv = torch.as_tensor(np.asarray(encoder_kv, dtype=np.float32))
+            ekv = torch.as_tensor(np.asarray(encoder_kv, dtype=np.float32)).to(self.device)
             for d in range(n_depth):
                 if self.funcs[d] == 6:
                     kv = torch.matmul(ekv, g(f"_attn_mods.{d}.attn.c_enc_kv.w")) + g(f"_attn_mods.{d}.attn.c_enc_kv.b")
@@ -45,7 +49,7 @@ class TorchDecodeStack:
     @torch.no_grad()
     def forward(self, x):
         """x: (N, 1, n_in) float32 at position self.t; returns (N, 1, n_in)."""
-        x = torch.as_tensor(x, dtype=torch.float32).reshape(-1, self.n_in)
+        x = torch.as_tensor(x, dtype=torch.float32).to(self.device).reshape(-1, self.n_in)
         N, S, H, t = x.shape[0], self.S, self.H, self.t
         d_head = S // H
         scale2 = 1.0 / np.sqrt(d_head)                       # (d^-1/4)^2, factored_attention.py:84-92
@@ -61,7 +65,7 @@ class TorchDecodeStack:
                     self.K[d][:, t], self.V[d][:, t] = k, v
                 idx = decode_key_index(func, t, self.bc, self.prime_r)
             if idx is None:
-                a = torch.zeros(N, S)
+                a = torch.zeros(N, S, device=self.device)
             else:
                 sl = slice(int(idx[0]), int(idx[-1]) + 1, int(idx[1] - idx[0]) if len(idx) > 1 else 1)
                 Ks = self.K[d][:, sl].reshape(N, -1, H, d_head).transpose(1, 2)      # (N, H, kl, d)

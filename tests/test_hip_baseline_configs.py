@@ -240,20 +240,22 @@ def _full_size_case(tag):
         torch.cuda.synchronize()
 
     # (b) decode of all samples from the validated caches
+    # (the port runs on torch's own GPU kernels here -- rocBLAS / ATen in fp32, nothing of libjukebox_hip: on the lease's host
+    # cores these 64 steps were 1 to 2 minutes per case)
     st = TorchDecodeStack(tr_sd, "", W, seq, heads, depth, attn_order=attn_order, blocks=blocks, prime_len=prime_len, n_batch=N,
-                          encoder_kv=enc_np)
+                          encoder_kv=enc_np, device="cuda")
     for d in range(depth):
         if funcs[d] == 6:
             continue                             # the port projects the encoder states itself
         n = min(st.K[d].shape[1], t0)
-        st.K[d][:, :n] = eng.kcaches[d][:, :n].cpu()
-        st.V[d][:, :n] = eng.vcaches[d][:, :n].cpu()
+        st.K[d][:, :n] = eng.kcaches[d][:, :n]
+        st.V[d][:, :n] = eng.vcaches[d][:, :n]
     st.t = t0
     w_out = sd_np["x_out.weight"]
     for i in range(n_steps):
         t = t0 + i
         x = FS.embed(sd_np, z, t, 1, xc_np, start)                # the engine's own tokens: teacher-forced on its stream
-        h = st.forward(x).numpy().reshape(N, W)
+        h = st.forward(x).cpu().numpy().reshape(N, W)
         if xc_np is not None and not merged_decoder:
             h = h + xc_np[:, t]                                    # add_cond_after_transformer
         logits = h @ w_out.T

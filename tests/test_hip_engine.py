@@ -221,7 +221,8 @@ def test_wide_value_engine_refuses_prefill_behind_decoded_positions(PE):
     assert int(eng.t_dev.item()) == 10
 
 
-def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch):
+@pytest.mark.parametrize("proto", ["0", "1"])
+def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, proto):
     """Software-pipelined launches (jb_engine_pipeline: the launches of a step alternate between two streams, launch j+1
     waits on launch j's completion word instead of on a kernel boundary): same kernels' arithmetic in the same order, so
     logits and tokens are BIT-identical to the plain chain -- upsampler geometry (one 480-channel head, wide-value layers),
@@ -232,6 +233,7 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch):
     xc = torch.from_numpy((rng.standard_normal((N, seq, width)) * 0.1).astype(np.float32))
     prime = torch.from_numpy(rng.integers(0, bins, (N, 200))).cuda()
     outs = {}
+    monkeypatch.setenv("JB_PIPE_PROTO", proto)          # completion protocol: two-level ticket + one flag / a flag word per shard
     for mode in ("chain", "pipelined"):
         monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1" if mode == "pipelined" else "0")
         eng = PE(sd, "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=1, attn_order=2, blocks=blocks,

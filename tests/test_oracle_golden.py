@@ -238,20 +238,28 @@ def test_separated_encoder_decoder_prior(tiny_hps):
 
 
 def test_torch_port_matches_numpy_oracle():
-    """oracle/torch_port.py (what bench.py times as the CPU baseline) against the golden-pinned numpy oracle: the same
-    hidden states step by step, for the block / transpose / prev and the prime patterns."""
+    """oracle/torch_port.py (what bench.py times as the CPU baseline, and the checker of the full-size decode steps) against the
+    golden-pinned numpy oracle: the same hidden states step by step, for the block / transpose / prev, the prime and the
+    cross-attention patterns (attn_order 10 as in prior_5b_lyrics: layer 18 of 20 reads the encoder states)."""
     from oracle.torch_port import TorchDecodeStack
     from oracle.transformer import Transformer
     rng = np.random.default_rng(0)
     for cfg in (dict(n_in=32, n_ctx=48, n_head=2, n_depth=6, attn_order=2, blocks=8),
                 dict(n_in=32, n_ctx=64, n_head=2, n_depth=8, attn_order=12, blocks=8, prime_len=12),
-                dict(n_in=24, n_ctx=20, n_head=3, n_depth=2, attn_order=0, blocks=None)):
+                dict(n_in=24, n_ctx=20, n_head=3, n_depth=2, attn_order=0, blocks=None),
+                dict(n_in=32, n_ctx=24, n_head=2, n_depth=20, attn_order=10, blocks=4, encoder_dims=7)):
+        from oracle.transformer import attn_func_of_layer
         W, D = cfg["n_in"], cfg["n_depth"]
         S = W // 4
         sd = {}
+        enc = rng.standard_normal((3, cfg["encoder_dims"], W)).astype(np.float32) if cfg.get("encoder_dims") else None
         for d in range(D):
             p = f"_attn_mods.{d}."
-            for nm, shp in (("attn.c_attn.w", (W, 3 * S)), ("attn.c_proj.w", (S, W)), ("mlp.c_fc.w", (W, W)),
+            cross = attn_func_of_layer(cfg["attn_order"], d) == 6
+            if cross:
+                sd[p + "attn.c_enc_kv.w"] = (0.2 * rng.standard_normal((W, 2 * S))).astype(np.float32)
+                sd[p + "attn.c_enc_kv.b"] = (0.1 * rng.standard_normal(2 * S)).astype(np.float32)
+            for nm, shp in (("attn.c_attn.w", (W, S if cross else 3 * S)), ("attn.c_proj.w", (S, W)), ("mlp.c_fc.w", (W, W)),
                             ("mlp.c_proj.w", (W, W))):
                 sd[p + nm] = (0.2 * rng.standard_normal(shp)).astype(np.float32)
                 sd[p + nm[:-1] + "b"] = (0.1 * rng.standard_normal(shp[1])).astype(np.float32)
@@ -259,10 +267,10 @@ def test_torch_port_matches_numpy_oracle():
                 sd[p + ln + ".weight"] = (1 + 0.1 * rng.standard_normal(W)).astype(np.float32)
                 sd[p + ln + ".bias"] = (0.1 * rng.standard_normal(W)).astype(np.float32)
         ref = Transformer(sd, "", **cfg)
-        port = TorchDecodeStack(sd, "", n_batch=3, **cfg)
+        port = TorchDecodeStack(sd, "", n_batch=3, encoder_kv=enc, **{k: v for k, v in cfg.items() if k != "encoder_dims"})
         for t in range(cfg["n_ctx"]):
             x = rng.standard_normal((3, 1, W)).astype(np.float32)
-            want = ref.forward(x)
+            want = ref.forward(x, encoder_kv=enc)
             got = port.forward(x).numpy()
             assert np.abs(got - want).max() < 2e-4 * max(1.0, np.abs(want).max()), (cfg["attn_order"], t)
 

@@ -1,15 +1,20 @@
-// User-mode AQL dispatch for the decode step: a hardware queue of the engine's own, fed with
-// pre-built kernel-dispatch packets.
+// User-mode AQL dispatch: a hardware queue of one's own, fed with pre-built kernel-dispatch packets (probe tool).
 //
-// Why not a HIP stream / hipGraph: the software-pipelined launches (section 4.2) need launch j+1 dispatched while launch j
-// runs.  HIP offers that only across streams -- i.e. across hardware queues, with everything that brings (stream -> queue
-// multiplexing, two graph replays per step, cross-queue ordering nobody guarantees) -- and refuses hipExtAnyOrderLaunch on
-// gfx9.  An AQL packet, however, carries the ordering itself: with the BARRIER bit clear the packet processor starts the
-// next packet of the SAME queue as soon as the previous one's workgroups are placed.  The packets of a step are identical
-// for every position (the position lives in device memory), so they are built once; a step is one memcpy of its packets
-// into the ring plus one doorbell write.
+// Why it was tried (round 4): the software-pipelined launches need launch j+1 dispatched while launch j
+// runs.  HIP offers that only across streams -- i.e. across hardware queues -- and refuses hipExtAnyOrderLaunch on gfx9.  An AQL
+// packet carries the ordering itself: with the BARRIER bit clear the packet processor starts the next packet of the SAME queue
+// as soon as the previous one's workgroups are placed, and its header says which cache actions surround the dispatch.  The
+// packets of a step are identical for every position (the position lives in device memory), so they are built once; a replay is
+// one memcpy of the packets into the ring plus one doorbell write (host cost: nothing measurable).
+// What it measured (tools/pipelined_launch_probe.hip, profiles/r04_pipelined_launch_probe_v1_aql.log, the 1920 x 1920 phase):
+//   barrier = 1, acquire / release at agent scope   8.3 us per phase  (HIP's own launch chain: 6.7 -- its packets fence less)
+//   barrier = 0, acquire / release at agent scope   7.7
+//   barrier = 0, no fences                          5.6  (valid for kernels that hand over with sc1 accesses only)
+//   two HIP streams, barrier = 1 each                4.7  <- what the engine uses
+// i.e. one queue without barriers pipelines less than two queues do (the packet processor still walks one queue's packets one
+// after the other), and an agent-scope acquire costs 2 us per packet.  Not used by the library.
 //
-// The kernels stay ordinary HIP kernels of this library: their descriptors are found in the executables HIP has loaded
+// The kernels stay ordinary HIP kernels: their descriptors are found in the executables HIP has loaded
 // (hsa_ven_amd_loader_iterate_executables) under the name hipKernelNameRefByPtr gives, so there is one code object, one
 // copy of every kernel, and the same kernel can still be launched through HIP.
 #pragma once

@@ -22,15 +22,15 @@
 //       capture in ONE graph replays at 22 us per kernel: round 3, profiles/r03_pipelined_launch_probe.log)
 // Spin loops are bounded: after 2^22 polls a workgroup raises the abort flag, every later poll returns at once and the
 // run is reported as aborted (no hung GPU).
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/pipelined_launch_probe tools/pipelined_launch_probe.hip
-// Run:   tools/pipelined_launch_probe [graph launches, default 40]
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tools -o tools/pipelined_launch_probe tools/pipelined_launch_probe.hip -lhsa-runtime64
+// Run:   tools/pipelined_launch_probe [graph launches, default 40] [first protocol] [last protocol] [1: the AQL modes too]
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <vector>
-#include "../jukebox_amd/csrc/aql.h"
+#include "aql_queue.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 constexpr int N_EL = 16 * 1920;            // halfs per activation block
@@ -145,6 +145,28 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
             }
             s_i = i;
         }
+    } else if constexpr (V == 5 || V == 7) {
+        // V5: 8 shard tickets; the last arriver of a shard stores the run's number into the shard's own FLAG WORD (write-through,
+        // once per run); lanes 0..7 of wave 0 poll one flag word each.  V5: the 8 words in 8 different 128-byte lines; V7: in
+        // one line.  Against the engine's protocol (V6) this drops the second-level ticket: one atomic round trip per launch.
+        if (tid < 64) {
+            const unsigned i = ld_flag(a.flags + j * PAD + 1);
+            if constexpr (WAIT) {
+                const int prev = j == 0 ? K - 1 : j - 1;
+                const unsigned n_shards = a.G < 8 ? (unsigned)a.G : 8u, need = j == 0 ? i : i + 1;
+                const unsigned* w = a.rows + (size_t)prev * 1024 + (V == 5 ? 256 + (tid & 7) * 32 : 512 + (tid & 7));
+                for (unsigned spins = 0;; ++spins) {
+                    const bool ok = (unsigned)tid >= n_shards || ld_flag(w) >= need;
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins > (1u << 22) || ((spins & 255) == 255 && ld_flag(a.abort_flag))) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            if (tid == 0) s_i = i;
+        }
     } else if (tid == 0) {
         const unsigned i = ld_flag(a.flags + j * PAD);
         if constexpr (WAIT) {
@@ -217,6 +239,31 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    } else if constexpr (V == 5 || V == 7) {
+        if (tid == 0) {
+            const unsigned shard = (unsigned)wg & 7u, members = ((unsigned)a.G - shard + 7u) >> 3;
+            unsigned* tk = a.rows + (size_t)j * 1024 + shard * 32;
+            if (__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (shard == 0) __hip_atomic_store(a.flags + j * PAD + 1, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.rows + (size_t)j * 1024 + (V == 5 ? 256 + shard * 32 : 512 + shard), i + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else if constexpr (V == 6) {
+        // V6: the engine's protocol (common.h, jb_pipe_publish): 8 shard tickets + a count of finished shards, the last shard's last
+        // workgroup stores the slot's completion count, which the consumer polls (as V1)
+        if (tid == 0) {
+            const unsigned shard = (unsigned)wg & 7u, members = ((unsigned)a.G - shard + 7u) >> 3, n_shards = a.G < 8 ? (unsigned)a.G : 8u;
+            unsigned* tk = a.rows + (size_t)j * 1024;
+            if (__hip_atomic_fetch_add(tk + shard * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(tk + shard * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_add(tk + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_shards - 1) {
+                    __hip_atomic_store(tk + 256, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.flags + j * PAD, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     } else if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(a.tickets + j * PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == (unsigned)a.G - 1) {
@@ -252,7 +299,7 @@ int main(int argc, char** argv) {
     struct Shape { int G; size_t wbytes; const char* what; };
     const Shape shapes[3] = {{120, 7372800, "c_fc / mlp.c_proj (1920x1920)"}, {192, 11059200, "wide c_attn (1920x2880)"},
                              {120, 0, "no weights"}};
-    unsigned* rows; CK(hipMalloc(&rows, (size_t)K * 256 * 4));
+    unsigned* rows; CK(hipMalloc(&rows, (size_t)K * 1024 * 4));
     // kind 0: one graph (all streams captured into it)   1: eager   2: one single-stream graph per stream, replayed side by side
     struct Mode { int ns; bool wait; int kind; const char* name; };
     const Mode modes[] = {{1, false, 0, "graph 1 stream, no wait"}, {1, true, 0, "graph 1 stream, wait"},
@@ -264,13 +311,16 @@ int main(int argc, char** argv) {
         if (a.w_phase_u4 == 0) a.w_phase_u4 = (size_t)sh.G;      // one dummy vector per workgroup
         CK(hipMemcpy(act, h.data(), N_EL * 2, hipMemcpyHostToDevice));
         CK(hipMemset(flags, 0, K * PAD * 4)); CK(hipMemset(tickets, 0, K * PAD * 4)); CK(hipMemset(err, 0, 4)); CK(hipMemset(abortf, 0, 4));
-        CK(hipMemset(rows, 0, (size_t)K * 256 * 4));
+        CK(hipMemset(rows, 0, (size_t)K * 1024 * 4));
         CK(hipDeviceSynchronize());
         auto launch_j = [&](int j, hipStream_t s) {
             if (v == 1) { if (m.wait) launch<1, true>(a, j, s); else launch<1, false>(a, j, s); }
             else if (v == 2) { if (m.wait) launch<2, true>(a, j, s); else launch<2, false>(a, j, s); }
             else if (v == 3) { if (m.wait) launch<3, true>(a, j, s); else launch<3, false>(a, j, s); }
-            else { if (m.wait) launch<4, true>(a, j, s); else launch<4, false>(a, j, s); }
+            else if (v == 4) { if (m.wait) launch<4, true>(a, j, s); else launch<4, false>(a, j, s); }
+            else if (v == 5) { if (m.wait) launch<5, true>(a, j, s); else launch<5, false>(a, j, s); }
+            else if (v == 6) { if (m.wait) launch<6, true>(a, j, s); else launch<6, false>(a, j, s); }
+            else { if (m.wait) launch<7, true>(a, j, s); else launch<7, false>(a, j, s); }
         };
         float ms = 0.f;
         if (m.kind == 0) {
@@ -321,13 +371,13 @@ int main(int argc, char** argv) {
         fflush(stdout);
         if (ab) { printf("aborted: a poll timed out -- stopping\n"); return 2; }
     }
-    // ---- the same chain through a hardware queue of our own (jukebox_amd/csrc/aql.h): pre-built AQL packets, one memcpy into the
+    // ---- the same chain through a hardware queue of our own (tools/aql_queue.h): pre-built AQL packets, one memcpy into the
     // ring + one doorbell per replay.  barrier = 1: the packet processor keeps stream order (today's chain without HIP);
     // barrier = 0: packet j+1 is dispatched as soon as packet j's workgroups are placed -- pipelined launches in ONE queue.
     // acquire / release: the cache actions the packet processor performs around each dispatch (2 = agent scope as HIP's launches,
     // 0 = none: V1 / V4 move their activations with sc1 accesses and need none).  `lds`: extra LDS per workgroup, i.e. how many
     // launches can be resident at once (the depth of the run-ahead).
-    {
+    if (argc > 4 && atoi(argv[4]) != 0) {
         jb_aql::Queue Q;
         if (!Q.create(0, 16384)) { printf("aql: %s\n", Q.error.c_str()); return 0; }
         struct AqlMode { int v; bool wait; bool barrier; int acq, rel; unsigned lds; const char* name; };
@@ -349,7 +399,7 @@ int main(int argc, char** argv) {
             if (a.w_phase_u4 == 0) a.w_phase_u4 = (size_t)sh.G;
             CK(hipMemcpy(act, h.data(), N_EL * 2, hipMemcpyHostToDevice));
             CK(hipMemset(flags, 0, K * PAD * 4)); CK(hipMemset(tickets, 0, K * PAD * 4)); CK(hipMemset(err, 0, 4)); CK(hipMemset(abortf, 0, 4));
-            CK(hipMemset(rows, 0, (size_t)K * 256 * 4));
+            CK(hipMemset(rows, 0, (size_t)K * 1024 * 4));
             CK(hipDeviceSynchronize());
             const void* fn = m.v == 1 ? (m.wait ? (const void*)&phase_kernel<1, true> : (const void*)&phase_kernel<1, false>)
                                       : (const void*)&phase_kernel<4, true>;
