@@ -189,9 +189,10 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
     const int n_slots = jb_engine_launches_per_step(e);
     int slot = 0;
-    // completion protocol (common.h): JB_PIPE_PROTO=1 -- a flag word per ticket shard, engines of >= 8 samples -- is the round-4
-    // experiment; 0 (two-level ticket, one flag) is what round 3 measured
-    const int proto_env = getenv("JB_PIPE_PROTO") ? atoi(getenv("JB_PIPE_PROTO")) : 0;      // read when a step is captured
+    // completion protocol (common.h): 1 -- a flag word per ticket shard, polled by eight lanes; engines of >= 8 samples -- unless
+    // JB_PIPE_PROTO=0 asks for round 3's two-level ticket with one flag (measured on the upsampler step: 1.541 vs 1.601 ms,
+    // profiles/r04_bench_engine_up_proto{1,0}.log).  Read when a step is captured.
+    const int proto_env = getenv("JB_PIPE_PROTO") ? atoi(getenv("JB_PIPE_PROTO")) : 1;
     JbPipe pp{c.pipe_words, c.pipe_words ? c.pipe_words + (size_t)n_slots * JB_PIPE_PAD : nullptr,
               c.pipe_words ? c.pipe_words + jb_pipe_words(n_slots) - JB_PIPE_PAD : nullptr, 0, 0,
               (getenv("JB_PIPE_TIMEOUT_MS") ? atoll(getenv("JB_PIPE_TIMEOUT_MS")) : 2000ll) * 100000ll,
