@@ -120,6 +120,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # decode longer, and the job time does not move; prefilling the next window in a second engine while the current one
     # decodes -- the prefill's bandwidth slows the latency-bound chain by what it saves.  Neither is in the tree.
     order = sorted(levels)                                 # lowest level first
+    lowest = min(sample_levels)
     prios = [-1, -1, 0, 0]      # (round 2: every assignment of priorities to the levels measured the same job time)
     stream_of = {level: t.cuda.Stream(device=device, priority=prios[min(i, 3)]) if on_gpu else None
                  for i, level in enumerate(order)}
@@ -131,10 +132,36 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         ev.record(t.cuda.current_stream(device) if stream is None else stream)
         return ev
 
+    # EXPERIMENT (hps.confine_upper_cus / JB_CONFINE_UPPER_CUS = n, a multiple of 8): once the lowest level starts, the levels
+    # above it move to streams confined to the last n / 8 compute units of every XCD and the lowest level runs pipelined
+    # launches on the others from its first step.  A lower level consumes the codes of the level above at a quarter of its
+    # own rate, so the upper levels can afford to be slow; their launches never meet the lowest level's waiting launches on a
+    # compute unit (the starvation measured in round 3), and the lowest level's step is the pipelined one for the whole job.
+    n_conf = int(hps.get("confine_upper_cus", 0) or os.environ.get("JB_CONFINE_UPPER_CUS", "0") or 0) if on_gpu else 0
+    n_conf = max(0, min(n_conf // 8 * 8, 128))
+    confined, raw_streams = {}, []
+
+    def confine_upper_levels():
+        from . import _lib as L
+        for k, l in enumerate(x for x in levels if x != lowest and x not in finished):
+            bits = [b for b in range(256 - n_conf, 256) if b != 255 - k]      # distinct masks: distinct hardware queues
+            st, raw = L.cu_mask_stream(bits, device=device)
+            raw_streams.append(raw)
+            with cond:
+                confined[l] = st
+
+    def move_to_confined(level):
+        """Called by an upper level's own thread between two decode calls: continue on the confined stream."""
+        st = confined.get(level)
+        if st is not None and t.cuda.current_stream(device) != st:
+            st.wait_stream(t.cuda.current_stream(device))
+            t.cuda.set_stream(st)
+
     def worker(level):
         try:
             prior = priors[level]
             stream = stream_of[level]
+            cur = (lambda: t.cuda.current_stream(device)) if on_gpu else (lambda: None)
             if on_gpu:
                 stream.wait_stream(current)
             with (t.cuda.stream(stream) if on_gpu else contextlib.nullcontext()):
@@ -160,7 +187,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                                 f"has only {progress[level + 1]} -- sample_length is shorter than this level's context")
                             ev = ready_event.get(level + 1)
                         if ev is not None:
-                            stream.wait_event(ev)
+                            cur().wait_event(ev)
                     k = dict(kw)
                     if sample_tokens is not None:
                         k["sample_tokens"] = sample_tokens
@@ -181,6 +208,13 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                             progress[level] = start + hi
                             ready_event[level] = ev
                             cond.notify_all()
+                        if n_conf:
+                            move_to_confined(level)
+
+                    if n_conf and level == lowest and not confined:
+                        confine_upper_levels()                     # from here on the upper levels keep to their compute units
+                    elif n_conf:
+                        move_to_confined(level)
 
                     prior.window_tap = (chunk, publish) if tapped else None
                     t_w = time.perf_counter()
@@ -192,7 +226,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                     new_len = int(out[level].shape[1])
                     if not tapped:
                         zbuf[level][:, known:new_len] = out[level][:, known:new_len]
-                    ev = new_event(stream)
+                    ev = new_event(cur())
                     with cond:
                         zs_local[level] = out[level]
                         progress[level] = new_len
@@ -200,7 +234,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                         cond.notify_all()
                 callback = getattr(_sample, "level_done", None)
                 if on_gpu:
-                    stream.synchronize()
+                    cur().synchronize()
                 with cond:
                     finished.add(level)
                     cond.notify_all()
@@ -213,7 +247,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                     with cond:
                         zs_now = list(zs_local)
                     early_audio[level] = prior.decode(zs_now[level:], start_level=level, bs_chunks=max(1, zs_now[level].shape[0]))
-                    stream.synchronize()
+                    cur().synchronize()
         except BaseException as e:          # noqa: BLE001 -- re-raised in the caller
             with cond:
                 errors.append(e)
@@ -227,9 +261,13 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # -- even idle ones -- slowed the concurrent levels' plain chains 2.5x (profiles/r04_pipe_in_job.log: first level-0 window
     # 47.8 s instead of 18.7 s).  The first pipelined window compares the two launch forms in situ and keeps the faster
     # (ConditionalAutoregressive2D._decode).
-    lowest = min(sample_levels)
     if _want_pipelined_launches(hps) and getattr(priors[lowest], "prior", None) is not None:
-        priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
+        if n_conf:
+            os.environ["JB_PIPE_CUS"] = str(256 - n_conf)       # the pair of streams keeps to the other compute units
+            priors[lowest].prior.pipeline_launches = True
+        else:
+            os.environ.pop("JB_PIPE_CUS", None)
+            priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
     # (level, window start, seconds into the job at which the window's sampling began / ended) per window: diagnostics
@@ -242,6 +280,9 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         th.join()
     if on_gpu:
         t.cuda.synchronize(device)
+    if raw_streams:
+        from . import _lib as L
+        L.destroy_streams(raw_streams)
     if errors:
         raise errors[0]
     return zs_local
