@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             aval[mt] = mvalid[mt] && tin >= 0 && tin < p.t_in;
             arow[mt] = A + ((int64_t)n_idx[mt] * p.in_seq_stride + (aval[mt] ? tin : 0)) * p.lda;
         }
+        // a tap whose shifted rows all fall outside the sequence for this wave's 64 output rows contributes zeros: skip its
+        // whole k-loop (the conditioner's dilations reach 2187 positions at sequence lengths of 2048 / 4096: up to two of
+        // the three taps of a layer are out of range for every row, or for the rows near one end)
+        if (!__any((int)(aval[0] || aval[1] || aval[2] || aval[3]))) continue;
         const T* wtap = (const T*)p.W + (int64_t)tap * p.tap_stride + (int64_t)lane * E;
         for (int kt = 0; kt < p.nkt; ++kt) {
             V wf[4], af[4];

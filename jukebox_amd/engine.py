@@ -358,8 +358,12 @@ class PriorEngine:
 
     def decode(self, t0, n_steps, use_graph=True):
         L.check(L.lib().jb_engine_decode(self.handle, t0, n_steps, int(use_graph), L.stream()))
-        if self.pipelined:                     # the library keeps the plain chain when the pair cannot have queues of its own
-            self.pipelined = bool(L.lib().jb_engine_pipelined(self.handle))
+        if self.pipelined and not L.lib().jb_engine_pipelined(self.handle):
+            # the library keeps the plain chain when the pair of streams cannot have hardware queues of its own: say why, once
+            self.pipelined = False
+            import sys
+            print("jukebox_amd: pipelined launches fell back to the plain chain:", L.lib().jb_last_error().decode(errors="replace"),
+                  file=sys.stderr, flush=True)
 
     def timed_decode(self, t0, n_steps):
         """decode + wait: seconds per step as the host sees them (the in-situ comparison of the two launch forms)."""
