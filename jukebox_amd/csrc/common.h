@@ -266,13 +266,14 @@ __device__ __forceinline__ void jb_pipe_publish(const JbPipe& P, unsigned own) {
         const unsigned members = (n_wg - shard + 7u) >> 3, n_shards = n_wg < 8u ? n_wg : 8u;
         if (__hip_atomic_fetch_add(tk + shard * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
             jb_st_word(tk + shard * JB_PIPE_PAD, 0u);
-            if (P.proto == 1) {
-                if (shard == 0) {                      // the slot's own count: read by its next run only (same-stream order)
-                    jb_st_word(P.runs + P.slot * JB_PIPE_PAD, own + 1);
-                    if (P.dbg) P.dbg[P.slot * 4 + 2] = wall_clock64();
-                }
-                jb_st_word(tk + (9 + shard) * JB_PIPE_PAD, own + 1);
-            } else if (__hip_atomic_fetch_add(tk + 8 * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_shards - 1) {
+            // protocol 1: the shard's flag is what the consumer waits for -- published first; the count of finished shards comes
+            // after it, off the consumer's path, and only guards the slot's OWN count: that word is read by every workgroup of
+            // the slot's next run at its start AND by late starters of THIS run (an attention workgroup waits for an empty
+            // compute unit), so it may move only once every workgroup of this run has arrived.  (Round 4's first form let
+            // shard 0's last arriver write it: a workgroup that started after that read the next run's number, waited for a
+            // completion that belongs to the next step, and timed out -- once in a 20-second job.)
+            if (P.proto == 1) jb_st_word(tk + (9 + shard) * JB_PIPE_PAD, own + 1);
+            if (__hip_atomic_fetch_add(tk + 8 * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_shards - 1) {
                 jb_st_word(tk + 8 * JB_PIPE_PAD, 0u);
                 jb_st_word(P.runs + P.slot * JB_PIPE_PAD, own + 1);
                 if (P.dbg) P.dbg[P.slot * 4 + 2] = wall_clock64();

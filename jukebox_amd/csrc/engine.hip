@@ -313,7 +313,7 @@ extern "C" int jb_engine_pipelined(void* handle) { return handle && ((JbEngine*)
 // (GPU_MAX_HW_QUEUES, 4 by default): a waiting launch that sits in the same hardware queue AHEAD of its producer -- or, with
 // two pipelined engines, ahead of the other engine's producer while that engine's waiter sits ahead of ours -- never ends.
 // Every stream that carries pipelined launches is therefore checked, once, against every other such stream of the process
-// with a two-kernel handshake: a kernel on stream a spins (bounded: 20 ms) for a flag that a kernel on stream b sets; if
+// with a two-kernel handshake: a kernel on stream a spins (bounded: 1.5 s) for a flag that a kernel on stream b sets; if
 // both streams feed one in-order queue the setter cannot start and the spin times out.  Engines whose streams cannot be
 // told apart keep the plain launch chain.
 __global__ void pipe_probe_wait_kernel(unsigned* flag, unsigned* result) {

@@ -99,8 +99,18 @@ class ConditionalAutoregressive2D(nn.Module):
         packed = self.packed(fp16)
         key = (n_samples, fp16, bool(want_preds))
         if key not in self._engines:
-            self._engines[key] = PriorEngine(packed=packed, n_batch=n_samples, chunk_cap=chunk_cap,
-                                             want_preds=want_preds)
+            make = lambda: PriorEngine(packed=packed, n_batch=n_samples, chunk_cap=chunk_cap, want_preds=want_preds)
+            try:
+                self._engines[key] = make()
+            except t.cuda.OutOfMemoryError:
+                # the budget is checked after the new engine exists (its size is not known before): when the old engines plus
+                # the new one do not fit, the old ones go first and the construction is repeated once
+                for k in list(self._engines):
+                    self._engines.pop(k).close()
+                self._last_engine = None
+                t.cuda.synchronize(self.x_emb.weight.device)
+                t.cuda.empty_cache()
+                self._engines[key] = make()
         eng = self._engines.pop(key)
         self._engines[key] = eng                     # dicts keep insertion order: most recently used last
         self._evict_engines()
@@ -163,11 +173,15 @@ class ConditionalAutoregressive2D(nn.Module):
         for attempt in range(2):
             eng.decode(pos, 16)                # the pair of streams and its graphs are made here, outside the timed steps
             pos += 16
-            if not eng.pipelined or eng.pipe_error():
+            if eng.pipe_error():
+                return                         # a wait timed out: the caller decodes the window again on the plain chain
+            if not eng.pipelined:
                 break
             report["pipelined_ms"].append(round(eng.timed_decode(pos, 384) * 1e3, 4))
             pos += 384
-            if not eng.pipelined or eng.pipe_error():
+            if eng.pipe_error():
+                return
+            if not eng.pipelined:
                 break
             if report["plain_ms"] is None:
                 eng.set_pipelined(False)
@@ -284,6 +298,19 @@ class ConditionalAutoregressive2D(nn.Module):
         tap = getattr(self, "decode_tap", None)
         if tap is None:
             self._decode(eng, n_prime, sample_tokens - n_prime)
+            if eng.pipe_error():
+                # A pipelined launch gave up waiting for its producer (bounded polls: no hang), so what it computed is void.
+                # Nobody has seen the window's tokens yet and the draw of a position is a pure function of (seed, position):
+                # the window is decoded again on the plain chain -- same tokens as if nothing had happened -- and this engine
+                # keeps the plain chain from here on.
+                import sys
+                print(f"jukebox_amd: pipelined decode: launch slot {eng.pipe_error() - 1} timed out waiting for its producer; "
+                      "decoding the window again on the plain launch chain", file=sys.stderr, flush=True)
+                eng.clear_pipe_error()
+                eng.set_pipelined(False)
+                eng._pipe_verdict = False
+                self.pipeline_report = dict(getattr(self, "pipeline_report", None) or {}, kept=False, timed_out=True)
+                eng.decode(n_prime, sample_tokens - n_prime)
         else:
             # (every, fn): hand the token buffer to fn after every `every` enqueued decode steps, so that a consumer on
             # another stream can start on a partial window (jukebox_amd.sample._sample_levels_pipelined)
@@ -296,7 +323,7 @@ class ConditionalAutoregressive2D(nn.Module):
                 fn(eng.tokens, pos, pos + n)
                 pos += n
         x = eng.tokens[:, :sample_tokens].clone()
-        if eng.pipelined and eng.pipe_error():
+        if eng.pipe_error():                   # (a tapped window: a consumer may already have read what the failed steps wrote)
             raise RuntimeError(f"pipelined decode: launch slot {eng.pipe_error() - 1} timed out waiting for its producer; the "
                                "tokens of this window are not valid (JB_PIPELINE_LAUNCHES=0 selects the plain launch chain)")
         x = self.postprocess(x, sample_tokens)

@@ -139,7 +139,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # compute unit (the starvation measured in round 3), and the lowest level's step is the pipelined one for the whole job.
     n_conf = int(hps.get("confine_upper_cus", 0) or os.environ.get("JB_CONFINE_UPPER_CUS", "0") or 0) if on_gpu else 0
     n_conf = max(0, min(n_conf // 8 * 8, 128))
-    confined, raw_streams = {}, []
+    confined, raw_streams, moved = {}, [], set()
 
     def confine_upper_levels():
         from . import _lib as L
@@ -156,6 +156,9 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         if st is not None and t.cuda.current_stream(device) != st:
             st.wait_stream(t.cuda.current_stream(device))
             t.cuda.set_stream(st)
+            with cond:
+                moved.add(level)
+                cond.notify_all()
 
     def worker(level):
         try:
@@ -213,6 +216,8 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
 
                     if n_conf and level == lowest and not confined:
                         confine_upper_levels()                     # from here on the upper levels keep to their compute units
+                        with cond:                                 # ... and this level's waiting launches start once they have moved
+                            cond.wait_for(lambda: errors or all(l in moved or l in finished for l in confined), timeout=10.0)
                     elif n_conf:
                         move_to_confined(level)
 

@@ -260,3 +260,46 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, proto):
         assert np.array_equal(z0, z1), "tokens differ between the plain chain and pipelined launches"
         assert np.array_equal(p0, p1), "logits differ between the plain chain and pipelined launches"
     assert not np.array_equal(outs["chain"][0][0][:, 200:], np.zeros_like(outs["chain"][0][0][:, 200:]))
+
+
+def test_pipelined_timeout_is_recovered_on_the_plain_chain(monkeypatch):
+    """ConditionalAutoregressive2D._run: when a pipelined launch gives up waiting for its producer (the engine's error word is
+    set; bounded polls, no hang) the window's tokens are void -- the sampler decodes the window again on the plain launch
+    chain, keeps that engine on the plain chain, and returns exactly the tokens of a run that never used pipelined launches
+    (the draw of a position is a pure function of seed and position).  The failure is injected: the error word is set before
+    the first pipelined decode call, so every wait of that call gives up at once."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from jukebox_amd.engine import PriorEngine
+    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
+    monkeypatch.delenv("JB_PIPELINE_LAUNCHES", raising=False)
+    width, depth, bins, seq, N = 1920, 3, 256, 512, 16
+    torch.manual_seed(3)
+    with torch.device("cuda"):
+        model = AR(input_shape=(seq,), bins=bins, width=width, depth=depth, heads=1, blocks=8, attn_order=2, x_cond=True, y_cond=True,
+                   init_scale=0.4).eval()
+    xc = torch.randn(N, seq, width, device="cuda") * 0.1
+    yc = torch.randn(N, 1, width, device="cuda") * 0.1
+    prime = torch.randint(0, bins, (N, 40), device="cuda")
+    kw = dict(x_cond=xc, y_cond=yc, fp16=True, temp=0.97, sample_tokens=300, seed=9)
+    model.pipeline_launches = False
+    want = model.primed_sample(N, prime, **kw).cpu()
+    eng = model.bound_engine()
+    assert not eng.pipelined
+    model.pipeline_launches = True
+    injected = []
+    real_decode = PriorEngine.decode
+
+    def decode(self, t0, n_steps, use_graph=True):
+        if self.pipelined and not injected:
+            injected.append((t0, n_steps))
+            self.pipe_words[18 * self.launches_per_step * 32] = 7          # "slot 6 timed out"
+        return real_decode(self, t0, n_steps, use_graph)
+
+    monkeypatch.setattr(PriorEngine, "decode", decode)
+    got = model.primed_sample(N, prime, **kw).cpu()
+    assert injected == [(40, 260)] and model.pipeline_report.get("timed_out") and not eng.pipelined and eng.pipe_error() == 0
+    assert torch.equal(got, want)
+    model.pipeline_launches = lambda: True                 # the sampler asks again for the next window: this engine stays plain
+    again = model.primed_sample(N, prime, **kw).cpu()
+    assert not eng.pipelined and torch.equal(again, want)

@@ -497,6 +497,10 @@ def test_in_situ_choice_between_the_launch_forms():
         assert eng.pipelined is kept
         h._decode(eng, 4096, 4096)
         assert len(eng.calls) == n_calls + 1                  # one call, nothing measured again
+    bad = FakeEngine([1.6])
+    bad.pipe_error = lambda: 19 if len(bad.calls) >= 2 else 0  # a wait times out inside the timed steps
+    Host()._decode(bad, 0, 4096)
+    assert bad.calls == [(0, 16, True), (16, 384, True)] and not hasattr(bad, "_pipe_verdict")   # stops: the caller redoes the window
     short = FakeEngine([])
     Host()._decode(short, 0, 700)                             # too short to measure on: decoded as asked
     assert short.calls == [(0, 700, True)] and not hasattr(short, "_pipe_verdict")
