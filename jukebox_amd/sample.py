@@ -218,6 +218,12 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                         confine_upper_levels()                     # from here on the upper levels keep to their compute units
                         with cond:                                 # ... and this level's waiting launches start once they have moved
                             cond.wait_for(lambda: errors or all(l in moved or l in finished for l in confined), timeout=10.0)
+                    elif n_conf and level == lowest and os.environ.get("JB_PIPE_CUS") and all(l in finished for l in confined):
+                        # the upper levels are done: a fresh pair of streams on ALL compute units for the rest of the job
+                        os.environ.pop("JB_PIPE_CUS", None)
+                        eng = priors[lowest].prior.bound_engine()
+                        if eng is not None and eng.pipelined:
+                            eng.set_pipelined(True, fresh=True)
                     elif n_conf:
                         move_to_confined(level)
 
