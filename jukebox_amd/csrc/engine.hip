@@ -359,10 +359,7 @@ static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mu
     JB_HIP(hipGetDeviceProperties(&prop, dev));
     const int n_cu = prop.multiProcessorCount;                   // 256 on MI355X; one mask bit per compute unit
     JB_REQUIRE(n_cu >= 8 && n_cu <= 1024, "unexpected compute-unit count");
-    // JB_PIPE_CUS=n (experiment of the level pipeline, sample.py): the pair keeps to the first n mask bits -- bit i is compute unit
-    // i / 8 of XCD i % 8 -- so that another level's launches, confined to the remaining ones, never meet a waiting launch
-    int usable = getenv("JB_PIPE_CUS") ? atoi(getenv("JB_PIPE_CUS")) : n_cu;
-    usable = usable < 64 || usable > n_cu ? n_cu : usable;
+    const int usable = n_cu;
     std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32);
     for (int k = 0; k < 2; ++k) {
         std::fill(mask.begin(), mask.end(), 0u);

@@ -132,34 +132,6 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         ev.record(t.cuda.current_stream(device) if stream is None else stream)
         return ev
 
-    # EXPERIMENT (hps.confine_upper_cus / JB_CONFINE_UPPER_CUS = n, a multiple of 8): once the lowest level starts, the levels
-    # above it move to streams confined to the last n / 8 compute units of every XCD and the lowest level runs pipelined
-    # launches on the others from its first step.  A lower level consumes the codes of the level above at a quarter of its
-    # own rate, so the upper levels can afford to be slow; their launches never meet the lowest level's waiting launches on a
-    # compute unit (the starvation measured in round 3), and the lowest level's step is the pipelined one for the whole job.
-    n_conf = int(hps.get("confine_upper_cus", 0) or os.environ.get("JB_CONFINE_UPPER_CUS", "0") or 0) if on_gpu else 0
-    n_conf = max(0, min(n_conf // 8 * 8, 128))
-    confined, raw_streams, moved = {}, [], set()
-
-    def confine_upper_levels():
-        from . import _lib as L
-        for k, l in enumerate(x for x in levels if x != lowest and x not in finished):
-            bits = [b for b in range(256 - n_conf, 256) if b != 255 - k]      # distinct masks: distinct hardware queues
-            st, raw = L.cu_mask_stream(bits, device=device)
-            raw_streams.append(raw)
-            with cond:
-                confined[l] = st
-
-    def move_to_confined(level):
-        """Called by an upper level's own thread between two decode calls: continue on the confined stream."""
-        st = confined.get(level)
-        if st is not None and t.cuda.current_stream(device) != st:
-            st.wait_stream(t.cuda.current_stream(device))
-            t.cuda.set_stream(st)
-            with cond:
-                moved.add(level)
-                cond.notify_all()
-
     def worker(level):
         try:
             prior = priors[level]
@@ -211,21 +183,6 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                             progress[level] = start + hi
                             ready_event[level] = ev
                             cond.notify_all()
-                        if n_conf:
-                            move_to_confined(level)
-
-                    if n_conf and level == lowest and not confined:
-                        confine_upper_levels()                     # from here on the upper levels keep to their compute units
-                        with cond:                                 # ... and this level's waiting launches start once they have moved
-                            cond.wait_for(lambda: errors or all(l in moved or l in finished for l in confined), timeout=10.0)
-                    elif n_conf and level == lowest and os.environ.get("JB_PIPE_CUS") and all(l in finished for l in confined):
-                        # the upper levels are done: a fresh pair of streams on ALL compute units for the rest of the job
-                        os.environ.pop("JB_PIPE_CUS", None)
-                        eng = priors[lowest].prior.bound_engine()
-                        if eng is not None and eng.pipelined:
-                            eng.set_pipelined(True, fresh=True)
-                    elif n_conf:
-                        move_to_confined(level)
 
                     prior.window_tap = (chunk, publish) if tapped else None
                     t_w = time.perf_counter()
@@ -273,12 +230,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # 47.8 s instead of 18.7 s).  The first pipelined window compares the two launch forms in situ and keeps the faster
     # (ConditionalAutoregressive2D._decode).
     if _want_pipelined_launches(hps) and getattr(priors[lowest], "prior", None) is not None:
-        if n_conf:
-            os.environ["JB_PIPE_CUS"] = str(256 - n_conf)       # the pair of streams keeps to the other compute units
-            priors[lowest].prior.pipeline_launches = True
-        else:
-            os.environ.pop("JB_PIPE_CUS", None)
-            priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
+        priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
     # (level, window start, seconds into the job at which the window's sampling began / ended) per window: diagnostics
@@ -291,9 +243,6 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
         th.join()
     if on_gpu:
         t.cuda.synchronize(device)
-    if raw_streams:
-        from . import _lib as L
-        L.destroy_streams(raw_streams)
     if errors:
         raise errors[0]
     return zs_local
