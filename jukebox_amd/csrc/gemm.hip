@@ -249,11 +249,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         // the three taps of a layer are out of range for every row, or for the rows near one end)
         if (!__any((int)(aval[0] || aval[1] || aval[2] || aval[3]))) continue;
         const T* wtap = (const T*)p.W + (int64_t)tap * p.tap_stride + (int64_t)lane * E;
-        for (int kt = 0; kt < p.nkt; ++kt) {
-            V wf[4], af[4];
+        // Software-pipelined over the k-tiles (round 4): the 8 operand loads of tile kt + 1 are in flight while the 16 (f16) /
+        // 64 (f32) MFMAs of tile kt issue, and the ReLU / validity selects are applied AFTER all loads of a tile have been
+        // requested.  (Before: `if (pre_relu)` behind each row's load compiled to load -> s_waitcnt vmcnt(0) -> branch, four
+        // dependent round trips per k-tile -- the conv stacks' fp32 kernel sat at 55 % of the fp32 MFMA peak.)  Two register
+        // sets, the loop unrolled by two so that no operand array is indexed dynamically.  Same MFMAs in the same order.
+        auto issue = [&](int kt, V (&wf)[4], V (&af)[4]) {
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
-                int jtg = jt_base + jt;
+                const int jtg = jt_base + jt;
                 if (FAST) {
                     wf[jt] = ld_frag<T>(wtap + ((int64_t)min(jtg, p.njt - 1) * p.nkt + kt) * (64 * E));
                 } else {
@@ -264,8 +268,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             const int k0 = kt * KT + g * E;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                if (FAST) af[mt] = keep_frag<T>(aval[mt], ld_frag<T>(arow[mt] + k0));
+                if (FAST) af[mt] = ld_frag<T>(arow[mt] + k0);
                 else af[mt] = load_row_frag<T>(arow[mt], aval[mt], k0, p.K, p.vec_a);
+            }
+        };
+        auto multiply = [&](V (&wf)[4], V (&af)[4]) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (FAST) af[mt] = keep_frag<T>(aval[mt], af[mt]);
                 if (p.pre_relu) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) af[mt][e] = af[mt][e] > (T)0 ? af[mt][e] : (T)0;
@@ -275,7 +285,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[jt][mt] = jb_mfma(wf[jt], af[mt], acc[jt][mt]);
+        };
+        V wA[4], aA[4], wB[4], aB[4];
+        issue(0, wA, aA);
+        int kt = 0;
+        for (; kt + 1 < p.nkt; kt += 2) {
+            issue(kt + 1, wB, aB);
+            multiply(wA, aA);
+            issue(min(kt + 2, p.nkt - 1), wA, aA);      // unconditional (a clamped, unused re-load at the very end): a branch here
+            multiply(wB, aB);                           // would make the compiler wait for ALL outstanding loads below
         }
+        if (kt < p.nkt) multiply(wA, aA);
     }
 
 #pragma unroll
