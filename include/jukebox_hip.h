@@ -17,7 +17,10 @@
 extern "C" {
 #endif
 
-typedef enum { JB_F32 = 0, JB_F16 = 1 } jb_dtype;
+typedef enum { JB_F32 = 0, JB_F16 = 1,
+               /* jb_pack_weight's dst_dtype only: an fp32 matrix as TWO f16 images, hi = half(w) and lo = half((w - hi) * 2^11),
+                * each in f16 fragment order, hi first -- the weight operand of jb_gemm_args.w_split */
+               JB_F16_SPLIT = 2 } jb_dtype;
 typedef enum { JB_OK = 0, JB_ERR_ARG = -1, JB_ERR_UNSUPPORTED = -2, JB_ERR_HIP = -3 } jb_status;
 typedef enum { JB_ACT_NONE = 0, JB_ACT_RELU = 1, JB_ACT_QUICK_GELU = 2 } jb_act;
 
@@ -46,7 +49,7 @@ int jb_cu_census(int n_blocks, uint32_t* out, void* stream);
 int jb_clock_probe(long long* out, int spin_ticks, void* stream);
 
 /* Bytes of the MFMA-fragment-ordered weight image for a K x J matrix of `dtype`
- * (K padded to 32 (f16) / 16 (f32), J padded to 16). */
+ * (K padded to 32 (f16, f16 split) / 16 (f32), J padded to 16; the split image is two f16 images). */
 int64_t jb_packed_weight_bytes(int K, int J, int dtype);
 
 /* Re-lay a weight matrix for the MFMA kernels: src element (k, j) is read at
@@ -90,6 +93,12 @@ typedef struct jb_gemm_args {
     float res_scale;
     int qkv_split, S;
     void* kcache; void* vcache; int cache_cap, cache_t0;
+    /* fp32 problems (dtype JB_F32, K a multiple of 32, 16-byte aligned rows) on the f16 matrix cores at fp32 accuracy: W is a
+     * JB_F16_SPLIT image per tap (same bytes as the fp32 image, so tap_stride counts fp32 elements as before).  The kernel
+     * splits the fp32 activations the same way and evaluates w_hi*a_hi + 2^-11 * (w_hi*a_lo + w_lo*a_hi) with fp32
+     * accumulation: three f16 MFMAs per k-tile at 16x the rate of the exact-fp32 instruction; the dropped term is
+     * 2^-22 relative, below the rounding of the fp32 accumulation itself.  Inputs must be inside the f16 range (|x| < 65504). */
+    int w_split;
 } jb_gemm_args;
 int jb_gemm(const jb_gemm_args* args /* host */, void* stream);
 /* Flat problems (one tap, unit strides) of at least `min_rows` output rows use the LDS-staged 256x128-tile kernel

@@ -7,7 +7,7 @@ resolved, `lib()` raises.  Build it with `python -m jukebox_amd.csrc.build` or
 import ctypes as C
 import os
 
-F32, F16 = 0, 1
+F32, F16, F16_SPLIT = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_QUICK_GELU = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -22,7 +22,8 @@ class GemmArgs(C.Structure):
                 ("n_seq", i32), ("t_in", i32), ("t_out", i32), ("in_seq_stride", i64), ("out_seq_stride", i64),
                 ("K", i32), ("J", i32), ("n_taps", i32), ("in_stride", i32), ("shift", i32 * 4),
                 ("out_stride", i32), ("out_offset", i32), ("pre_relu", i32), ("act", i32), ("res_scale", f32),
-                ("qkv_split", i32), ("S", i32), ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("cache_t0", i32)]
+                ("qkv_split", i32), ("S", i32), ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("cache_t0", i32),
+                ("w_split", i32)]
 
 
 class GemvArgs(C.Structure):
@@ -134,20 +135,6 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)          # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        # tuning knobs from the environment (tools/, bench.py and experiments share them): kernel-selection switches
-        # that default to the measured-best variant
-        env = os.environ.get
-        if env("JB_ATTN_SPLIT") is not None:          # "max_parts,waves"
-            mp, wv = (int(v) for v in env("JB_ATTN_SPLIT").split(","))
-            l.jb_tune_attn_decode_split(mp, wv)
-        if env("JB_ATTN_SPLIT_MIN_KEYS") is not None:
-            l.jb_tune_attn_decode_split_min_keys(int(env("JB_ATTN_SPLIT_MIN_KEYS")))
-        if env("JB_PREFILL_V2") is not None:
-            l.jb_tune_attn_prefill_v2(int(env("JB_PREFILL_V2")))
-        if env("JB_GEMM_LDS_MIN_ROWS") is not None:
-            l.jb_tune_gemm_lds(int(env("JB_GEMM_LDS_MIN_ROWS")))
-        if env("JB_GEMM_GLDS_MIN_ROWS") is not None:
-            l.jb_tune_gemm_glds(int(env("JB_GEMM_GLDS_MIN_ROWS")))
         _lib = l
     return _lib
 

@@ -189,15 +189,14 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
     const int n_slots = jb_engine_launches_per_step(e);
     int slot = 0;
-    // completion protocol (common.h): 1 -- a flag word per ticket shard, polled by eight lanes; engines of >= 8 samples -- unless
-    // JB_PIPE_PROTO=0 asks for round 3's two-level ticket with one flag (measured on the upsampler step: 1.541 vs 1.601 ms,
-    // profiles/r04_bench_engine_up_proto{1,0}.log).  Read when a step is captured.
-    const int proto_env = getenv("JB_PIPE_PROTO") ? atoi(getenv("JB_PIPE_PROTO")) : 1;
+    // completion protocol (common.h): 1 -- a flag word per ticket shard, polled by eight lanes -- for engines of >= 8 samples
+    // (every launch of their step has >= 8 workgroups, so every shard has a member); 0 -- the two-level ticket with one flag --
+    // for smaller batches (measured on the 16-sample upsampler step: 1.541 vs 1.601 ms, profiles/r04_bench_engine_up_proto{1,0}.log)
     JbPipe pp{c.pipe_words, c.pipe_words ? c.pipe_words + (size_t)n_slots * JB_PIPE_PAD : nullptr,
               c.pipe_words ? c.pipe_words + jb_pipe_words(n_slots) - JB_PIPE_PAD : nullptr, 0, 0,
               (getenv("JB_PIPE_TIMEOUT_MS") ? atoll(getenv("JB_PIPE_TIMEOUT_MS")) : 2000ll) * 100000ll,
               (c.pipe_words && getenv("JB_PIPE_DEBUG")) ? reinterpret_cast<long long*>(c.pipe_words + jb_pipe_words(n_slots)) : nullptr,
-              (proto_env == 1 && c.n_batch >= 8) ? 1 : 0};
+              c.n_batch >= 8 ? 1 : 0};
     // the pipeline slot of the next launch, or NULL for the plain chain; `mine`: this call enqueues it
     bool mine = true;
     auto next = [&]() -> const JbPipe* {

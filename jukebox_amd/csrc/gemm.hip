@@ -29,9 +29,30 @@ __global__ void pack_weight_kernel(const void* __restrict__ src, int src_dtype, 
     dst[idx] = (TO)v;
 }
 
+// The split image of an fp32 matrix (JB_F16_SPLIT, jb_gemm_args.w_split): part 0 = half(w), part 1 = half((w - part 0) * 2^11),
+// each laid out like an f16 image.
+__global__ void pack_weight_split_kernel(const void* __restrict__ src, int src_dtype, int64_t sk, int64_t sj, int K, int J,
+                                         f16* __restrict__ dst, int nkt, int64_t total) {
+    constexpr int E = Frag<f16>::E, KT = Frag<f16>::KT;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int e = (int)(idx % E);
+    int lane = (int)((idx / E) % 64);
+    int64_t tile = idx / (E * 64);
+    int kt = (int)(tile % nkt);
+    int jt = (int)(tile / nkt);
+    int k = kt * KT + (lane >> 4) * E + e;
+    int j = jt * 16 + (lane & 15);
+    float v = 0.0f;
+    if (k < K && j < J) v = jb_load_any(src, src_dtype, (int64_t)k * sk + (int64_t)j * sj);
+    const f16 hi = (f16)v;
+    dst[idx] = hi;
+    dst[total + idx] = (f16)((v - (float)hi) * 2048.0f);
+}
+
 static inline void packed_dims(int K, int J, int dtype, int* nkt, int* njt, int* E) {
-    int KT = dtype == JB_F16 ? 32 : 16;
-    *E = dtype == JB_F16 ? 8 : 4;
+    int KT = dtype == JB_F32 ? 16 : 32;
+    *E = dtype == JB_F32 ? 4 : 8;
     *nkt = (K + KT - 1) / KT;
     *njt = (J + 15) / 16;
 }
@@ -39,18 +60,21 @@ static inline void packed_dims(int K, int J, int dtype, int* nkt, int* njt, int*
 extern "C" int64_t jb_packed_weight_bytes(int K, int J, int dtype) {
     int nkt, njt, E;
     packed_dims(K, J, dtype, &nkt, &njt, &E);
-    return (int64_t)nkt * njt * 64 * E * (dtype == JB_F16 ? 2 : 4);
+    return (int64_t)nkt * njt * 64 * E * (dtype == JB_F32 ? 4 : 2) * (dtype == JB_F16_SPLIT ? 2 : 1);
 }
 
 extern "C" int jb_pack_weight(const void* src, int src_dtype, int64_t stride_k, int64_t stride_j, int K, int J,
                               void* dst, int dst_dtype, void* stream) {
     JB_REQUIRE(src && dst && K > 0 && J > 0, "null pointer or empty matrix");
-    JB_REQUIRE((src_dtype == JB_F32 || src_dtype == JB_F16) && (dst_dtype == JB_F32 || dst_dtype == JB_F16), "bad dtype");
+    JB_REQUIRE((src_dtype == JB_F32 || src_dtype == JB_F16) &&
+                   (dst_dtype == JB_F32 || dst_dtype == JB_F16 || dst_dtype == JB_F16_SPLIT), "bad dtype");
     int nkt, njt, E;
     packed_dims(K, J, dst_dtype, &nkt, &njt, &E);
     int64_t total = (int64_t)nkt * njt * 64 * E;
     dim3 grid((unsigned)((total + 255) / 256));
-    if (dst_dtype == JB_F16)
+    if (dst_dtype == JB_F16_SPLIT)
+        pack_weight_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, src_dtype, stride_k, stride_j, K, J, (f16*)dst, nkt, total);
+    else if (dst_dtype == JB_F16)
         pack_weight_kernel<f16><<<grid, 256, 0, (hipStream_t)stream>>>(src, src_dtype, stride_k, stride_j, K, J, (f16*)dst, nkt, total);
     else
         pack_weight_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(src, src_dtype, stride_k, stride_j, K, J, (float*)dst, nkt, total);
@@ -315,6 +339,113 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
+// The conv stacks (conditioner, VQ-VAE encoder / decoder: fp32 in the reference) on the f16 matrix cores at fp32 accuracy
+// (jb_gemm_args.w_split).  Same block / wave tiling and the same tap logic as gemm_kernel<float>; a k-step is one f16 k-tile
+// (32 channels).  Both operands are split x = hi + 2^-11 * lo with hi = half(x), lo = half((x - hi) * 2^11) -- the weights
+// once, when they are packed (pack_weight_split_kernel), the activation fragments in registers after the step's loads have
+// been requested -- and   w * a = w_hi*a_hi + 2^-11 * (w_hi*a_lo + w_lo*a_hi)   (+ 2^-22 w_lo*a_lo, dropped)
+// goes through three v_mfma_f32_16x16x32_f16 with fp32 accumulation (every f16 product is exact in fp32); the 2^-11 terms
+// have their own accumulators and join at the end.  The exact-fp32 instruction (v_mfma_f32_16x16x4_f32) has 1/16 of the f16
+// rate: 3 instead of 8 instructions per 32 channels, each twice as fast.  Error against exact arithmetic: that of the fp32
+// accumulation (1.5e-7 ... 5.8e-7 of the largest output at K = 3 x 64 ... 3 x 1024, as the fp32 kernel; tests/test_hip_kernels.py).
+// Two workgroups per compute unit hide the operand latency; a second register set with the next k-step's operands in
+// flight (one workgroup per compute unit) measured slower: 122 against 77 ms for the upsampler's conditioner at 16 samples,
+// exact-fp32 kernel 133 ms (profiles/r04_bench_conditioner.log).
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t m_base = (int64_t)blockIdx.x * 256 + wave * 64;
+    const int jt_base = blockIdx.y * 4;
+
+    f32x4 acc[4][4], acc2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int n_idx[4], t_idx[4];
+    bool mvalid[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int64_t q = m_base + mt * 16 + c;
+        mvalid[mt] = q < p.m_total;
+        int64_t qq = mvalid[mt] ? q : 0;
+        n_idx[mt] = (int)(qq / p.t_out);
+        t_idx[mt] = (int)(qq - (int64_t)n_idx[mt] * p.t_out);
+    }
+    if (m_base >= p.m_total) return;   // whole wave out of range (uniform per wave)
+
+    const float* A = (const float*)p.A;
+    const int64_t lo_image = (int64_t)p.njt * p.nkt * 512;      // f16 elements from a tap's hi image to its lo image
+    const float relu_floor = p.pre_relu ? 0.f : -INFINITY;      // the input ReLU as a branch-free max
+    int64_t woff[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) woff[jt] = ((int64_t)min(jt_base + jt, p.njt - 1) * p.nkt) * 512 + (int64_t)lane * 8;
+    for (int tap = 0; tap < p.n_taps; ++tap) {
+        const float* arow[4];
+        bool aval[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            int tin = t_idx[mt] * p.in_stride + p.shift[tap];
+            aval[mt] = mvalid[mt] && tin >= 0 && tin < p.t_in;
+            arow[mt] = A + ((int64_t)n_idx[mt] * p.in_seq_stride + (aval[mt] ? tin : 0)) * p.lda + g * 8;
+        }
+        if (!__any((int)(aval[0] || aval[1] || aval[2] || aval[3]))) continue;      // (see gemm_kernel)
+        const f16* whi = reinterpret_cast<const f16*>((const float*)p.W + (int64_t)tap * p.tap_stride);
+        const f16* wlo = whi + lo_image;
+        auto issue = [&](int ks, f16x8 (&wh)[4], f16x8 (&wl)[4], f32x4 (&ar)[4][2]) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                wh[jt] = ld_frag<f16>(whi + woff[jt] + (int64_t)ks * 512);
+                wl[jt] = ld_frag<f16>(wlo + woff[jt] + (int64_t)ks * 512);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                ar[mt][0] = *reinterpret_cast<const f32x4*>(arow[mt] + ks * 32);
+                ar[mt][1] = *reinterpret_cast<const f32x4*>(arow[mt] + ks * 32 + 4);
+            }
+        };
+        auto multiply = [&](const f16x8 (&wh)[4], const f16x8 (&wl)[4], const f32x4 (&ar)[4][2]) {
+            f16x8 ah[4], al[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = ar[mt][e >> 2][e & 3];
+                    x = aval[mt] ? fmaxf(x, relu_floor) : 0.f;
+                    const f16 h = (f16)x;
+                    ah[mt][e] = h;
+                    al[mt][e] = (f16)((x - (float)h) * 2048.0f);
+                }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    acc[jt][mt] = jb_mfma(wh[jt], ah[mt], acc[jt][mt]);
+                    acc2[jt][mt] = jb_mfma(wh[jt], al[mt], acc2[jt][mt]);
+                    acc2[jt][mt] = jb_mfma(wl[jt], ah[mt], acc2[jt][mt]);
+                }
+        };
+        for (int ks = 0; ks < p.nkt; ++ks) {
+            f16x8 wh[4], wl[4];
+            f32x4 ar[4][2];
+            issue(ks, wh, wl, ar);
+            multiply(wh, wl, ar);
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        if (!mvalid[mt]) continue;
+        int64_t orow = (int64_t)n_idx[mt] * p.out_seq_stride + (int64_t)t_idx[mt] * p.out_stride + p.out_offset;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            int jb = (jt_base + jt) * 16 + g * 4;
+            if (jb < p.epi.J) epilogue_store<float>(p.epi, acc[jt][mt] + acc2[jt][mt] * (1.0f / 2048.0f), orow, jb, -1);
+        }
+    }
+}
+
 // LDS-staged GEMM for "flat" problems (one tap, unit strides: output row q reads input row q) -- the prefill
 // projections.  gemm_kernel above feeds every MFMA operand straight from L1: 32 FLOP per L1 byte, so the texture path
 // saturates at a few percent of the matrix cores.  Here a block of 4 waves owns a 256-row x 128-column tile; per
@@ -524,6 +655,8 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     JB_REQUIRE(a->K > 0 && a->J > 0 && a->n_seq > 0 && a->t_out > 0 && a->t_in > 0, "empty problem");
     JB_REQUIRE(a->n_taps >= 1 && a->n_taps <= 4, "n_taps must be 1..4");
     JB_REQUIRE(!a->qkv_split || (a->S > 0 && a->J == 3 * a->S && a->kcache && a->vcache), "bad qkv split");
+    JB_REQUIRE(!a->w_split || (a->dtype == JB_F32 && !a->qkv_split && a->K % 32 == 0 && a->lda % 4 == 0 && aligned_to(a->A, 16)),
+               "w_split takes fp32 problems with K a multiple of 32 and 16-byte aligned rows, no q/k/v split");
     const int esz = a->dtype == JB_F16 ? 2 : 4;
     const int E = a->dtype == JB_F16 ? 8 : 4;
     GemmParams p;
@@ -532,7 +665,7 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     p.in_seq_stride = a->in_seq_stride; p.out_seq_stride = a->out_seq_stride;
     p.K = a->K;
     int Edummy;
-    packed_dims(a->K, a->J, a->dtype, &p.nkt, &p.njt, &Edummy);
+    packed_dims(a->K, a->J, a->w_split ? JB_F16_SPLIT : a->dtype, &p.nkt, &p.njt, &Edummy);
     p.n_taps = a->n_taps; p.in_stride = a->in_stride;
     for (int i = 0; i < 4; ++i) p.shift[i] = a->shift[i];
     p.out_stride = a->out_stride; p.out_offset = a->out_offset;
@@ -551,6 +684,11 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     const int KT = a->dtype == JB_F16 ? 32 : 16;
     const bool fast = p.vec_a && (a->K % KT == 0);
     hipStream_t st = (hipStream_t)stream;
+    if (a->w_split) {
+        gemm_split_kernel<<<grid, 256, 0, st>>>(p);
+        JB_CHECK_LAUNCH();
+        return JB_OK;
+    }
     const bool flat = a->n_taps == 1 && a->shift[0] == 0 && a->in_stride == 1 && a->out_stride == 1 && a->out_offset == 0 &&
                       a->t_in == a->t_out && a->in_seq_stride == a->t_in && a->out_seq_stride == a->t_out && !a->pre_relu;
     // one tap at unit strides, rows = (sequence, position) with a pitch per sequence on either side

@@ -69,17 +69,16 @@ class PackedPrior:
         self.funcs = attn_funcs(attn_order, depth)
         self.y_cond, self.add_cond_after, self.only_encode = y_cond, add_cond_after, only_encode
         self.enc_len = int(encoder_dims or 0)
-        # Decode step: LayerNorm folded into c_attn / c_fc (hip_ops.FoldedLN).  Default: on for fp16 engines; the fp32
-        # engine (the parity mode) normalises rows explicitly, operation for operation as the reference.  JB_FOLD_LN=0/1
-        # overrides both.
+        # Decode step: LayerNorm folded into c_attn / c_fc (hip_ops.FoldedLN).  Default (fold_ln=None): on for fp16 engines;
+        # the fp32 engine (the parity mode) normalises rows explicitly, operation for operation as the reference.
         if fold_ln is None:
-            fold_ln = bool(int(os.environ["JB_FOLD_LN"])) if "JB_FOLD_LN" in os.environ else fp16
+            fold_ln = fp16
         self.fold_ln = bool(fold_ln) and not only_encode
         # Wide-value layers (jb_layer.vcache_w): single-head fp16 models cache v' = v·Wp, the value already carried through
         # attn.c_proj, so the decode step's attention writes the residual stream and the attn.c_proj launch disappears
-        # (4 launches per layer instead of 5).  Needs the folded c_attn.  JB_WIDE_V=0/1 overrides.
+        # (4 launches per layer instead of 5).  Needs the folded c_attn.  wide_v=False keeps the five-launch form.
         if wide_v is None:
-            wide_v = bool(int(os.environ["JB_WIDE_V"])) if "JB_WIDE_V" in os.environ else True
+            wide_v = True
         self.wide_v = bool(wide_v) and self.fold_ln and fp16 and heads == 1
         dev, dt = self.device, self.dtype
         g = lambda name: sd[prefix + name].to(dev).contiguous()
@@ -143,7 +142,7 @@ class PriorEngine:
     windows (set_cond per window is a device copy, not a re-capture)."""
 
     def __init__(self, sd=None, prefix="", *, n_batch, chunk_cap=256, want_preds=False, record=None, packed=None,
-                 **model):
+                 attn_split=None, **model):
         if packed is None:
             packed = PackedPrior(sd, prefix, **model)
         self.packed = pk = packed
@@ -159,8 +158,9 @@ class PriorEngine:
         N, T, S, W, M = self.N, self.T, self.S, self.W, self.M
         self.layers_c = (L.Layer * self.depth)()
         self.kcaches, self.vcaches, self.vcaches_w = [], [], []
-        # key-split decode attention (fp16 engines whose head size the split kernel takes) for layers with long key sets
-        split_off = os.environ.get("JB_ATTN_SPLIT_OFF", "0") == "1"
+        # key-split decode attention (fp16 engines whose head size the split kernel takes) for layers with long key sets;
+        # attn_split=False: never (the reference-ordered engine of the fp16 gate, tests/test_hip_baseline_configs.py)
+        split_off = attn_split is False
         bc = max(self.block_ctx, 1)
         max_keys = lambda lay: {0: T, 1: bc, 2: (T + bc - 1) // bc, 3: bc}.get(lay["func"], lay["cap"])
         splits = lambda lay: (not self.only_encode and not split_off and N <= 32 and

@@ -20,9 +20,10 @@ class PackedWeight:
     """A K x J matrix in MFMA fragment order (see csrc/gemm.hip) plus its logical dims.
     `taps` > 1 holds the per-tap matrices of a (transposed) convolution back to back."""
 
-    def __init__(self, data, K, J, dtype, taps=1):
+    def __init__(self, data, K, J, dtype, taps=1, split=False):
         self.data, self.K, self.J, self.dtype, self.taps = data, K, J, dtype, taps
         self.tap_stride = data.numel() // taps
+        self.split = split              # fp32 matrix as hi / lo f16 images (jb_gemm_args.w_split); `data` holds the raw words
 
     @property
     def ptr(self):
@@ -73,22 +74,30 @@ def pack_linear_w(w, dtype):
     return PackedWeight(pack_weight(w, K, J, 1, K, dtype), K, J, dtype)
 
 
-def pack_conv_taps(w, dtype, transposed=False):
+def pack_conv_taps(w, dtype, transposed=False, split=False):
     """nn.Conv1d weight (Cout, Cin, k) or nn.ConvTranspose1d weight (Cin, Cout, k): one K=Cin x J=Cout
-    matrix per tap."""
+    matrix per tap.  split (fp32 only, Cin a multiple of 32): every tap as the hi / lo pair of f16 images that lets the
+    fp32 conv stacks run on the f16 matrix cores at fp32 accuracy (jb_gemm_args.w_split) -- the same bytes per tap."""
     w = w.contiguous()
+    if split:
+        assert dtype == torch.float32 and w.shape[0 if transposed else 1] % 32 == 0
     if transposed:
         Cin, Cout, k = w.shape
         sk, sj = Cout * k, k
     else:
         Cout, Cin, k = w.shape
         sk, sj = k, Cin * k
-    code = L.dtype_code(dtype)
+    code = L.F16_SPLIT if split else L.dtype_code(dtype)
     per = L.lib().jb_packed_weight_bytes(Cin, Cout, code) // (2 if code == L.F16 else 4)
     out = torch.empty(per * k, dtype=dtype, device=w.device)
     for tap in range(k):
-        pack_weight(w, Cin, Cout, sk, sj, dtype, out=out[tap * per:(tap + 1) * per], offset_elems=tap)
-    return PackedWeight(out, Cin, Cout, dtype, taps=k)
+        dst = out[tap * per:(tap + 1) * per]
+        if split:
+            L.check(L.lib().jb_pack_weight(w.data_ptr() + tap * w.element_size(), L.dtype_code(w.dtype), sk, sj, Cin, Cout,
+                                           dst.data_ptr(), code, L.stream()))
+        else:
+            pack_weight(w, Cin, Cout, sk, sj, dtype, out=dst, offset_elems=tap)
+    return PackedWeight(out, Cin, Cout, dtype, taps=k, split=split)
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
@@ -130,6 +139,7 @@ def gemm(A, pw, bias=None, out=None, res=None, n_seq=1, t_in=None, t_out=None, s
         a.shift[i] = s
     a.out_stride, a.out_offset = out_stride, out_offset
     a.pre_relu, a.act, a.res_scale = int(pre_relu), act, res_scale
+    a.w_split = int(pw.split)
     L.check(L.lib().jb_gemm(C.byref(a), L.stream()))
     return out
 
@@ -159,7 +169,7 @@ def tap_view(pw, taps):
     step = taps[1] - taps[0] if len(taps) > 1 else 1
     assert all(taps[i] == taps[0] + i * step for i in range(len(taps)))
     base = pw.data[taps[0] * pw.tap_stride:]
-    v = PackedWeight(base, pw.K, pw.J, pw.dtype, taps=1)
+    v = PackedWeight(base, pw.K, pw.J, pw.dtype, taps=1, split=pw.split)
     v.tap_stride = pw.tap_stride * step
     v.taps = len(taps)
     return v

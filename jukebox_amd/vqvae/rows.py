@@ -4,16 +4,21 @@ import torch
 
 from .. import hip_ops as H
 
+SPLIT_F16 = True        # (tests switch it off to compare with the exact-fp32 kernel)
+
 
 class PackedConvCache:
     """Mixin: lazily packed (MFMA-ordered, fp32) copies of nn.Conv1d / nn.ConvTranspose1d weights, dropped
-    whenever the module is moved or cast (`_apply`) or a weight is updated in place."""
+    whenever the module is moved or cast (`_apply`) or a weight is updated in place.  Layers with a multiple of 32 input
+    channels are packed as hi / lo pairs of f16 images: their fp32 convolution runs on the f16 matrix cores at fp32
+    accuracy (jb_gemm_args.w_split); the others (the 1-channel audio input, tiny test models) keep the exact-fp32 kernel."""
 
     def packed(self, conv, transposed=False):
         cache = self.__dict__.setdefault("_packed_cache", {})
         key = (id(conv), conv.weight.data_ptr(), conv.weight._version)
         if key not in cache:
-            cache[key] = H.pack_conv_taps(conv.weight.detach().float(), torch.float32, transposed=transposed)
+            cache[key] = H.pack_conv_taps(conv.weight.detach().float(), torch.float32, transposed=transposed,
+                                          split=SPLIT_F16 and conv.in_channels % 32 == 0)
         return cache[key]
 
     def _apply(self, fn, *a, **k):

@@ -535,7 +535,7 @@ def test_config2_small_prior_whole_window_greedy_vs_reference_golden():
     eng.close()
 
 
-def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
+def test_fp16_production_engine_teacher_forced_agreement():
     """The timed configuration is fp16 with folded LayerNorm and wide-value layers (v' = v·Wp cached, no attn.c_proj launch),
     whose rounding points differ from the reference-ordered fp16 path; the five-launch form and the key-split attention
     are gated the same way.  Gate: on the upsampler geometry (width 1920, depth 72, block_ctx 64), N = 16, with
@@ -566,10 +566,10 @@ def test_fp16_production_engine_teacher_forced_agreement(monkeypatch):
     def make(fp16, fold_ln, split, wide=None):
         # split: None = the default policy (this geometry's key sets are <= 128 keys: not split), True = force the key split
         # wide: None = the default policy (single head + fp16 + folded LayerNorm: wide-value layers), False = five launches
-        monkeypatch.setenv("JB_ATTN_SPLIT_OFF", "1" if split is False else "0")
         L.lib().jb_tune_attn_decode_split_min_keys(1 if split else 129)
         e = PriorEngine(sd, "", n_batch=N, seq_len=seq, bins=bins, width=W, depth=depth, heads=1, attn_order=2, blocks=128,
-                        y_cond=True, fp16=fp16, fold_ln=fold_ln, want_preds=True, chunk_cap=512, wide_v=wide)
+                        y_cond=True, fp16=fp16, fold_ln=fold_ln, want_preds=True, chunk_cap=512, wide_v=wide,
+                        attn_split=False if split is False else None)
         e.set_cond(x_cond, yc)
         e.set_sampling(temp=1.0, top_k=1)
         e.tokens[:, :t0] = prefix

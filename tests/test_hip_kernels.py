@@ -210,6 +210,92 @@ def test_conv_stack_ops_fp32(H):
     assert relerr(got, want) < 2e-5
 
 
+def _conv1d_f64(x, w, b, stride, padding, dilation):
+    """conv1d_nct's arithmetic (oracle/vqvae.py) in float64: the yardstick for kernels that claim fp32 accuracy."""
+    N, Ci, T = x.shape
+    Co, _, k = w.shape
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (padding, padding)))
+    To = (T + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    out = np.zeros((N, Co, To))
+    for tap in range(k):
+        out += np.matmul(w[:, :, tap].astype(np.float64), xp[:, :, tap * dilation: tap * dilation + (To - 1) * stride + 1: stride])
+    return out + b.astype(np.float64)[None, :, None]
+
+
+def _conv_transpose1d_f64(x, w, b, stride, padding):
+    N, Ci, T = x.shape
+    _, Co, k = w.shape
+    full = np.zeros((N, Co, (T - 1) * stride + k))
+    for tap in range(k):
+        full[:, :, tap: tap + (T - 1) * stride + 1: stride] += np.matmul(w[:, :, tap].T.astype(np.float64), x.astype(np.float64))
+    To = (T - 1) * stride - 2 * padding + k
+    return full[:, :, padding: padding + To] + b.astype(np.float64)[None, :, None]
+
+
+@pytest.mark.parametrize("Ci,Co,T,scale", [(64, 40, 200, 1.0), (1024, 136, 300, 1.0), (96, 72, 130, 3000.0), (32, 16, 70, 1e-3)])
+def test_conv_stack_ops_f16_split(H, Ci, Co, T, scale):
+    """The fp32 conv stacks on the f16 matrix cores (jb_gemm_args.w_split: both operands as hi + 2^-11 lo pairs of halves,
+    three f16 MFMAs per k-tile, fp32 accumulation) against float64 arithmetic and against the exact-fp32 kernel: dilated
+    k=3 convolutions in the Resnet1D form (input ReLU, residual, dilations beyond the sequence), the strided and the
+    transposed convolution, ragged row / column tiles, activations of a few thousand and of a few thousandths (the low
+    halves go subnormal there).  Bar: within 2e-6 of the output scale of float64 -- the accumulation's own rounding, as for
+    the exact-fp32 kernel (first GPU run: 1.0e-7 ... 5.8e-7, profiles/r04_split_kernel_tests.log)."""
+    rng = np.random.default_rng(Ci + Co)
+    N = 3
+    x = (scale * rng.standard_normal((N, Ci, T))).astype(np.float32)
+    xr = dev(np.transpose(x, (0, 2, 1)).reshape(N * T, Ci))
+    x64 = x.astype(np.float64)
+    worst = 0.0
+    for dil in (1, 9, 243):
+        w = (rng.standard_normal((Co, Ci, 3)) / np.sqrt(3 * Ci)).astype(np.float32)
+        b = rng.standard_normal(Co).astype(np.float32)
+        R = (scale * rng.standard_normal((N * T, Co))).astype(np.float32)
+        want = _conv1d_f64(np.maximum(x64, 0), w, b, 1, dil, dil)
+        want = R.astype(np.float64) + 0.5 * np.transpose(want, (0, 2, 1)).reshape(N * T, Co)
+        outs = []
+        for split in (True, False):
+            pw = H.pack_conv_taps(dev(w), torch.float32, split=split)
+            assert pw.split == split and pw.data.numel() == H.pack_conv_taps(dev(w), torch.float32).data.numel()
+            outs.append(H.gemm(xr, pw, bias=dev(b), res=dev(R), res_scale=0.5, n_seq=N, t_in=T, shifts=(-dil, 0, dil),
+                               pre_relu=True).cpu().numpy().astype(np.float64))
+        e_split, e_exact = relerr(outs[0], want), relerr(outs[1], want)
+        worst = max(worst, e_split)
+        assert e_split < 2e-6 and e_exact < 2e-6, (dil, e_split, e_exact)
+    # strided conv k=4 s=2 p=1
+    w = (rng.standard_normal((Co, Ci, 4)) / np.sqrt(4 * Ci)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    want = _conv1d_f64(x64, w, b, 2, 1, 1)
+    pw = H.pack_conv_taps(dev(w), torch.float32, split=True)
+    got = H.gemm(xr, pw, bias=dev(b), n_seq=N, t_in=T, t_out=T // 2, in_stride=2, shifts=(-1, 0, 1, 2)).cpu().numpy()
+    got = np.transpose(got.reshape(N, T // 2, Co), (0, 2, 1))
+    worst = max(worst, relerr(got, want))
+    assert relerr(got, want) < 2e-6
+    # transposed conv k=4 s=2 p=1 through tap views of the split image
+    w = (rng.standard_normal((Ci, Co, 4)) / np.sqrt(2 * Ci)).astype(np.float32)
+    want = _conv_transpose1d_f64(x64, w, b, 2, 1)
+    pw = H.pack_conv_taps(dev(w), torch.float32, transposed=True, split=True)
+    out = torch.empty((N * 2 * T, Co), dtype=torch.float32, device="cuda")
+    H.gemm(xr, H.tap_view(pw, [1, 3]), bias=dev(b), out=out, n_seq=N, t_in=T, t_out=T, shifts=(0, -1),
+           out_stride=2, out_offset=0, out_rows_per_seq=2 * T)
+    H.gemm(xr, H.tap_view(pw, [0, 2]), bias=dev(b), out=out, n_seq=N, t_in=T, t_out=T, shifts=(1, 0),
+           out_stride=2, out_offset=1, out_rows_per_seq=2 * T)
+    got = np.transpose(out.cpu().numpy().reshape(N, 2 * T, Co), (0, 2, 1))
+    worst = max(worst, relerr(got, want))
+    assert relerr(got, want) < 2e-6
+    print("f16-split conv stack Ci=%d scale=%g: worst error %.2e of the output scale" % (Ci, scale, worst))
+
+
+def test_gemm_split_refuses_what_it_cannot_take(H):
+    """w_split is for fp32 problems with K a multiple of 32 (jb_gemm says so instead of computing something else)."""
+    w = torch.randn(16, 48, 3, device="cuda")
+    with pytest.raises(AssertionError):
+        H.pack_conv_taps(w, torch.float32, split=True)
+    pw = H.pack_conv_taps(torch.randn(16, 64, 3, device="cuda"), torch.float32, split=True)
+    pw.K = 48                                                # a caller lying about K
+    with pytest.raises(RuntimeError):
+        H.gemm(torch.randn(30, 48, device="cuda"), pw, n_seq=1, t_in=30, shifts=(-1, 0, 1))
+
+
 @pytest.mark.parametrize("name,dt,tol", DT)
 @pytest.mark.parametrize("rows,K,J", [(16, 256, 96), (3, 100, 50), (40, 64, 16), (64, 512, 130)])
 def test_gemv_ln_epilogues(H, name, dt, tol, rows, K, J):

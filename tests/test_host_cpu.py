@@ -372,9 +372,6 @@ def test_engine_layer_policy_without_a_gpu(monkeypatch):
 
     monkeypatch.setattr(H, "pack_weight", fake_pack)
     monkeypatch.setattr(H, "make_sample_params", lambda *a, device="cpu", **k: torch.zeros(8, dtype=torch.int64))
-    monkeypatch.delenv("JB_WIDE_V", raising=False)
-    monkeypatch.delenv("JB_FOLD_LN", raising=False)
-    monkeypatch.delenv("JB_ATTN_SPLIT_OFF", raising=False)
 
     def state(W, depth, bins, T):
         S = W // 4
@@ -522,8 +519,7 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
 
     monkeypatch.setattr(H, "pack_weight", fake_pack)
     monkeypatch.setattr(H, "make_sample_params", lambda *a, device="cpu", **k: torch.zeros(8, dtype=torch.int64))
-    for k in ("JB_WIDE_V", "JB_FOLD_LN", "JB_ATTN_SPLIT_OFF", "JB_PIPELINE_LAUNCHES"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("JB_PIPELINE_LAUNCHES", raising=False)
 
     def state(W, depth, bins, T):
         S = W // 4
