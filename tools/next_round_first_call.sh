@@ -7,13 +7,16 @@
 # with level 1 beside it (plain chains, 2.28 ms per step each) + 20 windows of 6.9 s alone (4096 x 1.56 ms pipelined + 0.5 s).
 # Candidates, by what they could take off the 215 s, with what is already known:
 #   1. the pipelined phase (5.2-5.6 us: 2.9 inputs seen -> stores issued, 1.4 of it the sc1 fetch of the 61-KB activation
-#      block; ~2.3 until the consumer sees the flags).  Probe first (tools/pipelined_launch_probe.hip, a new protocol number):
-#      per-producer dependencies -- wave w of a consumer needs only the 15 producer workgroups that own its K-slice; their
-#      flags in one line per consumer wave -- so that the fetch of early slices overlaps the producers' tail.  10 s per run.
+#      block; ~2.3 until the consumer sees the flags).  Probed at the end of round 4: contiguous shards + per-wave
+#      dependencies (V12 of tools/pipelined_launch_probe.hip) are worth -0.06 .. -0.20 us per phase -> build them into JbPipe
+#      (shard = workgroup / ceil(G / 8); gemv_lnf / gemv PIPE: wave w polls the one or two shards its k-tiles come from and
+#      requests its rows before the workgroup barrier; attention -> c_fc: one shard per channel slice) and validate with the
+#      20-second job (~3 s).  Data-carrying flags (V8-V11), 60 / 240 workgroups per launch and a horizontal fusion of the two
+#      upsampler chains are measured / worked-out dead ends.
 #   2. prefill GEMM 670-745 TFLOP/s -> the guide's 8-phase 256x256 structure (counted vmcnt, raw barriers, 128 KB of LDS):
 #      tools/gemm_glds_probe.hip takes a new tile variant and checks it bit for bit; worth ~1.5 s of the job.
-#   3. conv stacks on three fp16 MFMAs per k-tile with scaled fp16 remainders of both operands (fp32 accuracy, ~3x the exact-fp32
-#      instruction): the tap kernel is at 71 % of the fp32 peak, so this is the only lever left there; ~2.5 s of the job.
+#   3. conv stacks: DONE in round 4 (gemm_split_kernel, conditioner 133 -> 77 ms); staging both operands through LDS (128 x 128
+#      tile, split once per tile) would reach ~45 ms: ~0.8 s of the job.
 #   4. 5b_lyrics decode (4.06 ms, 33 % of HBM): its 16-wave projections are ONE workgroup per compute unit, 300 column tiles take
 #      two rounds; K split over pairs of 8-wave workgroups + a tile queue (1.17 rounds), merged by the pair's last arriver.
 #   5. one prefill chunk per window (measured: no faster, 244 vs 240 ms) would let all wide-value layers share ONE S-wide V buffer:

@@ -18,12 +18,24 @@
 //       16-byte sc1 load per lane (round 3)
 //   V3: V1 with the completion count sharded per XCD: every workgroup adds 1 (non-returning atomic) to the counter of the XCD
 //       it runs on, the consumer's lanes 0..7 read the 8 counters with one sc1 load and compare their sum with (i + 1) * G
+//   V8 / V9 / V10 (round 4, the candidate for round 5): NO completion word at all -- the activations carry their own validity.  V8: every
+//       8-byte word = two halves + a 32-bit tag (the producing slot's number), written and read with relaxed agent-scope 8-byte
+//       atomics; V9 / V10: 16-byte words = four / six halves + the tag (buffer_store / buffer_load b128 sc1; a torn word would show as a checksum
+//       error; a producer's slice ends in a zero-padded word).  The consumer's first wave polls the last word of 64 producers until they carry the producer's tag, then every
+//       thread reads its share of the block and re-reads whatever is not there yet.  Drops the producer's drain (s_waitcnt vmcnt(0)), the ticket atomics, the flag store and
+//       the consumer's flag poll; costs 2x (V8, V9) / 1.35x (V10) the activation bytes.  The tag of a slot never changes: the word a
+//       slot overwrites was written two slots earlier (another tag), so no run counter is needed.
+//   V11: V10's words behind protocol 1's flags (V5) with the producer's drain removed: the flags say "stores issued", the tags catch
+//       the words still in flight.
+//   V12: protocol 1 (V5) with contiguous shards -- the producers of one eighth of the block -- and consumer waves that wait for
+//       their own eighth only.
 //   "2 graphs": the even and the odd kernels of the chain as two single-stream graphs replayed on two streams (a 2-stream
 //       capture in ONE graph replays at 22 us per kernel: round 3, profiles/r03_pipelined_launch_probe.log)
 // Spin loops are bounded: after 2^22 polls a workgroup raises the abort flag, every later poll returns at once and the
 // run is reported as aborted (no hung GPU).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tools -o tools/pipelined_launch_probe tools/pipelined_launch_probe.hip -lhsa-runtime64
 // Run:   tools/pipelined_launch_probe [graph launches, default 40] [first protocol] [last protocol] [1: the AQL modes too]
+//        [1: sweep of the workgroup count instead of the three shapes of the step]
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <cstdio>
@@ -38,12 +50,14 @@ constexpr int N_W8 = N_EL / 4;             // 8-byte words
 constexpr int THREADS = 512;
 constexpr int K = 288;                     // kernels per graph (even: the double buffer of phase j is static)
 constexpr int PAD = 32;                    // flags / tickets 128 B apart
+constexpr size_t TAGGED_BLOCK = 131072;    // bytes per block of tagged words (V8 / V9: 122 880, V10: <= 82 944)
 typedef unsigned long long u64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct Args {
     __half* act; const u32x4* wts; size_t w_phase_u4; unsigned* flags; unsigned* tickets; unsigned* err; unsigned* abort_flag;
     float* sink; int G; unsigned* rows;      // rows: [K][256] per-producer flags (V2)
+    void* tagged;                             // V8 / V9: two blocks of tagged words
 };
 __device__ inline __amdgpu_buffer_rsrc_t rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, 0x7fffffff, 0x00020000);
@@ -66,17 +80,153 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
     __shared__ float red[THREADS / 64];
     __shared__ unsigned s_i;
     const int tid = threadIdx.x, wg = blockIdx.x;
-    // 1. the weight stream does not depend on the producer: request it first (8 x 16 B per thread = 64 KB per workgroup)
+    // 1. the weight stream does not depend on the producer: request it first (up to 16 x 16 B per thread = 128 KB per workgroup;
+    //    8 at G = 120 / 192, 15 at G = 60)
     const size_t per_wg = a.w_phase_u4 / a.G;
     const u32x4* w = a.wts + (size_t)j * a.w_phase_u4 + (size_t)wg * per_wg;
-    u32x4 wv[8];
+    u32x4 wv[16];
+    const int n_ld = min(16, (int)((per_wg + THREADS - 1) / THREADS));
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
         const size_t k = (size_t)tid + (size_t)u * THREADS;
-        wv[u] = __builtin_nontemporal_load(w + (k < per_wg ? k : per_wg - 1));
+        wv[u] = u32x4{0u, 0u, 0u, 0u};
+        if (u < n_ld) wv[u] = __builtin_nontemporal_load(w + (k < per_wg ? k : per_wg - 1));
     }
     asm volatile("" ::: "memory");
+    if constexpr (V >= 8 && V <= 11) {
+        // ---- tagged activations: the data is the flag ----
+        constexpr int HPW = V == 8 ? 2 : (V == 9 ? 4 : 6);        // halves per word (V11: as V10)
+        constexpr int WB = V == 8 ? 8 : 16;                       // bytes per word (V9: 4 bytes of padding)
+        constexpr int PER_T = V == 8 ? 30 : (V == 9 ? 15 : 11);   // words per thread (upper bound)
+        const int per = N_EL / a.G;                               // halves per producer workgroup (256 / 160)
+        const int spw = (per + HPW - 1) / HPW;                    // words per producer workgroup (the last one padded with zeros)
+        const int nwt = a.G * spw;                                // words per block
+        const unsigned want = j == 0 ? (unsigned)K : (unsigned)j; // the producer slot's tag (slot j writes tag j + 1)
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.tagged) + (size_t)(j & 1) * TAGGED_BLOCK;
+        unsigned char* dst = reinterpret_cast<unsigned char*>(a.tagged) + (size_t)((j + 1) & 1) * TAGGED_BLOCK;
+        auto ld_word = [&](int w, float& sum) -> bool {           // true if the word carries the wanted tag; sum = its halves
+            if (w >= nwt) { sum = 0.f; return true; }
+            if constexpr (V == 8) {
+                const u64 q = __hip_atomic_load(reinterpret_cast<const u64*>(src) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                union { unsigned u; __half h[2]; } cv; cv.u = (unsigned)q;
+                sum = __half2float(cv.h[0]) + __half2float(cv.h[1]);
+                return (unsigned)(q >> 32) == want;
+            } else {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc(src), w * 16, 0, 16);
+                union { unsigned u[3]; __half h[6]; } cv; cv.u[0] = q.x; cv.u[1] = q.y; cv.u[2] = q.z;
+                sum = 0.f;
+                for (int k = 0; k < HPW; ++k) sum += __half2float(cv.h[k]);
+                return q.w == want;
+            }
+        };
+        float part[PER_T];
+        unsigned own_runs = 0;
+        if constexpr (V == 11) {
+            // V11: protocol 1's flags say "every producer has ISSUED its stores" (no drain before the ticket); the tags catch the words
+            // that are still in flight
+            if (tid < 64) {
+                const unsigned i = ld_flag(a.flags + j * PAD + 1);
+                if constexpr (WAIT) {
+                    const int prev = j == 0 ? K - 1 : j - 1;
+                    const unsigned n_shards = a.G < 8 ? (unsigned)a.G : 8u, need = j == 0 ? i : i + 1;
+                    const unsigned* w = a.rows + (size_t)prev * 1024 + 256 + (tid & 7) * 32;
+                    for (unsigned spins = 0;; ++spins) {
+                        const bool ok = (unsigned)tid >= n_shards || ld_flag(w) >= need;
+                        if (__all(ok)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (spins > (1u << 22) || ((spins & 255) == 255 && ld_flag(a.abort_flag))) {
+                            __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                if (tid == 0) s_i = i;
+            }
+            __syncthreads();
+            own_runs = s_i;
+        } else if constexpr (WAIT) {
+            // a. the cheap poll: the lanes of the first wave watch the LAST word of 64 producers spread over the launch (64 lines per
+            //    workgroup and round) until all of them carry the producer's tag; the other waves sleep at the barrier
+            if (tid < 64) {
+                const int w = ((tid * a.G) >> 6) * spw + spw - 1;
+                for (unsigned spins = 0;; ++spins) {
+                    if (__all(ld_word(w, part[0]))) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins > (1u << 22) || ((spins & 255) == 255 && ld_flag(a.abort_flag))) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // b. the thread's share of the block, all requests in flight; c. whatever is not there yet, again
+        bool ok[PER_T];
+#pragma unroll
+        for (int u = 0; u < PER_T; ++u) ok[u] = ld_word(tid + u * THREADS, part[u]);
+        if constexpr (WAIT) {
+            for (unsigned spins = 0;; ++spins) {
+                bool all_ok = true;
+#pragma unroll
+                for (int u = 0; u < PER_T; ++u) all_ok = all_ok && ok[u];
+                if (__all(all_ok)) break;
+#pragma unroll
+                for (int u = 0; u < PER_T; ++u) if (!ok[u]) ok[u] = ld_word(tid + u * THREADS, part[u]);
+                if (spins > (1u << 22) || ((spins & 255) == 255 && ld_flag(a.abort_flag))) {
+                    __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < PER_T; ++u) s += part[u];
+        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        float tot = 0.f;
+        for (int k = 0; k < THREADS / 64; ++k) tot += red[k];
+        const unsigned p = (unsigned)j;                           // K is a multiple of 8: the values depend on j only
+        if (tid == 0 && tot != expected_sum(p)) atomicAdd(a.err, 1u);
+        // my slice of the next block, tagged with this slot's number; nothing to drain, nothing to publish
+        if (tid < spw) {
+            __half hv[6];
+            for (int k = 0; k < HPW; ++k) {
+                const int o = tid * HPW + k;                      // position inside this workgroup's slice
+                hv[k] = o < per ? value_at(wg * per + o, p + 1) : __float2half(0.f);
+            }
+            if constexpr (V == 8) {
+                union { unsigned u; __half h[2]; } cv; cv.h[0] = hv[0]; cv.h[1] = hv[1];
+                __hip_atomic_store(reinterpret_cast<u64*>(dst) + wg * spw + tid, ((u64)(unsigned)(j + 1) << 32) | cv.u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                union { unsigned u[3]; __half h[6]; } cv; cv.u[2] = 0u;
+                for (int k = 0; k < HPW; ++k) cv.h[k] = hv[k];
+                u32x4 q; q.x = cv.u[0]; q.y = cv.u[1]; q.z = cv.u[2]; q.w = (unsigned)(j + 1);
+                __builtin_amdgcn_raw_buffer_store_b128(q, rsrc(dst), (wg * spw + tid) * 16, 0, 16);
+            }
+        }
+        float wacc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wacc += __uint_as_float(wv[u].x ^ wv[u].y ^ wv[u].z ^ wv[u].w);
+        if (wacc + tot * 1e-30f == 123.456f) a.sink[0] = wacc;
+        if constexpr (V == 11) {
+            // publish as V5, but WITHOUT waiting for the stores to be acknowledged: the barrier only orders their issue
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned shard = (unsigned)wg & 7u, members = ((unsigned)a.G - shard + 7u) >> 3;
+                unsigned* tk = a.rows + (size_t)j * 1024 + shard * 32;
+                if (__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                    __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (shard == 0) __hip_atomic_store(a.flags + j * PAD + 1, own_runs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.rows + (size_t)j * 1024 + 256 + shard * 32, own_runs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        return;
+    }
     // 2. how often has this slot run (its own flag), then wait for the producer slot to have run once more
+    u64 r12[N_W8 / THREADS];                 // V12: the wave's eighth of the block, requested as soon as its shard is complete
     if constexpr (V == 3) {
         if (tid < 64) {
             // counters never reset: slot j has run i times when its 8 counters sum to i * G
@@ -145,6 +295,31 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
             }
             s_i = i;
         }
+    } else if constexpr (V == 12) {
+        // V12: protocol 1 with CONTIGUOUS shards (workgroups g / (G / 8): the producers of one eighth of the activation block) and a
+        // consumer whose wave w needs only shard w: it polls that one flag and requests its eighth of the block at once -- the
+        // fetch of early shards overlaps the producers' tail.  (The barrier below then only joins the waves for the reduction.)
+        {
+            const int wv_id = tid >> 6, ln = tid & 63;
+            const unsigned i = ld_flag(a.flags + j * PAD + 1);
+            if constexpr (WAIT) {
+                const int prev = j == 0 ? K - 1 : j - 1;
+                const unsigned need = j == 0 ? i : i + 1;
+                const unsigned* w = a.rows + (size_t)prev * 1024 + 256 + wv_id * 32;
+                for (unsigned spins = 0;; ++spins) {
+                    if (ld_flag(w) >= need) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins > (1u << 22) || ((spins & 255) == 255 && ld_flag(a.abort_flag))) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            const u64* s8 = reinterpret_cast<const u64*>(a.act + (size_t)(j & 1) * N_EL) + wv_id * (N_W8 / 8);
+#pragma unroll
+            for (int u = 0; u < N_W8 / THREADS; ++u) r12[u] = ld8<1>(s8 + ln + u * 64);
+            if (tid == 0) s_i = i;
+        }
     } else if constexpr (V == 5 || V == 7) {
         // V5: 8 shard tickets; the last arriver of a shard stores the run's number into the shard's own FLAG WORD (write-through,
         // once per run); lanes 0..7 of wave 0 poll one flag word each.  V5: the 8 words in 8 different 128-byte lines; V7: in
@@ -193,7 +368,7 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
     const u64* s8 = reinterpret_cast<const u64*>(src);
     u64 r[N_W8 / THREADS];
 #pragma unroll
-    for (int u = 0; u < N_W8 / THREADS; ++u) r[u] = ld8<V>(s8 + tid + u * THREADS);
+    for (int u = 0; u < N_W8 / THREADS; ++u) r[u] = V == 12 ? r12[u] : ld8<(V == 12 ? 1 : V)>(s8 + tid + u * THREADS);
 #pragma unroll
     for (int u = 0; u < N_W8 / THREADS; ++u) {
         union { u64 q; __half h[4]; } cv; cv.q = r[u];
@@ -215,7 +390,7 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
     }
     float wacc = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) wacc += __uint_as_float(wv[u].x ^ wv[u].y ^ wv[u].z ^ wv[u].w);
+    for (int u = 0; u < 16; ++u) wacc += __uint_as_float(wv[u].x ^ wv[u].y ^ wv[u].z ^ wv[u].w);
     if (wacc + tot * 1e-30f == 123.456f) a.sink[0] = wacc;
     // 5. publish: every workgroup's stores are visible device-wide before its ticket; the last ticket raises the flag
     if constexpr (V == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // s_waitcnt + buffer_wbl2 sc1
@@ -237,6 +412,19 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
                 if (shard == 0) __hip_atomic_store(a.flags + j * PAD + 1, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(reinterpret_cast<unsigned char*>(a.flags + j * PAD + 2) + shard, (unsigned char)((i + 1) & 0xffu),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else if constexpr (V == 12) {
+        if (tid == 0) {
+            const unsigned spb = ((unsigned)a.G + 7u) >> 3, shard = (unsigned)wg / spb;
+            const unsigned members = min(spb, (unsigned)a.G - shard * spb);
+            unsigned* tk = a.rows + (size_t)j * 1024 + shard * 32;
+            if (__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the slot's own count moves with the LAST shard's flag: in this probe every workgroup of a run is resident before any
+                // can finish (G <= 256), so no late starter reads it (the engine guards it with a count of finished shards)
+                if (shard == 0) __hip_atomic_store(a.flags + j * PAD + 1, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.rows + (size_t)j * 1024 + 256 + shard * 32, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     } else if constexpr (V == 5 || V == 7) {
@@ -297,9 +485,17 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     for (int k = 0; k < 3; ++k) CK(hipEventCreateWithFlags(&join[k], hipEventDisableTiming));
     struct Shape { int G; size_t wbytes; const char* what; };
-    const Shape shapes[3] = {{120, 7372800, "c_fc / mlp.c_proj (1920x1920)"}, {192, 11059200, "wide c_attn (1920x2880)"},
+    // argv[5] = 1: the same 1920 x 1920 matrix on 60 / 120 / 240 workgroups (32 / 16 / 8 columns each) and the weightless phase on as
+    // many: does the phase get cheaper when fewer workgroups fetch the 61-KB activation block?
+    const bool sweep = argc > 5 && atoi(argv[5]) != 0;
+    const std::vector<Shape> shapes = sweep
+        ? std::vector<Shape>{{60, 7372800, "1920x1920 on 60 workgroups"}, {120, 7372800, "1920x1920 on 120 workgroups"},
+                             {240, 7372800, "1920x1920 on 240 workgroups"}, {60, 0, "no weights, 60 workgroups"},
+                             {120, 0, "no weights, 120 workgroups"}, {240, 0, "no weights, 240 workgroups"}}
+        : std::vector<Shape>{{120, 7372800, "c_fc / mlp.c_proj (1920x1920)"}, {192, 11059200, "wide c_attn (1920x2880)"},
                              {120, 0, "no weights"}};
     unsigned* rows; CK(hipMalloc(&rows, (size_t)K * 1024 * 4));
+    void* tagged; CK(hipMalloc(&tagged, 2 * TAGGED_BLOCK));
     // kind 0: one graph (all streams captured into it)   1: eager   2: one single-stream graph per stream, replayed side by side
     struct Mode { int ns; bool wait; int kind; const char* name; };
     const Mode modes[] = {{1, false, 0, "graph 1 stream, no wait"}, {1, true, 0, "graph 1 stream, wait"},
@@ -307,11 +503,24 @@ int main(int argc, char** argv) {
                           {2, true, 2, "2 graphs on 2 streams, wait"}, {3, true, 2, "3 graphs on 3 streams, wait"}};
     const int v_lo = argc > 2 ? atoi(argv[2]) : 1, v_hi = argc > 3 ? atoi(argv[3]) : 4;     // protocol variants to run
     for (const Shape& sh : shapes) for (int v = v_lo; v <= v_hi; ++v) for (const Mode& m : modes) {
-        Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G, rows};
+        Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G, rows, tagged};
         if (a.w_phase_u4 == 0) a.w_phase_u4 = (size_t)sh.G;      // one dummy vector per workgroup
         CK(hipMemcpy(act, h.data(), N_EL * 2, hipMemcpyHostToDevice));
         CK(hipMemset(flags, 0, K * PAD * 4)); CK(hipMemset(tickets, 0, K * PAD * 4)); CK(hipMemset(err, 0, 4)); CK(hipMemset(abortf, 0, 4));
         CK(hipMemset(rows, 0, (size_t)K * 1024 * 4));
+        if (v >= 8 && v <= 11) {
+            // block 0 as the last slot of a previous replay would have left it (tag K), block 1 with a tag no slot waits for
+            const int hpw = v == 8 ? 2 : (v == 9 ? 4 : 6), wu = v == 8 ? 2 : 4;          // (V11: as V10)        // halves / 32-bit units per word
+            const int per = N_EL / sh.G, spw = (per + hpw - 1) / hpw;
+            std::vector<unsigned> t(2 * TAGGED_BLOCK / 4, 0xffffffffu);
+            for (int g = 0; g < sh.G; ++g) for (int w = 0; w < spw; ++w) {
+                unsigned* word = &t[((size_t)g * spw + w) * wu];
+                for (int u = 0; u < wu; ++u) word[u] = 0u;
+                for (int k = 0; k < hpw; ++k) if (w * hpw + k < per) reinterpret_cast<__half*>(word)[k] = h[(size_t)g * per + w * hpw + k];
+                word[wu - 1] = (unsigned)K;
+            }
+            CK(hipMemcpy(tagged, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        }
         CK(hipDeviceSynchronize());
         auto launch_j = [&](int j, hipStream_t s) {
             if (v == 1) { if (m.wait) launch<1, true>(a, j, s); else launch<1, false>(a, j, s); }
@@ -320,7 +529,12 @@ int main(int argc, char** argv) {
             else if (v == 4) { if (m.wait) launch<4, true>(a, j, s); else launch<4, false>(a, j, s); }
             else if (v == 5) { if (m.wait) launch<5, true>(a, j, s); else launch<5, false>(a, j, s); }
             else if (v == 6) { if (m.wait) launch<6, true>(a, j, s); else launch<6, false>(a, j, s); }
-            else { if (m.wait) launch<7, true>(a, j, s); else launch<7, false>(a, j, s); }
+            else if (v == 7) { if (m.wait) launch<7, true>(a, j, s); else launch<7, false>(a, j, s); }
+            else if (v == 8) { if (m.wait) launch<8, true>(a, j, s); else launch<8, false>(a, j, s); }
+            else if (v == 9) { if (m.wait) launch<9, true>(a, j, s); else launch<9, false>(a, j, s); }
+            else if (v == 10) { if (m.wait) launch<10, true>(a, j, s); else launch<10, false>(a, j, s); }
+            else if (v == 11) { if (m.wait) launch<11, true>(a, j, s); else launch<11, false>(a, j, s); }
+            else { if (m.wait) launch<12, true>(a, j, s); else launch<12, false>(a, j, s); }
         };
         float ms = 0.f;
         if (m.kind == 0) {
@@ -395,7 +609,7 @@ int main(int argc, char** argv) {
             {4, true, false, 0, 0, 81920, "aql barrier=0 no fences lds 80K"},
         };
         for (const Shape& sh : shapes) for (const AqlMode& m : am) {
-            Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G, rows};
+            Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G, rows, tagged};
             if (a.w_phase_u4 == 0) a.w_phase_u4 = (size_t)sh.G;
             CK(hipMemcpy(act, h.data(), N_EL * 2, hipMemcpyHostToDevice));
             CK(hipMemset(flags, 0, K * PAD * 4)); CK(hipMemset(tickets, 0, K * PAD * 4)); CK(hipMemset(err, 0, 4)); CK(hipMemset(abortf, 0, 4));
