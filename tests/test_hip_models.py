@@ -151,10 +151,18 @@ def test_pipelined_levels_equal_sequential(models):
     outs = []
     # pipeline_chunk: decode steps between two publications of a window's codes to the level below (0: whole windows);
     # 5 does not divide the windows, so a lower window starts in the middle of an upper one
-    for pipe, chunk, bs in ((False, 0, 3), (True, 0, 3), (True, 5, 3), (True, 256, 3), (False, 0, 2)):
+    # recheck: the lowest level's window in plain chunks of that many steps while upper levels still run, the sampler asked
+    # again between them (ConditionalAutoregressive2D._decode_window; 512 in production -- longer than these windows)
+    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
+    for pipe, chunk, bs, recheck in ((False, 0, 3, 512), (True, 0, 3, 512), (True, 5, 3, 512), (True, 256, 3, 512), (False, 0, 2, 512),
+                                     (True, 0, 3, 7)):
         hps = Hyperparams(n_samples=n, sample_length=4608, hop_fraction=[0.5, 0.5, 0.125], sr=22050, name="unused",
                           keep_priors_resident=True, pipeline_levels=pipe, pipeline_chunk=chunk, seed=5)
-        zs = S.ancestral_sample(labels, [dict(k, max_batch_size=bs) for k in sk], priors, hps, save=False)
+        AR.PIPE_RECHECK_STEPS = recheck
+        try:
+            zs = S.ancestral_sample(labels, [dict(k, max_batch_size=bs) for k in sk], priors, hps, save=False)
+        finally:
+            AR.PIPE_RECHECK_STEPS = 512
         outs.append([z.cpu().numpy() for z in zs])
     for other in outs[1:]:            # the last run splits the batch 2 + 1: draws are keyed by the global sample index
         for a, b in zip(outs[0], other):

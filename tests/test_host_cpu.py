@@ -503,6 +503,77 @@ def test_in_situ_choice_between_the_launch_forms():
     assert short.calls == [(0, 700, True)] and not hasattr(short, "_pipe_verdict")
 
 
+def test_window_switches_to_pipelined_launches_when_the_upper_levels_finish():
+    """ConditionalAutoregressive2D._decode_window: while the sampler says "not alone yet" the window runs on the plain chain in
+    chunks of PIPE_RECHECK_STEPS steps and asks again between them; from the chunk boundary at which the upper levels are done
+    the rest of the window takes pipelined launches (with the in-situ comparison when >= 1024 steps are left).  Every position is
+    decoded exactly once, in order; a sampler without an opinion, a verdict against pipelined launches, or an engine that
+    already runs them leave the window as one call."""
+    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
+
+    class FakeEngine:
+        def __init__(self):
+            self.pipelined, self.calls = False, []
+        def pipe_error(self):
+            return 0
+        def set_pipelined(self, on, fresh=False):
+            self.pipelined = bool(on)
+            return self.pipelined
+        def decode(self, t0, n):
+            self.calls.append((t0, n, self.pipelined))
+        def timed_decode(self, t0, n):
+            self.decode(t0, n)
+            return (1.56 if self.pipelined else 1.87) * 1e-3
+
+    class Host:
+        _decode, _decode_window, _apply_pipeline = AR._decode, AR._decode_window, AR._apply_pipeline
+        PIPE_RECHECK_STEPS = AR.PIPE_RECHECK_STEPS
+
+    def covered(eng, t0, n):
+        pos = t0
+        for c0, cn, _ in eng.calls:
+            assert c0 == pos
+            pos += cn
+        assert pos == t0 + n
+
+    C = AR.PIPE_RECHECK_STEPS
+    # the upper levels finish while the third chunk runs
+    h, eng = Host(), FakeEngine()
+    h.pipeline_launches = lambda: len(eng.calls) >= 3
+    h._decode_window(eng, 4096, 4096)
+    covered(eng, 4096, 4096)
+    assert eng.calls[:3] == [(4096, C, False), (4096 + C, C, False), (4096 + 2 * C, C, False)]
+    assert eng.calls[3] == (4096 + 3 * C, 16, True) and eng.calls[4][1:] == (384, True) and eng.calls[5][1:] == (128, False)
+    assert eng._pipe_verdict is True and eng.calls[-1][2] is True and h.pipeline_report["kept"] is True
+    # they never do: plain chunks to the end, the last call takes what is left (>= one chunk), nothing is switched on
+    h, eng = Host(), FakeEngine()
+    h.pipeline_launches = lambda: False
+    h._decode_window(eng, 0, 4096 + 100)
+    covered(eng, 0, 4096 + 100)
+    assert all(not p for _, _, p in eng.calls) and eng.calls[-1][1] == C + 100 and not hasattr(eng, "_pipe_verdict")
+    # already alone at the start of the window: no chunks, straight into the in-situ comparison
+    h, eng = Host(), FakeEngine()
+    h.pipeline_launches = lambda: True
+    h._decode_window(eng, 4096, 4096)
+    covered(eng, 4096, 4096)
+    assert eng.calls[0] == (4096, 16, True)
+    # alone from a chunk boundary with < 1024 steps left: pipelined without a measurement, the next window measures
+    h, eng = Host(), FakeEngine()
+    h.pipeline_launches = lambda: len(eng.calls) >= 7
+    h._decode_window(eng, 0, 4096)
+    covered(eng, 0, 4096)
+    assert eng.calls[-1] == (7 * C, C, True) and not hasattr(eng, "_pipe_verdict")
+    # no opinion / a verdict against them / an engine that already has them: one call
+    for setup in ("none", "verdict", "on"):
+        h, eng = Host(), FakeEngine()
+        if setup == "verdict":
+            h.pipeline_launches, eng._pipe_verdict = (lambda: False), False
+        if setup == "on":
+            h.pipeline_launches, eng.pipelined, eng._pipe_verdict = (lambda: True), True, True
+        h._decode_window(eng, 0, 4096)
+        assert eng.calls == [(0, 4096, setup == "on")]
+
+
 def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
     """jb_engine_pipeline's host logic (no launch happens before the first decode): which engines are eligible (fp16, <= 16
     samples, wide-value layers of one 480-channel head, key sets <= 128), ONE owner per process, release by switching off
