@@ -7,12 +7,10 @@
 # with level 1 beside it (plain chains, 2.28 ms per step each) + 20 windows of 6.9 s alone (4096 x 1.56 ms pipelined + 0.5 s).
 # Candidates, by what they could take off the 215 s, with what is already known:
 #   1. the pipelined phase (5.2-5.6 us: 2.9 inputs seen -> stores issued, 1.4 of it the sc1 fetch of the 61-KB activation
-#      block; ~2.3 until the consumer sees the flags).  Probed at the end of round 4: contiguous shards + per-wave
-#      dependencies (V12 of tools/pipelined_launch_probe.hip) are worth -0.06 .. -0.20 us per phase -> build them into JbPipe
-#      (shard = workgroup / ceil(G / 8); gemv_lnf / gemv PIPE: wave w polls the one or two shards its k-tiles come from and
-#      requests its rows before the workgroup barrier; attention -> c_fc: one shard per channel slice) and validate with the
-#      20-second job (~3 s).  Data-carrying flags (V8-V11), 60 / 240 workgroups per launch and a horizontal fusion of the two
-#      upsampler chains are measured / worked-out dead ends.
+#      block; ~2.3 until the consumer sees the flags): every idea inside this decomposition has now been measured --
+#      data-carrying flags, "stores issued" flags, 60 / 240 workgroups, per-wave dependencies (built into the engine on branch
+#      wip/pipe-v12: no gain).  What is left is structural: pipelined forms of the multi-head / 16-wave kernels (top priors, 5b),
+#      or a fused pipelined pair of the two upsampler levels (~6 s of the job for a lock-step scheduler).
 #   2. prefill GEMM 670-745 TFLOP/s -> the guide's 8-phase 256x256 structure (counted vmcnt, raw barriers, 128 KB of LDS):
 #      tools/gemm_glds_probe.hip takes a new tile variant and checks it bit for bit; worth ~1.5 s of the job.
 #   3. conv stacks: DONE in round 4 (gemm_split_kernel, conditioner 133 -> 77 ms); staging both operands through LDS (128 x 128
