@@ -97,10 +97,15 @@ typedef struct jb_gemm_args {
      * JB_F16_SPLIT image per tap (same bytes as the fp32 image, so tap_stride counts fp32 elements as before).  The kernel
      * splits the fp32 activations the same way and evaluates w_hi*a_hi + 2^-11 * (w_hi*a_lo + w_lo*a_hi) with fp32
      * accumulation: three f16 MFMAs per k-tile at 16x the rate of the exact-fp32 instruction; the dropped term is
-     * 2^-22 relative, below the rounding of the fp32 accumulation itself.  Inputs must be inside the f16 range (|x| < 65504). */
+     * 2^-22 relative, below the rounding of the fp32 accumulation itself.  Inputs must be inside the f16 range (|x| <= 65504): a launch that
+     * sees one outside raises a sticky device flag, jb_gemm_split_overflow. */
     int w_split;
 } jb_gemm_args;
 int jb_gemm(const jb_gemm_args* args /* host */, void* stream);
+/* 1 if a w_split launch since the last reset was given an activation outside the half range (|x| > 65504, or NaN) -- its output is
+ * then not the convolution --, 0 if not, < 0 on error.  Synchronises with the device (a 4-byte read); reset != 0 clears the flag.
+ * The sampler asks once per job (jukebox_amd/sample.py), the tests after every case. */
+int jb_gemm_split_overflow(int reset);
 /* Flat problems (one tap, unit strides) of at least `min_rows` output rows use the LDS-staged 256x128-tile kernel
  * (default 1024; < 0: never). */
 void jb_tune_gemm_lds(int min_rows);

@@ -79,6 +79,7 @@ _SIGS = {
     "jb_pack_weight": (i32, [vp, i32, i64, i64, i32, i32, vp, i32, vp]),
     "jb_layernorm_fwd": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, f32, vp]),
     "jb_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "jb_gemm_split_overflow": (i32, [i32]),
     "jb_gemv": (i32, [C.POINTER(GemvArgs), vp]),
     "jb_gemv_ln_fold_supported": (i32, [i32, i32, i32, i32]),
     "jb_attn_decode": (i32, [i32, i32, vp, i64, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp]),

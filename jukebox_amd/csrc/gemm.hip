@@ -351,6 +351,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 // Two workgroups per compute unit hide the operand latency; a second register set with the next k-step's operands in
 // flight (one workgroup per compute unit) measured slower: 122 against 77 ms for the upsampler's conditioner at 16 samples,
 // exact-fp32 kernel 133 ms (profiles/r04_bench_conditioner.log).
+// Set (sticky) by gemm_split_kernel when an activation it was given does not fit a half: the hi part would be +-inf and the result
+// garbage.  Read and cleared by jb_gemm_split_overflow; the sampler asks once per job, the tests after every case.
+__device__ unsigned g_split_overflow = 0u;
+
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -376,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
     if (m_base >= p.m_total) return;   // whole wave out of range (uniform per wave)
 
     const float* A = (const float*)p.A;
+    bool too_big = false;                                       // an activation outside the half range was seen (g_split_overflow)
     const int64_t lo_image = (int64_t)p.njt * p.nkt * 512;      // f16 elements from a tap's hi image to its lo image
     const float relu_floor = p.pre_relu ? 0.f : -INFINITY;      // the input ReLU as a branch-free max
     int64_t woff[4];
@@ -413,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
                 for (int e = 0; e < 8; ++e) {
                     float x = ar[mt][e >> 2][e & 3];
                     x = aval[mt] ? fmaxf(x, relu_floor) : 0.f;
+                    too_big = too_big || !(fabsf(x) <= 65504.0f);       // (a NaN input is reported too)
                     const f16 h = (f16)x;
                     ah[mt][e] = h;
                     al[mt][e] = (f16)((x - (float)h) * 2048.0f);
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
         }
     }
 
+    if (__any((int)too_big) && lane == 0) atomicOr(&g_split_overflow, 1u);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         if (!mvalid[mt]) continue;
@@ -648,6 +655,22 @@ static int g_gemm_lds_min_rows = 1024;
 extern "C" void jb_tune_gemm_lds(int min_rows) { g_gemm_lds_min_rows = min_rows; }
 
 static inline bool aligned_to(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+extern "C" int jb_gemm_split_overflow(int reset) {
+    unsigned v = 0u;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_overflow), sizeof v, 0, hipMemcpyDeviceToHost) != hipSuccess) {
+        jb_set_error("jb_gemm_split_overflow: cannot read the device flag");
+        return JB_ERR_HIP;
+    }
+    if (reset && v) {
+        const unsigned zero = 0u;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_overflow), &zero, sizeof zero, 0, hipMemcpyHostToDevice) != hipSuccess) {
+            jb_set_error("jb_gemm_split_overflow: cannot clear the device flag");
+            return JB_ERR_HIP;
+        }
+    }
+    return v ? 1 : 0;
+}
 
 extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     JB_REQUIRE(a && a->A && a->W && a->out, "null pointer");

@@ -81,6 +81,7 @@ def pack_conv_taps(w, dtype, transposed=False, split=False):
     w = w.contiguous()
     if split:
         assert dtype == torch.float32 and w.shape[0 if transposed else 1] % 32 == 0
+        assert float(w.abs().max()) <= 65504.0, "f16-split weight image: |w| must fit a half"     # (once per layer, at pack time)
     if transposed:
         Cin, Cout, k = w.shape
         sk, sj = Cout * k, k
@@ -142,6 +143,18 @@ def gemm(A, pw, bias=None, out=None, res=None, n_seq=1, t_in=None, t_out=None, s
     a.w_split = int(pw.split)
     L.check(L.lib().jb_gemm(C.byref(a), L.stream()))
     return out
+
+
+def check_split_overflow():
+    """Raise if a conv-stack launch on the f16-split path (jb_gemm_args.w_split) has seen an activation outside the half range
+    since the last check: its output is not the convolution.  Waits for the device (called once per job / per test)."""
+    torch.cuda.synchronize()                 # the flag is read on the null stream, which does not wait for torch's streams
+    rc = L.lib().jb_gemm_split_overflow(1)
+    if rc < 0:
+        L.check(rc)
+    if rc:
+        raise L.JukeboxHipError("a convolution on the f16-split path was given activations outside the half range (|x| > 65504 or "
+                                "NaN): its output is invalid (jukebox_amd.vqvae.rows.SPLIT_F16 = False selects the exact-fp32 kernel)")
 
 
 def gemm_qkv(h, pw, bias, n_seq, n_q, S, kcache, vcache, t0):

@@ -352,6 +352,11 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
                 if "info" in labels[-1] and all("lyrics" in i for i in labels[-1]["info"]):
                     from .save_html import save_html                      # sample.py:120
                     save_html(logdir, x, zs, labels[-1], alignments, Hyperparams(levels=len(priors), sr=hps.sr))
+    if t.device(device).type == "cuda":
+        # the conv stacks (conditioners, VQ-VAE decoder) ran on the f16-split kernels: fail loudly if any of them was handed
+        # activations outside the half range (a sticky device flag; one 4-byte read per job)
+        from . import hip_ops
+        hip_ops.check_split_overflow()
     _sample.last_audio = xs
     return zs
 

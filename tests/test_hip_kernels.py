@@ -285,6 +285,32 @@ def test_conv_stack_ops_f16_split(H, Ci, Co, T, scale):
     print("f16-split conv stack Ci=%d scale=%g: worst error %.2e of the output scale" % (Ci, scale, worst))
 
 
+def test_gemm_split_reports_activations_outside_the_half_range(H):
+    """The f16-split path cannot represent |x| > 65504: a launch that sees such an activation (or a NaN) raises the sticky device
+    flag behind jb_gemm_split_overflow, hip_ops.check_split_overflow turns it into an exception and clears it; values up to the
+    largest half, and rows that are only out of range BEFORE the input ReLU, do not."""
+    from jukebox_amd import _lib as L
+    H.check_split_overflow()                                         # (clean start)
+    w = torch.randn(16, 64, 3, device="cuda") * 0.05
+    pw = H.pack_conv_taps(w, torch.float32, split=True)
+    x = torch.randn(2 * 50, 64, device="cuda")
+    x[7, 3] = 65504.0
+    x[9, 5] = -3.0e5
+    H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1), pre_relu=True)   # the negative outlier dies in the ReLU
+    H.check_split_overflow()
+    H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1))
+    assert L.lib().jb_gemm_split_overflow(0) == 1 and L.lib().jb_gemm_split_overflow(0) == 1      # sticky until reset
+    with pytest.raises(L.JukeboxHipError):
+        H.check_split_overflow()
+    assert L.lib().jb_gemm_split_overflow(0) == 0
+    x[9, 5] = float("nan")
+    H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1))
+    with pytest.raises(L.JukeboxHipError):
+        H.check_split_overflow()
+    with pytest.raises(AssertionError):                              # weights are checked when they are packed
+        H.pack_conv_taps(w * 1e7, torch.float32, split=True)
+
+
 def test_gemm_split_refuses_what_it_cannot_take(H):
     """w_split is for fp32 problems with K a multiple of 32 (jb_gemm says so instead of computing something else)."""
     w = torch.randn(16, 48, 3, device="cuda")
