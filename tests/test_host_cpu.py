@@ -503,6 +503,38 @@ def test_in_situ_choice_between_the_launch_forms():
     assert short.calls == [(0, 700, True)] and not hasattr(short, "_pipe_verdict")
 
 
+def test_f16_split_arithmetic_keeps_fp32_accuracy():
+    """The arithmetic of gemm_split_kernel (jb_gemm_args.w_split), restated in numpy: x = hi + 2^-11 lo with hi = half(x),
+    lo = half((x - hi) 2^11) for BOTH operands and w a = w_hi a_hi + 2^-11 (w_hi a_lo + w_lo a_hi), every half product exact.
+    Against float64 the representation error (the dropped 2^-22 term and the rounding of lo) stays below the rounding of an
+    fp32 accumulation of the same length -- for activations of order 1, of a few thousand, of a few thousandths (lo goes
+    subnormal), after a ReLU -- and the split of a value is exact to 2^-22 of it inside the half range."""
+    rng = np.random.default_rng(0)
+
+    def split(x):
+        hi = x.astype(np.float16)
+        lo = ((x - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64)
+
+    x = (rng.standard_normal(100000) * 10.0 ** rng.uniform(-3, 4, 100000)).astype(np.float32)
+    x = x[np.abs(x) <= 65504]
+    hi, lo = split(x)
+    rel = np.abs(hi + lo / 2048.0 - x.astype(np.float64)) / np.maximum(np.abs(x.astype(np.float64)), 6.2e-5)   # (normal halves)
+    assert rel.max() < 2.0 ** -21
+    for scale in (1.0, 3000.0, 1e-3):
+        K = 3072
+        a = np.maximum((scale * rng.standard_normal((48, K))).astype(np.float32), 0)
+        w = (rng.standard_normal((K, 40)) / np.sqrt(K)).astype(np.float32)
+        ah, al = split(a)
+        wh, wl = split(w)
+        got = ah @ wh + (al @ wh + ah @ wl) / 2048.0
+        want = a.astype(np.float64) @ w.astype(np.float64)
+        out_scale = np.abs(want).max()
+        err_split = np.abs(got - want).max() / out_scale
+        err_fp32 = np.abs((a @ w).astype(np.float64) - want).max() / out_scale          # an fp32 accumulation of the same products
+        assert err_split < 1.5e-7 and err_split < err_fp32, (scale, err_split, err_fp32)
+
+
 def test_window_switches_to_pipelined_launches_when_the_upper_levels_finish():
     """ConditionalAutoregressive2D._decode_window: while the sampler says "not alone yet" the window runs on the plain chain in
     chunks of PIPE_RECHECK_STEPS steps and asks again between them; from the chunk boundary at which the upper levels are done
