@@ -15,8 +15,11 @@
 #      tools/gemm_glds_probe.hip takes a new tile variant and checks it bit for bit; worth ~1.5 s of the job.
 #   3. conv stacks: DONE in round 4 (gemm_split_kernel, conditioner 133 -> 77 ms); staging both operands through LDS (128 x 128
 #      tile, split once per tile) would reach ~45 ms: ~0.8 s of the job.
-#   4. 5b_lyrics decode (4.06 ms, 33 % of HBM): its 16-wave projections are ONE workgroup per compute unit, 300 column tiles take
-#      two rounds; K split over pairs of 8-wave workgroups + a tile queue (1.17 rounds), merged by the pair's last arriver.
+#   4. 5b_lyrics decode (4.06-4.16 ms, 33 % of HBM; profiles/r04_5b_kernel_stats.csv: 12.0 / 14.6 / 6.6 / 6.5 us per launch): what
+#      its 16-wave launches lose is fixed cost (dispatch, wave start, first byte, second round of 300 tiles) -- pipelined launches
+#      hide exactly that.  Needs PIPE forms of gemv_lnf<16 waves>, gemv<16 waves>, attn_decode_mfma (ragged heads, cross-attention)
+#      and, for the 1b top prior, attn_decode_split + gemv_merge; the eligibility rule in engine.hip (pipeline_eligible) and the
+#      bit-identity test at 5b geometry (N = 3: protocol 0).  Estimate ~3.2 ms per step.
 #   5. one prefill chunk per window (measured: no faster, 244 vs 240 ms) would let all wide-value layers share ONE S-wide V buffer:
 #      -9 GB per upsampler engine; memory only.
 # Dead ends measured in round 4 (do not repeat): flag bytes / flag words in one line; one barrier-less AQL queue of our own;
