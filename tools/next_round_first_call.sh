@@ -15,11 +15,11 @@
 #      tools/gemm_glds_probe.hip takes a new tile variant and checks it bit for bit; worth ~1.5 s of the job.
 #   3. conv stacks: DONE in round 4 (gemm_split_kernel, conditioner 133 -> 77 ms); staging both operands through LDS (128 x 128
 #      tile, split once per tile) would reach ~45 ms: ~0.8 s of the job.
-#   4. 5b_lyrics decode (4.06-4.16 ms, 33 % of HBM; profiles/r04_5b_kernel_stats.csv: 12.0 / 14.6 / 6.6 / 6.5 us per launch): what
-#      its 16-wave launches lose is fixed cost (dispatch, wave start, first byte, second round of 300 tiles) -- pipelined launches
-#      hide exactly that.  Needs PIPE forms of gemv_lnf<16 waves>, gemv<16 waves>, attn_decode_mfma (ragged heads, cross-attention)
-#      and, for the 1b top prior, attn_decode_split + gemv_merge; the eligibility rule in engine.hip (pipeline_eligible) and the
-#      bit-identity test at 5b geometry (N = 3: protocol 0).  Estimate ~3.2 ms per step.
+#   4. 5b_lyrics decode (4.06-4.16 ms, 33 % of HBM; profiles/r04_5b_kernel_stats.csv: 12.0 / 14.6 / 6.6 / 6.5 us per launch).
+#      Pipelined launches for multi-head engines exist on branch wip/pipe-5b (PIPE form of the MFMA decode attention, 16- / 4-wave
+#      PIPE projections, eligibility rule, pad launch for an odd launch count): bit-identical in 5 cases, and NO faster at 5b
+#      (4.15 ms): a 16-wave workgroup fills a compute unit, so the next launch is not resident while this one streams.  First the
+#      kernels: 8-wave workgroups, two per compute unit, K split over pairs (merged by the pair's last arriver) -- then the branch.
 #   5. one prefill chunk per window (measured: no faster, 244 vs 240 ms) would let all wide-value layers share ONE S-wide V buffer:
 #      -9 GB per upsampler engine; memory only.
 # Dead ends measured in round 4 (do not repeat): flag bytes / flag words in one line; one barrier-less AQL queue of our own;
