@@ -18,8 +18,12 @@
 #   4. 5b_lyrics decode (4.06-4.16 ms, 33 % of HBM; profiles/r04_5b_kernel_stats.csv: 12.0 / 14.6 / 6.6 / 6.5 us per launch).
 #      Pipelined launches for multi-head engines exist on branch wip/pipe-5b (PIPE form of the MFMA decode attention, 16- / 4-wave
 #      PIPE projections, eligibility rule, pad launch for an odd launch count): bit-identical in 5 cases, and NO faster at 5b
-#      (4.15 ms): a 16-wave workgroup fills a compute unit, so the next launch is not resident while this one streams.  First the
-#      kernels: 8-wave workgroups, two per compute unit, K split over pairs (merged by the pair's last arriver) -- then the branch.
+#      (4.15 ms): a 16-wave workgroup fills a compute unit, so the next launch is not resident while this one streams.  The same
+#      branch carries the kernel that should change that, written after the budget was spent and NEVER RUN: gemv_long_kernel (8
+#      waves walking their k-tiles through two register stages of 5 fragments, >= 10 requests in flight per wave by the ISA, 2
+#      workgroups per compute unit, all 300 column tiles resident; jb_tune_gemv_long(1)) with its tests
+#      (test_gemv_long_rows_on_8_waves, the [..-1] cases of test_pipelined_launches_equal_the_plain_chain); the commented lines at
+#      the end of tools/r04_call24.sh on the branch are its first call.  Merge only what the measurement keeps.
 #   5. one prefill chunk per window (measured: no faster, 244 vs 240 ms) would let all wide-value layers share ONE S-wide V buffer:
 #      -9 GB per upsampler engine; memory only.
 # Dead ends measured in round 4 (do not repeat): flag bytes / flag words in one line; one barrier-less AQL queue of our own;
