@@ -98,13 +98,19 @@ typedef struct jb_gemm_args {
      * splits the fp32 activations the same way and evaluates w_hi*a_hi + 2^-11 * (w_hi*a_lo + w_lo*a_hi) with fp32
      * accumulation: three f16 MFMAs per k-tile at 16x the rate of the exact-fp32 instruction; the dropped term is
      * 2^-22 relative, below the rounding of the fp32 accumulation itself.  Inputs must be inside the f16 range (|x| <= 65504): a launch that
-     * sees one outside raises a sticky device flag, jb_gemm_split_overflow. */
+     * sees one outside raises a sticky device flag, jb_gemm_split_overflow.  Weights have no such limit: the caller packs
+     * s * W for a power of two s that brings max |W| into [128, 256) -- small weights then keep 2^-22 relative precision down
+     * to 2^-22 of the largest one, instead of going subnormal below 6e-5 -- and passes 1 / s as w_split_unscale (0 = 1): the
+     * accumulators are multiplied by it before bias, activation and residual (exact: a power of two). */
     int w_split;
+    float w_split_unscale;
 } jb_gemm_args;
 int jb_gemm(const jb_gemm_args* args /* host */, void* stream);
-/* 1 if a w_split launch since the last reset was given an activation outside the half range (|x| > 65504, or NaN) -- its output is
- * then not the convolution --, 0 if not, < 0 on error.  Synchronises with the device (a 4-byte read); reset != 0 clears the flag.
- * The sampler asks once per job (jukebox_amd/sample.py), the tests after every case. */
+/* 1 if a w_split launch since the last reset was given an activation outside the half range (|x| > 65504; under pre_relu only
+ * x > 65504, what the ReLU clips cannot overflow) or a NaN (judged before the ReLU) -- its output is then not the convolution
+ * --, 0 if not, < 0 on error.  The flag is a word in host-coherent memory: the call reads it without touching the device, so
+ * it sees launches that have FINISHED (synchronise the stream first for the launches just enqueued); reset != 0 clears it.
+ * The sampler looks after every window and at the end of a job (jukebox_amd/sample.py), the tests after every case. */
 int jb_gemm_split_overflow(int reset);
 /* Flat problems (one tap, unit strides) of at least `min_rows` output rows use the LDS-staged 256x128-tile kernel
  * (default 1024; < 0: never). */
@@ -173,6 +179,12 @@ int jb_attn_decode_wide(int attn_func, const void* q, int64_t ldq, const void* k
                         const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
                         int width, int block_ctx, const int* t_dev, int max_len, void* stream);
 int jb_attn_decode_wide_supported(int attn_func, int d_head, int width, int block_ctx, int max_len);
+/* 480-channel heads (the 1b upsamplers): 1 (default) = the lean form of the kernel -- the query row goes through LDS instead
+ * of 60 registers per lane, <= 168 registers: a workgroup then shares a compute unit with a waiting projection workgroup of a
+ * pipelined chain, which is what lets TWO engines of a process run pipelined launches (jb_engine_pipeline) and keeps a plain
+ * chain next to a pipelined engine from starving; 0 = the fat form (198-216 registers per lane: one workgroup per otherwise
+ * empty compute unit; jb_engine_pipeline then admits one engine).  Same arithmetic in the same order: bit-identical. */
+void jb_tune_attn_decode_wide_lean(int on);
 
 /* Tuning hook: workgroup size (multiple of 64, <= 1024) and key/value row pairs in flight per wave (2, 4 or 8) of
  * the generic kernel of jb_attn_decode (defaults 512 / 4; a value <= 0 keeps the current one).  kb < 0 disables the
@@ -339,7 +351,11 @@ int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
 /* Run n_steps decode steps starting at position t0 (sets *t_dev = t0 and embeds position t0 first).  One step =
  * L x [c_attn | attention | attn.c_proj | mlp.c_fc | mlp.c_proj] | logits | sample + embed(t+1) + counter: 5 L + 2 launches
  * (wide-value layers have no attn.c_proj launch: 4 per layer; jb_engine_launches_per_step reports the count).
- * use_graph != 0 captures one step into a hipGraph on first use and replays it. */
+ * use_graph = 1 captures one step into a hipGraph on first use and replays it (as pipelined launches while those are
+ * switched on: jb_engine_pipeline); use_graph = 0 is always the eager plain chain on `stream`; use_graph = 2 (diagnostics,
+ * pipelined launches switched on) enqueues the pipelined launches without the graph executor; use_graph = 3 replays the
+ * plain chain's graph even while pipelined launches are switched on (the sampler's in-situ comparison of the two forms).
+ * A pipelined decode is host-synchronous and must not be called on a stream that is being captured. */
 int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
 /* Software-pipelined launches of the decode step (graph replay only): the launches of a step alternate between two streams
  * of the engine's own (each on a hardware queue of its own), so launch j+1 is dispatched -- and requests its weight stream,
@@ -349,15 +365,22 @@ int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* str
  * drains the caller's stream, runs the steps on the pair and returns when they are done (no queue of the process holds a
  * waiting packet meanwhile).  enable != 0 returns JB_ERR_UNSUPPORTED unless every launch of this engine's step has a
  * pipelined form (cfg.pipe_words given, fp16, <= 16 samples, every layer a wide-value layer of one 480-channel head, width
- * and n_mlp of 33..64 k-tiles: the 1b upsamplers), and while ANOTHER engine of the process has them on: a waiting launch
- * occupies compute units, and the waiters of two engines can leave no room for the launches they wait for -- one pipelined
- * engine at a time (enable = 0 or jb_engine_destroy releases the right).  The two streams must feed different hardware
- * queues; the first pipelined decode checks that with a two-kernel handshake and keeps the plain chain otherwise
- * (jb_engine_pipelined then reports 0).  enable = 2 is enable = 1 with a fresh pair of streams and freshly captured
- * graphs at the next decode (the engine must be idle).  Replaces the same reference code as jb_engine_decode. */
+ * and n_mlp of 33..64 k-tiles: the 1b upsamplers), and while TWO other engines of the process have them on: a waiting launch
+ * occupies compute units (two 8-wave projection workgroups fill one); the waiters of two engines leave half of >= 152 compute
+ * units free, where the lean attention workgroups and the projections they wait for still fit; a third engine's could cover
+ * the chip (one engine with jb_tune_attn_decode_wide_lean(0); enable = 0 or jb_engine_destroy releases the right).  The two streams must feed different hardware
+ * queues; the first pipelined decode makes the pair, checks that with a two-kernel handshake and keeps the plain chain
+ * otherwise (jb_engine_pipelined then reports 0).  enable = 0 RELEASES the pair -- streams, hardware queues, graphs --, so
+ * that nothing of it outlives the phase that uses it (two more hardware queues in the process, even idle ones, slow every
+ * plain launch chain next to them; the reference's loop leaves nothing behind either: jukebox/sample.py:90-121); the next
+ * enable makes a new one (milliseconds).  enable = 2 is enable = 1 with a fresh pair at the next decode.  The engine must
+ * be idle in every case.  Replaces the same reference code as jb_engine_decode. */
 int jb_engine_pipeline(void* handle, int enable);
 /* 1 while the engine's decode steps run as pipelined launches, else 0 (also after a fallback to the plain chain). */
 int jb_engine_pipelined(void* handle);
+/* 1 while the engine holds a pair of streams for pipelined launches (from its first pipelined decode until
+ * jb_engine_pipeline(handle, 0) / jb_engine_destroy), else 0. */
+int jb_engine_pipeline_resident(void* handle);
 /* Measurement aid: n_steps passes over all layers launching only the LayerNorm-fused projections (attn.c_attn and
  * mlp.c_fc -- the dominant kernel of the decode step) with their real arguments, back to back on `stream`, bracketed
  * by one HIP event pair.  Synchronises.  out[0] = average microseconds per launch, out[1] = launches timed,

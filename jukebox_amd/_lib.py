@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("K", i32), ("J", i32), ("n_taps", i32), ("in_stride", i32), ("shift", i32 * 4),
                 ("out_stride", i32), ("out_offset", i32), ("pre_relu", i32), ("act", i32), ("res_scale", f32),
                 ("qkv_split", i32), ("S", i32), ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("cache_t0", i32),
-                ("w_split", i32)]
+                ("w_split", i32), ("w_split_unscale", f32)]
 
 
 class GemvArgs(C.Structure):
@@ -89,6 +89,7 @@ _SIGS = {
     # attn_func, q, ldq, kcache, vcache_w, cache_cap, res, ldr, bias, x_out, ldo, n_batch, d_head, width, block_ctx, t_dev, max_len, stream
     "jb_attn_decode_wide": (i32, [i32, vp, i64, vp, vp, i32, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "jb_attn_decode_wide_supported": (i32, [i32, i32, i32, i32, i32]),
+    "jb_tune_attn_decode_wide_lean": (None, [i32]),
     "jb_tune_attn_decode_split": (None, [i32, i32]),
     "jb_tune_attn_decode_split_min_keys": (None, [i32]),
     "jb_tune_gemm_lds": (None, [i32]),
@@ -111,6 +112,7 @@ _SIGS = {
     "jb_engine_launches_per_step": (i32, [vp]),
     "jb_engine_pipeline": (i32, [vp, i32]),
     "jb_engine_pipelined": (i32, [vp]),
+    "jb_engine_pipeline_resident": (i32, [vp]),
     "jb_engine_step_bytes": (C.c_double, [vp, i32]),
 }
 EXPORTS = tuple(_SIGS)

@@ -311,7 +311,12 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
 // PIPE: one launch of a software-pipelined chain (common.h, JbPipe): the query, the position and every cache row are read
 // write-through after the producer launch (c_attn, which appends this position's k / v' rows) has completed; the residual
 // rows are two launches old and the bias is constant: both are requested before the wait.
-template <int ND32, bool PIPE = false>
+// QL ("lean"): the query fragments do not live in registers (15 x 4 of the 198-216 per lane) but in LDS -- every wave copies
+// the 960-byte row into a region of its own (no workgroup barrier: a wave's LDS operations are ordered) and the QK^T chain
+// reads its B operands from there.  At <= 168 registers per lane a workgroup shares a compute unit with a WAITING projection
+// workgroup of a pipelined chain (8 waves at 88 registers): the fat form needs an EMPTY compute unit, which is why only one
+// engine of a process could run pipelined launches, and why a plain chain next to a pipelined engine starved.
+template <int ND32, bool PIPE = false, bool QL = false>
 __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f16* __restrict__ q, int64_t ldq,
                                                                const f16* __restrict__ kc, const f16* __restrict__ vw, int cap,
                                                                const f16* __restrict__ res, int64_t ldr,
@@ -328,12 +333,17 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     const int g = lane >> 4, c = lane & 15;
     const int n = blockIdx.x, sl = blockIdx.y;
     const f16* qrow = q + (int64_t)n * ldq;
+    f16* s_q = reinterpret_cast<f16*>(s_o + nw * d) + wave * d;      // QL: [nw][d] halves, one row per wave
     unsigned pipe_own = 0;
     if constexpr (PIPE) pipe_own = jb_pipe_own(pipe);
-    f16x8 qf[ND32];
+    f16x8 qf[QL ? 1 : ND32];
     if constexpr (!PIPE) {
+        if constexpr (QL) {
+            if (lane * 8 < d) *reinterpret_cast<f16x8*>(s_q + lane * 8) = ld_frag<f16>(qrow + lane * 8);
+        } else {
 #pragma unroll
-        for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+            for (int dt = 0; dt < ND32; ++dt) qf[dt] = ld_frag<f16>(qrow + dt * 32 + g * 8);
+        }
     }
     // epilogue operands of this thread's output channel (blockDim.x >= d): requested with the query, used at the end
     const int och = sl * d + min((int)threadIdx.x, d - 1);
@@ -362,7 +372,10 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     auto tile_math = [&](const f16x8 (&kf)[ND32], const f16x8 (&vv)[16], int kbase_i) {
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dt = 0; dt < ND32; ++dt) sc = jb_mfma(kf[dt], qf[dt], sc);
+        for (int dt = 0; dt < ND32; ++dt) {
+            if constexpr (QL) sc = jb_mfma(kf[dt], *reinterpret_cast<const f16x8*>(s_q + dt * 32 + g * 8), sc);
+            else sc = jb_mfma(kf[dt], qf[dt], sc);
+        }
         float pv[4], mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -418,8 +431,12 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
         }
         jb_issue_fence();
         jb_pipe_wait(pipe, pipe_own);
+        if constexpr (QL) {
+            if (lane * 8 < d) *reinterpret_cast<f16x8*>(s_q + lane * 8) = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + lane * 8);
+        } else {
 #pragma unroll
-        for (int dt = 0; dt < ND32; ++dt) qf[dt] = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + dt * 32 + g * 8);
+            for (int dt = 0; dt < ND32; ++dt) qf[dt] = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + dt * 32 + g * 8);
+        }
         if (ks.count == 0) {      // zero rows -> attention output 0 -> c_proj gives its bias
             if (threadIdx.x < d) jb_st_sc1(out, (int64_t)n * ldo + och, (f16)jb_round<f16>((float)res_e + jb_round<f16>(jb_round<f16>(bias_e))));
             jb_pipe_publish(pipe, pipe_own);
@@ -437,7 +454,8 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
 #pragma unroll
                 for (int k = 0; k < 16; ++k) vv[k] = (kbase_i + k >= ks.count - 1) ? fv : vv[k];
             }
-            jb_issue_fence_before_use(qf[0]);
+            if constexpr (QL) jb_issue_fence_before_use(kf[0]);
+            else jb_issue_fence_before_use(qf[0]);
             tile_math(kf, vv, kbase_i);
         }
     } else {
@@ -458,7 +476,8 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
                 const int64_t vpos = ks.start + min(kbase_i + k, ks.count - 1) * ks.stride;
                 vv[k] = ld_frag<f16>(vbase + vpos * W + c0);
             }
-            jb_issue_fence_before_use(qf[0]);
+            if constexpr (QL) jb_issue_fence_before_use(kf[0]);
+            else jb_issue_fence_before_use(qf[0]);
             tile_math(kf, vv, kbase_i);
         }
     }
@@ -695,6 +714,12 @@ extern "C" int jb_attn_decode_wide(int attn_func, const void* q, int64_t ldq, co
                                     width, block_ctx, t_dev, max_len, nullptr, stream);
 }
 
+// 480-channel heads (the 1b upsamplers): the lean form of the kernel (query through LDS, <= 168 registers per lane: shares a
+// compute unit with a waiting projection workgroup of a pipelined chain).  jb_tune_attn_decode_wide_lean.
+static int g_wide_lean = 1;
+extern "C" void jb_tune_attn_decode_wide_lean(int on) { g_wide_lean = on ? 1 : 0; }
+int jb_attn_decode_wide_lean() { return g_wide_lean; }
+
 int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache_w, int cache_cap,
                              const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
                              int width, int block_ctx, const int* t_dev, int max_len, const JbPipe* pipe, void* stream) {
@@ -703,16 +728,29 @@ int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const vo
     JB_REQUIRE(jb_attn_decode_wide_supported(attn_func, d_head, width, block_ctx, max_len) && ldq % 8 == 0,
                "wide-value attention: self-attention pattern, d_head = 32 x {1,2,4,8,15,16}, width a multiple of d_head");
     const int nw = 8;
-    const size_t lds = (size_t)(2 * nw + 16 * nw + nw * d_head) * sizeof(float);
+    const bool lean = g_wide_lean && d_head == 480;
+    const size_t lds = (size_t)(2 * nw + 16 * nw + nw * d_head) * sizeof(float) + (lean ? (size_t)nw * d_head * sizeof(f16) : 0);
     dim3 grid(n_batch, width / d_head);
     hipStream_t s = (hipStream_t)stream;
     const JbPipe nopipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr};
     if (pipe) {
         JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30),
                    "a pipelined launch of the wide-value attention takes d_head = 480 and caches below 2 GiB");
-        attn_decode_wide_kernel<15, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
-                                                                   (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, bias,
-                                                                   (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe);
+        if (lean)
+            attn_decode_wide_kernel<15, true, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+                                                                             (const f16*)vcache_w, cache_cap, (const f16*)res, ldr,
+                                                                             bias, (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe);
+        else
+            attn_decode_wide_kernel<15, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+                                                                       (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, bias,
+                                                                       (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe);
+        JB_CHECK_LAUNCH();
+        return JB_OK;
+    }
+    if (lean) {
+        attn_decode_wide_kernel<15, false, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+                                                                          (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, bias,
+                                                                          (f16*)x_out, ldo, width, block_ctx, t_dev, nopipe);
         JB_CHECK_LAUNCH();
         return JB_OK;
     }

@@ -287,6 +287,7 @@ int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream);
 int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache_w, int cache_cap,
                              const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
                              int width, int block_ctx, const int* t_dev, int max_len, const JbPipe* pipe, void* stream);
+int jb_attn_decode_wide_lean();        // jb_tune_attn_decode_wide_lean's state (engine.hip: how many engines may be pipelined)
 int jb_sample_step_impl(const float* logits, int n_batch, int bins, const jb_sample_params* params, int64_t* tokens,
                         int64_t tok_stride, int* t_dev, float* preds, int64_t preds_n_stride, int x_dtype, void* x_next,
                         const float* x_emb, const float* pos_emb, const float* x_cond, int64_t xc_n_stride, int64_t xc_t_stride,

@@ -14,9 +14,22 @@
 
 #include "common.h"
 
-// the ONE engine of the process that may run pipelined launches (jb_engine_pipeline)
+// the engines of the process that may run pipelined launches (jb_engine_pipeline): at most JB_MAX_PIPE_OWNERS at a time
 static std::mutex g_pipe_mutex;
-static void* g_pipe_owner = nullptr;
+constexpr int JB_MAX_PIPE_OWNERS = 2;
+static void* g_pipe_owners[JB_MAX_PIPE_OWNERS] = {nullptr, nullptr};
+static bool pipe_owner(const void* e) {               // caller holds g_pipe_mutex
+    for (void* o : g_pipe_owners) if (o == e) return true;
+    return false;
+}
+static bool pipe_own(void* e) {                       // caller holds g_pipe_mutex
+    if (pipe_owner(e)) return true;
+    for (void*& o : g_pipe_owners) if (!o) { o = e; return true; }
+    return false;
+}
+static void pipe_disown(const void* e) {              // caller holds g_pipe_mutex
+    for (void*& o : g_pipe_owners) if (o == e) o = nullptr;
+}
 
 struct JbEngine {
     jb_engine_cfg cfg;
@@ -88,20 +101,32 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
     return JB_OK;
 }
 
+// The pair of streams of the pipelined launches and its two parity graphs go: a pair that merely EXISTS -- two more hardware
+// queues in the process -- slows every plain launch chain that runs next to it (profiles/r04_pipe_in_job.log; BENCH_r04: the
+// upper levels of every job after a process's first ran 3.8x / 1.8x slower), so nothing of it may outlive the phase that
+// uses it.  The pair is idle whenever no jb_engine_decode is in progress (a pipelined decode is host-synchronous).
+static void release_pipeline(JbEngine* e) {
+    for (int k = 0; k < 2; ++k) {
+        if (e->pstream[k]) (void)hipStreamSynchronize(e->pstream[k]);
+        if (e->pexec[k]) (void)hipGraphExecDestroy(e->pexec[k]);
+        if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
+        e->pexec[k] = nullptr; e->pgraph[k] = nullptr;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (e->pstream[k]) (void)hipStreamDestroy(e->pstream[k]);
+        e->pstream[k] = nullptr;
+    }
+}
+
 extern "C" int jb_engine_destroy(void* handle) {
     if (!handle) return JB_OK;
     JbEngine* e = (JbEngine*)handle;
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
-    for (int k = 0; k < 2; ++k) {
-        if (e->pexec[k]) (void)hipGraphExecDestroy(e->pexec[k]);
-        if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
-    }
-    for (int k = 0; k < 2; ++k)
-        if (e->pstream[k]) (void)hipStreamDestroy(e->pstream[k]);
+    release_pipeline(e);
     {
         std::lock_guard<std::mutex> lock(g_pipe_mutex);
-        if (g_pipe_owner == e) g_pipe_owner = nullptr;
+        pipe_disown(e);
     }
     if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
     delete e;
@@ -281,32 +306,38 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     JbEngine* e = (JbEngine*)handle;
     if (enable && !pipeline_eligible(e)) JB_UNSUPPORTED("this engine's decode step has launches without a pipelined form (needs pipe_words, "
                                                         "fp16, <= 16 samples, wide-value layers of one 480-channel head, 33..64 k-tiles)");
-    // ONE pipelined engine per process.  Its waiting launch holds up to 180 workgroup slots while it spins; the producer it
-    // waits for -- in particular the attention launch, 198 registers per lane: one workgroup per otherwise empty compute
-    // unit -- must still find room.  One waiter leaves >= 76 compute units free of waiters; the waiters of two engines can
-    // cover all 256, and then neither producer is ever placed (seen in the 3-level job: every slot timed out).
+    // At most TWO pipelined engines per process.  A waiting launch holds up to 180 workgroup slots (8 waves at 88 registers per
+    // lane: two such workgroups fill a compute unit) while it spins, and the producer it waits for must still find room.  The
+    // waiters of two engines take <= 360 of the chip's 512 such slots, so >= 152 compute units keep half of their registers
+    // free -- enough for a projection workgroup or for a LEAN wide-value attention workgroup (<= 168 registers per lane,
+    // attention.hip), which every eligible engine's attention launches are: the producers of both engines always make progress.
+    // (Round 4's one-owner rule came from the fat attention kernel, 198 registers per lane: one workgroup per otherwise EMPTY
+    // compute unit, and the waiters of two engines can leave none -- every slot timed out.)  A third engine's waiters could
+    // cover all 512 slots.
     JB_REQUIRE(enable >= 0 && enable <= 2, "enable must be 0, 1 or 2");
     std::lock_guard<std::mutex> lock(g_pipe_mutex);
     if (enable) {
-        if (g_pipe_owner && g_pipe_owner != e) JB_UNSUPPORTED("another engine of this process runs pipelined launches (one at a time: "
-                                                              "switch it off or destroy it first)");
-        g_pipe_owner = e;
-        if (enable == 2) {        // a fresh pair of streams and fresh graphs at the next decode (the engine must be idle)
-            for (int k = 0; k < 2; ++k) {
-                if (e->pexec[k]) (void)hipGraphExecDestroy(e->pexec[k]);
-                if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
-                if (e->pstream[k]) (void)hipStreamDestroy(e->pstream[k]);
-                e->pexec[k] = nullptr; e->pgraph[k] = nullptr; e->pstream[k] = nullptr;
-            }
-        }
-    } else if (g_pipe_owner == e) {
-        g_pipe_owner = nullptr;
+        if (!pipe_owner(e) && !jb_attn_decode_wide_lean() && (g_pipe_owners[0] || g_pipe_owners[1]))
+            JB_UNSUPPORTED("another engine of this process runs pipelined launches, and the fat attention kernel "
+                           "(jb_tune_attn_decode_wide_lean(0)) admits one at a time");
+        if (!pipe_own(e)) JB_UNSUPPORTED("two other engines of this process run pipelined launches (two at a time: switch one off "
+                                         "or destroy it first)");
+        if (enable == 2) release_pipeline(e);   // a fresh pair of streams and fresh graphs at the next decode
+    } else {
+        // switched off = gone: streams, hardware queues and graphs are released now and made again (milliseconds) the next
+        // time the launches are switched on
+        release_pipeline(e);
+        pipe_disown(e);
     }
     e->pipelined = enable != 0;
     return JB_OK;
 }
 
 extern "C" int jb_engine_pipelined(void* handle) { return handle && ((JbEngine*)handle)->pipelined ? 1 : 0; }
+
+// 1 while the engine holds a pair of streams for pipelined launches (made at the first pipelined decode, released by
+// jb_engine_pipeline(handle, 0)), else 0.
+extern "C" int jb_engine_pipeline_resident(void* handle) { return handle && ((JbEngine*)handle)->pstream[0] ? 1 : 0; }
 
 // Pipelined launches wait on each other ACROSS streams, and HIP multiplexes streams onto a few in-order hardware queues
 // (GPU_MAX_HW_QUEUES, 4 by default): a waiting launch that sits in the same hardware queue AHEAD of its producer -- or, with
@@ -345,7 +376,8 @@ static int streams_overlap(hipStream_t a, hipStream_t b, unsigned* scratch /* de
 // crawls: measured, the 3-level job went from 80 to 128 s when the side stream was an ordinary pooled stream).  HIP gives
 // no handle on the stream -> queue mapping, except that a stream created with a compute-unit mask gets a hardware queue
 // with that mask: two masks that differ (each all compute units but one) are two queues of their own.  The
-// pair is still verified with the handshake above.  The caller's stream only forks to and joins from them with events.
+// pair is still verified with the handshake above.  The caller's stream never waits on them: a pipelined decode drains the
+// caller's stream, runs on the pair and returns when the pair is done (decode_pipelined).
 static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mutex
     unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(jb_engine_launches_per_step(e)) - JB_PIPE_PAD + 8;
     // every pair of the process gets two masks nobody else has (each leaves out ONE compute unit): should the runtime key
@@ -433,18 +465,21 @@ extern "C" int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph
     if (n_steps == 0) return JB_OK;
     for (const jb_layer& L : e->layers) e->v_rows_stale = e->v_rows_stale || layer_wide(e->cfg, L);
     JB_TRY(enqueue_embed(e, t0, s));         // later positions are embedded by the sampler of the step before
-    if (!use_graph) {
-        if (e->pipelined && e->pexec[0]) return decode_pipelined(e, n_steps, s, false);
+    if (use_graph == 2) {        // diagnostics: the pipelined launches without the graph executor
+        JB_REQUIRE(e->pipelined, "use_graph = 2 asks for pipelined launches: switch them on first (jb_engine_pipeline)");
+        return decode_pipelined(e, n_steps, s, false);
+    }
+    if (!use_graph) {            // the eager plain chain, whatever jb_engine_pipeline says
         for (int i = 0; i < n_steps; ++i) JB_TRY(enqueue_step(e, s));
         return JB_OK;
     }
-    if (e->pipelined) {
+    if (e->pipelined && use_graph != 3) {
         const int rc = decode_pipelined(e, n_steps, s);
         if (rc != JB_ERR_UNSUPPORTED || e->pstream[0]) return rc;
         // no hardware queue of its own for the side stream: the plain chain from here on, and another engine may have them
         e->pipelined = false;
         std::lock_guard<std::mutex> lock(g_pipe_mutex);
-        if (g_pipe_owner == e) g_pipe_owner = nullptr;
+        pipe_disown(e);
     }
     if (!e->graph_exec) {
         // One eager step first, so that every kernel's dynamic-LDS attribute is configured outside of capture;

@@ -8,6 +8,8 @@
 // once (cdna_hip_programming.md "GEMV / M <= 16 decode weights").  The MFMA computes
 // D[j][m] = sum_k W[k][j] * X[m][k], i.e. the output tile transposed: lane l holds row m = l&15 and
 // the four consecutive columns j = (l>>4)*4 + r, which it stores as one 8/16-byte vector.
+#include <mutex>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -226,6 +228,8 @@ struct GemmParams {
     int pre_relu, vec_a;
     int cache_t0;
     int64_t m_total;
+    unsigned* overflow;                  // gemm_split_kernel: the process's host-coherent "activation outside the half range" word
+    float w_unscale;                     // gemm_split_kernel: 1 / (the power of two the weights were multiplied by when packed)
     EpiParams epi;
 };
 
@@ -351,9 +355,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 // Two workgroups per compute unit hide the operand latency; a second register set with the next k-step's operands in
 // flight (one workgroup per compute unit) measured slower: 122 against 77 ms for the upsampler's conditioner at 16 samples,
 // exact-fp32 kernel 133 ms (profiles/r04_bench_conditioner.log).
-// Set (sticky) by gemm_split_kernel when an activation it was given does not fit a half: the hi part would be +-inf and the result
-// garbage.  Read and cleared by jb_gemm_split_overflow; the sampler asks once per job, the tests after every case.
-__device__ unsigned g_split_overflow = 0u;
+// Set (sticky) by gemm_split_kernel when an activation it was given does not fit a half (the hi part would be +-inf and the
+// result garbage) or is a NaN.  The word lives in host-coherent memory (split_overflow_word): a launch that sees such a value
+// stores 1 through the fabric, and jb_gemm_split_overflow reads it from the host without touching any queue -- the sampler
+// looks after every window (a check that waited for the device would stall the other levels' streams), the tests after every case.
+static unsigned* split_overflow_word() {
+    static unsigned* word = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        unsigned* w = nullptr;
+        if (hipHostMalloc((void**)&w, 64, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) == hipSuccess && w) {
+            *w = 0u;
+            word = w;
+        }
+    });
+    return word;
+}
 
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -383,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
     bool too_big = false;                                       // an activation outside the half range was seen (g_split_overflow)
     const int64_t lo_image = (int64_t)p.njt * p.nkt * 512;      // f16 elements from a tap's hi image to its lo image
     const float relu_floor = p.pre_relu ? 0.f : -INFINITY;      // the input ReLU as a branch-free max
+    const float neg_limit = p.pre_relu ? -INFINITY : -65504.0f;
     int64_t woff[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) woff[jt] = ((int64_t)min(jt_base + jt, p.njt - 1) * p.nkt) * 512 + (int64_t)lane * 8;
@@ -417,8 +435,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float x = ar[mt][e >> 2][e & 3];
+                    // judged on the value as loaded: fmaxf(NaN, 0) is 0, so a NaN under the input ReLU would pass unseen
+                    // (torch's relu propagates it); what the ReLU clips anyway (x < 0) cannot overflow
+                    too_big = too_big || (aval[mt] && !(x <= 65504.0f && x >= neg_limit));
                     x = aval[mt] ? fmaxf(x, relu_floor) : 0.f;
-                    too_big = too_big || !(fabsf(x) <= 65504.0f);       // (a NaN input is reported too)
                     const f16 h = (f16)x;
                     ah[mt][e] = h;
                     al[mt][e] = (f16)((x - (float)h) * 2048.0f);
@@ -440,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
         }
     }
 
-    if (__any((int)too_big) && lane == 0) atomicOr(&g_split_overflow, 1u);
+    if (__any((int)too_big) && lane == 0) __hip_atomic_store(p.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         if (!mvalid[mt]) continue;
@@ -448,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
             int jb = (jt_base + jt) * 16 + g * 4;
-            if (jb < p.epi.J) epilogue_store<float>(p.epi, acc[jt][mt] + acc2[jt][mt] * (1.0f / 2048.0f), orow, jb, -1);
+            if (jb < p.epi.J) epilogue_store<float>(p.epi, (acc[jt][mt] + acc2[jt][mt] * (1.0f / 2048.0f)) * p.w_unscale, orow, jb, -1);
         }
     }
 }
@@ -657,18 +677,13 @@ extern "C" void jb_tune_gemm_lds(int min_rows) { g_gemm_lds_min_rows = min_rows;
 static inline bool aligned_to(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
 extern "C" int jb_gemm_split_overflow(int reset) {
-    unsigned v = 0u;
-    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_overflow), sizeof v, 0, hipMemcpyDeviceToHost) != hipSuccess) {
-        jb_set_error("jb_gemm_split_overflow: cannot read the device flag");
+    unsigned* w = split_overflow_word();
+    if (!w) {
+        jb_set_error("jb_gemm_split_overflow: no host-coherent memory for the flag");
         return JB_ERR_HIP;
     }
-    if (reset && v) {
-        const unsigned zero = 0u;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_overflow), &zero, sizeof zero, 0, hipMemcpyHostToDevice) != hipSuccess) {
-            jb_set_error("jb_gemm_split_overflow: cannot clear the device flag");
-            return JB_ERR_HIP;
-        }
-    }
+    const unsigned v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+    if (reset && v) __atomic_store_n(w, 0u, __ATOMIC_RELEASE);
     return v ? 1 : 0;
 }
 
@@ -707,7 +722,11 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     const int KT = a->dtype == JB_F16 ? 32 : 16;
     const bool fast = p.vec_a && (a->K % KT == 0);
     hipStream_t st = (hipStream_t)stream;
+    p.overflow = nullptr;
+    p.w_unscale = a->w_split_unscale != 0.f ? a->w_split_unscale : 1.0f;
     if (a->w_split) {
+        p.overflow = split_overflow_word();
+        JB_REQUIRE(p.overflow, "no host-coherent memory for the f16-split overflow flag");
         gemm_split_kernel<<<grid, 256, 0, st>>>(p);
         JB_CHECK_LAUNCH();
         return JB_OK;

@@ -304,8 +304,9 @@ class PriorEngine:
 
     def set_pipelined(self, on, fresh=False):
         """Switch software-pipelined launches of the decode step on / off; returns whether they are on (they stay off for
-        shapes without pipelined kernels, while another engine has them, and under JB_PIPELINE_LAUNCHES=0).  `fresh`: drop
-        the engine's pair of streams and its captured graphs, the next decode makes new ones (diagnostics)."""
+        shapes without pipelined kernels, while another engine has them, and under JB_PIPELINE_LAUNCHES=0).  Switching them
+        off RELEASES the engine's pair of streams and its two graphs (an idle pair slows the plain chains of every other
+        engine of the process); the next pipelined decode makes new ones.  `fresh`: the same release while staying on."""
         if on and os.environ.get("JB_PIPELINE_LAUNCHES", "") == "0":
             return False
         if self.handle is None:
@@ -318,6 +319,11 @@ class PriorEngine:
         L.check(rc)
         self.pipelined = bool(on)
         return self.pipelined
+
+    @property
+    def pipeline_resident(self):
+        """Whether the engine holds a pair of streams for pipelined launches (first pipelined decode .. set_pipelined(False))."""
+        return bool(self.handle) and L.lib().jb_engine_pipeline_resident(self.handle) == 1
 
     def pipe_stamps(self):
         """JB_PIPE_DEBUG=1: (n_slots, 4) int64 ticks of the 100 MHz clock of the last pipelined step: poll entered, producer
@@ -356,8 +362,11 @@ class PriorEngine:
     def prefill(self, t0, n_t):
         L.check(L.lib().jb_engine_prefill(self.handle, t0, n_t, L.stream()))
 
-    def decode(self, t0, n_steps, use_graph=True):
-        L.check(L.lib().jb_engine_decode(self.handle, t0, n_steps, int(use_graph), L.stream()))
+    def decode(self, t0, n_steps, use_graph=True, plain=False):
+        """use_graph: True / 1 = graph replay (pipelined launches while they are on), False / 0 = the eager plain chain, 2 =
+        the pipelined launches without the graph executor (diagnostics); plain: the plain chain's graph even while pipelined
+        launches are on (the pair of streams stays)."""
+        L.check(L.lib().jb_engine_decode(self.handle, t0, n_steps, 3 if plain else int(use_graph), L.stream()))
         if self.pipelined and not L.lib().jb_engine_pipelined(self.handle):
             # the library keeps the plain chain when the pair of streams cannot have hardware queues of its own: say why, once
             self.pipelined = False
@@ -365,12 +374,12 @@ class PriorEngine:
             print("jukebox_amd: pipelined launches fell back to the plain chain:", L.lib().jb_last_error().decode(errors="replace"),
                   file=sys.stderr, flush=True)
 
-    def timed_decode(self, t0, n_steps):
+    def timed_decode(self, t0, n_steps, plain=False):
         """decode + wait: seconds per step as the host sees them (the in-situ comparison of the two launch forms)."""
         import time
         torch.cuda.current_stream(self.device).synchronize()
         t = time.perf_counter()
-        self.decode(t0, n_steps)
+        self.decode(t0, n_steps, plain=plain)
         torch.cuda.current_stream(self.device).synchronize()
         return (time.perf_counter() - t) / max(n_steps, 1)
 

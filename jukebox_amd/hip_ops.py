@@ -4,6 +4,7 @@ torch supplies device memory and the current HIP stream only; every computation 
 in libjukebox_hip.so.  Tensors must live on the GPU and be contiguous; there is no CPU path.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -20,10 +21,11 @@ class PackedWeight:
     """A K x J matrix in MFMA fragment order (see csrc/gemm.hip) plus its logical dims.
     `taps` > 1 holds the per-tap matrices of a (transposed) convolution back to back."""
 
-    def __init__(self, data, K, J, dtype, taps=1, split=False):
+    def __init__(self, data, K, J, dtype, taps=1, split=False, unscale=1.0):
         self.data, self.K, self.J, self.dtype, self.taps = data, K, J, dtype, taps
         self.tap_stride = data.numel() // taps
         self.split = split              # fp32 matrix as hi / lo f16 images (jb_gemm_args.w_split); `data` holds the raw words
+        self.unscale = unscale          # split images hold s * W for a power of two s: 1 / s (jb_gemm_args.w_split_unscale)
 
     @property
     def ptr(self):
@@ -79,9 +81,17 @@ def pack_conv_taps(w, dtype, transposed=False, split=False):
     matrix per tap.  split (fp32 only, Cin a multiple of 32): every tap as the hi / lo pair of f16 images that lets the
     fp32 conv stacks run on the f16 matrix cores at fp32 accuracy (jb_gemm_args.w_split) -- the same bytes per tap."""
     w = w.contiguous()
+    unscale = 1.0
     if split:
         assert dtype == torch.float32 and w.shape[0 if transposed else 1] % 32 == 0
-        assert float(w.abs().max()) <= 65504.0, "f16-split weight image: |w| must fit a half"     # (once per layer, at pack time)
+        # (once per layer, at pack time) the image holds s * w with the power of two s that puts max |w| into [128, 256): every
+        # weight down to 2^-22 of the largest keeps a NORMAL hi half, i.e. 2^-22 relative precision after the split, whatever the
+        # layer's scale -- unscaled, a trained layer with |w| < 6e-5 would have subnormal hi halves (exact: powers of two)
+        amax = float(w.abs().max())
+        assert math.isfinite(amax), "f16-split weight image: weights must be finite"
+        if amax > 0.0:
+            scale = 2.0 ** (8 - math.frexp(amax)[1])
+            w, unscale = (w.float() * scale).contiguous(), 1.0 / scale
     if transposed:
         Cin, Cout, k = w.shape
         sk, sj = Cout * k, k
@@ -98,7 +108,7 @@ def pack_conv_taps(w, dtype, transposed=False, split=False):
                                            dst.data_ptr(), code, L.stream()))
         else:
             pack_weight(w, Cin, Cout, sk, sj, dtype, out=dst, offset_elems=tap)
-    return PackedWeight(out, Cin, Cout, dtype, taps=k, split=split)
+    return PackedWeight(out, Cin, Cout, dtype, taps=k, split=split, unscale=unscale)
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
@@ -141,14 +151,19 @@ def gemm(A, pw, bias=None, out=None, res=None, n_seq=1, t_in=None, t_out=None, s
     a.out_stride, a.out_offset = out_stride, out_offset
     a.pre_relu, a.act, a.res_scale = int(pre_relu), act, res_scale
     a.w_split = int(pw.split)
+    a.w_split_unscale = float(pw.unscale)
     L.check(L.lib().jb_gemm(C.byref(a), L.stream()))
     return out
 
 
-def check_split_overflow():
+def check_split_overflow(wait=True):
     """Raise if a conv-stack launch on the f16-split path (jb_gemm_args.w_split) has seen an activation outside the half range
-    since the last check: its output is not the convolution.  Waits for the device (called once per job / per test)."""
-    torch.cuda.synchronize()                 # the flag is read on the null stream, which does not wait for torch's streams
+    (or a NaN) since the last check: its output is not the convolution.  The flag is a host-coherent word, so reading it costs
+    nothing and waits for nothing: wait=True synchronises the device first (end of a job, tests: the launches just enqueued
+    count), wait=False looks at what has FINISHED so far -- the sampler's look after every window, which must not stall the
+    other levels' streams (a window's conv stacks ran seconds before its last token)."""
+    if wait:
+        torch.cuda.synchronize()
     rc = L.lib().jb_gemm_split_overflow(1)
     if rc < 0:
         L.check(rc)
@@ -182,7 +197,7 @@ def tap_view(pw, taps):
     step = taps[1] - taps[0] if len(taps) > 1 else 1
     assert all(taps[i] == taps[0] + i * step for i in range(len(taps)))
     base = pw.data[taps[0] * pw.tap_stride:]
-    v = PackedWeight(base, pw.K, pw.J, pw.dtype, taps=1, split=pw.split)
+    v = PackedWeight(base, pw.K, pw.J, pw.dtype, taps=1, split=pw.split, unscale=pw.unscale)
     v.tap_stride = pw.tap_stride * step
     v.taps = len(taps)
     return v

@@ -146,17 +146,46 @@ class ConditionalAutoregressive2D(nn.Module):
                 t.cuda.synchronize(self.x_emb.weight.device)     # its graphs and buffers may still be in flight (rare path)
             eng.close()
 
+    @property
+    def pipeline_candidate(self):
+        """Whether this model's engines can run software-pipelined launches, from the geometry alone (the library decides for
+        an engine: jb_engine_pipeline's eligibility rule -- fp16, <= 16 samples, one 480-channel head on lean wide-value
+        attention, width and MLP of 33..64 k-tiles, key sets of <= 128 keys: the 1b upsamplers)."""
+        S, M = int(self.m_attn * self.width), int(self.m_mlp * self.width)
+        bc = self.input_dims // self.blocks if self.blocks else 0
+        return (self.heads == 1 and S == 480 and not self.only_encode and self.attn_order == 2 and 0 < bc <= 128
+                and self.blocks <= 128 and self.width % 32 == 0 and M % 32 == 0 and 33 <= self.width // 32 <= 64
+                and 33 <= M // 32 <= 64)
+
     def _apply_pipeline(self, eng):
         """Software-pipelined launches as the sampler asks for them: `pipeline_launches` is None (leave the engine alone), a
-        bool, or a callable that is asked again before every decode call (the level pipeline: only while the level runs
-        alone).  A verdict of the in-situ comparison (`_decode`) against them is final for the engine."""
+        bool, or a callable that is asked again before every decode call and answers with a falsy value (not now) or with a
+        REGIME -- any truthy, comparable token that names the conditions the launches would run under (the level pipeline:
+        how many pipelined engines share the GPU).  The verdict of the in-situ comparison (`_decode`) against them stands
+        within the regime it was measured in; a new regime is measured afresh."""
         want = getattr(self, "pipeline_launches", None)
         if callable(want):
             want = want()
+        if want and getattr(eng, "_pipe_regime", None) != want:
+            eng._pipe_regime = want
+            if not getattr(eng, "_pipe_timed_out", False):
+                eng._pipe_verdict = None
         if want and getattr(eng, "_pipe_verdict", None) is False:
             want = False
         if want is not None and eng.pipelined != bool(want):
             eng.set_pipelined(bool(want))
+
+    def release_pipeline(self):
+        """End of the phase in which this prior's engines may run pipelined launches (its level has finished, a job starts or
+        ends): every engine goes back to the plain chain and RELEASES its pair of streams and graphs -- a pair that merely
+        exists slows the other levels' plain chains (BENCH_r04: levels 2 / 1 ran 3.8x / 1.8x slower in every job after a
+        process's first), and the reference's loop leaves nothing behind either (jukebox/sample.py:90-121).  The in-situ
+        verdict belongs to the pair it was measured on and goes with it; an engine on which a wait once TIMED OUT keeps the
+        plain chain for good."""
+        for eng in list(self._engines.values()):
+            eng.set_pipelined(False)
+            if not getattr(eng, "_pipe_timed_out", False):
+                eng._pipe_verdict = None
 
     # steps between two looks at `pipeline_launches` while a window is decoded on the plain chain (_decode_window)
     PIPE_RECHECK_STEPS = 512
@@ -169,11 +198,13 @@ class ConditionalAutoregressive2D(nn.Module):
         1.56 ms in the 20-second job) need not wait for the window's end.  Same tokens in every form."""
         want = getattr(self, "pipeline_launches", None)
         pos, end = t0, t0 + n_steps
-        if callable(want) and not eng.pipelined and getattr(eng, "_pipe_verdict", None) is not False:
-            while end - pos >= 2 * self.PIPE_RECHECK_STEPS and not want():
+        if callable(want):
+            while True:
+                self._apply_pipeline(eng)          # (a new regime -- a level finished -- re-opens a verdict against them)
+                if eng.pipelined or end - pos < 2 * self.PIPE_RECHECK_STEPS:
+                    break
                 eng.timed_decode(pos, self.PIPE_RECHECK_STEPS)
                 pos += self.PIPE_RECHECK_STEPS
-            self._apply_pipeline(eng)
         self._decode(eng, pos, end - pos)
 
     def _decode(self, eng, t0, n_steps):
@@ -181,30 +212,40 @@ class ConditionalAutoregressive2D(nn.Module):
         process has measured them at 1.6 ms per step (the pair of streams made early) and at 3.0 ms + 0.18 s per call (made
         late, a waiting packet in a neighbouring hardware queue: DESIGN.md section 4.2), against 1.87 ms for the plain chain.
         Both forms produce the same tokens bit for bit, so the window's first steps are the measurement: 384 pipelined steps,
-        128 plain ones, and the engine keeps pipelined launches only if they were >= 3 % faster -- once more on a fresh pair of
-        streams before giving them up.  The verdict holds for the engine's lifetime (`pipeline_report` keeps the numbers)."""
-        if not eng.pipelined or getattr(eng, "_pipe_verdict", None) is not None or n_steps < 1024:
+        128 plain ones (after 16 untimed ones: the plain graph may not exist yet, and its capture is not the chain's speed;
+        112 / 64 after 8 in a call of 256..1023 steps), and the engine keeps pipelined launches only if they were >= 3 %
+        faster -- once more on a fresh pair of streams, where the call is long enough, before giving them up.  The verdict holds for as long as the pair lives (`release_pipeline`; `pipeline_report` keeps
+        the numbers)."""
+        if not eng.pipelined or getattr(eng, "_pipe_verdict", None) is not None or n_steps < 256:
             eng.decode(t0, n_steps)
             return
-        report = dict(pipelined_ms=[], plain_ms=None, kept=False)
+        # steps: untimed warm-up, timed pipelined, untimed plain warm-up, timed plain -- the short form fits one published
+        # chunk of a tapped window (256 steps: the level pipeline's upper levels)
+        warm, n_pipe, n_plain = (16, 384, 128) if n_steps >= 1024 else (8, 112, 64)
+        report = dict(pipelined_ms=[], plain_ms=None, kept=False, regime=getattr(eng, "_pipe_regime", None))
         pos, end = t0, t0 + n_steps
         for attempt in range(2):
-            eng.decode(pos, 16)                # the pair of streams and its graphs are made here, outside the timed steps
-            pos += 16
+            if end - pos < warm + n_pipe + (0 if report["plain_ms"] is not None else warm + n_plain):
+                break
+            eng.decode(pos, warm)              # the pair of streams and its graphs are made here, outside the timed steps
+            pos += warm
             if eng.pipe_error():
                 return                         # a wait timed out: the caller decodes the window again on the plain chain
             if not eng.pipelined:
                 break
-            report["pipelined_ms"].append(round(eng.timed_decode(pos, 384) * 1e3, 4))
-            pos += 384
+            report["pipelined_ms"].append(round(eng.timed_decode(pos, n_pipe) * 1e3, 4))
+            pos += n_pipe
             if eng.pipe_error():
                 return
             if not eng.pipelined:
                 break
             if report["plain_ms"] is None:
-                eng.set_pipelined(False)
-                report["plain_ms"] = round(eng.timed_decode(pos, 128) * 1e3, 4)
-                pos += 128
+                # the plain chain's graph, with the pair kept (switching off would release the very pair that was measured);
+                # untimed steps first: an engine that was pipelined from its creation captures that graph here
+                eng.decode(pos, warm, plain=True)
+                pos += warm
+                report["plain_ms"] = round(eng.timed_decode(pos, n_plain, plain=True) * 1e3, 4)
+                pos += n_plain
             if report["pipelined_ms"][-1] < 0.97 * report["plain_ms"]:
                 report["kept"] = True
                 break
@@ -213,7 +254,17 @@ class ConditionalAutoregressive2D(nn.Module):
         eng._pipe_verdict = report["kept"]
         eng.set_pipelined(report["kept"])
         self.pipeline_report = report
-        eng.decode(pos, end - pos)
+        self.pipeline_reports = (getattr(self, "pipeline_reports", None) or [])[-15:] + [report]
+        if end > pos:
+            eng.decode(pos, end - pos)
+
+    def _pipe_give_up(self, eng):
+        """A pipelined wait timed out on this engine: forget the error, release the pair, plain chain for the engine's lifetime."""
+        eng.clear_pipe_error()
+        eng.set_pipelined(False)
+        eng._pipe_verdict = False
+        eng._pipe_timed_out = True
+        self.pipeline_report = dict(getattr(self, "pipeline_report", None) or {}, kept=False, timed_out=True)
 
     def packed(self, fp16):
         """This prior's weights in MFMA order for one engine dtype (built on first use, dropped when the module moves)."""
@@ -324,10 +375,7 @@ class ConditionalAutoregressive2D(nn.Module):
                 import sys
                 print(f"jukebox_amd: pipelined decode: launch slot {eng.pipe_error() - 1} timed out waiting for its producer; "
                       "decoding the window again on the plain launch chain", file=sys.stderr, flush=True)
-                eng.clear_pipe_error()
-                eng.set_pipelined(False)
-                eng._pipe_verdict = False
-                self.pipeline_report = dict(getattr(self, "pipeline_report", None) or {}, kept=False, timed_out=True)
+                self._pipe_give_up(eng)
                 eng.decode(n_prime, sample_tokens - n_prime)
         else:
             # (every, fn): hand the token buffer to fn after every `every` enqueued decode steps, so that a consumer on
@@ -338,6 +386,11 @@ class ConditionalAutoregressive2D(nn.Module):
                 n = min(int(every), sample_tokens - pos)
                 self._apply_pipeline(eng)
                 self._decode(eng, pos, n)
+                if eng.pipelined and eng.pipe_error():       # (a pipelined decode is host-synchronous: the read costs no wait)
+                    # before anybody is handed the chunk: what the failed steps wrote is void, the same chunk is decoded
+                    # again on the plain chain (same tokens as if nothing had happened)
+                    self._pipe_give_up(eng)
+                    eng.decode(pos, n)
                 fn(eng.tokens, pos, pos + n)
                 pos += n
         x = eng.tokens[:, :sample_tokens].clone()

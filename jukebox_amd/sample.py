@@ -64,6 +64,11 @@ def sample_single_window(zs, labels, sampling_kwargs, level, prior, start, hps):
     z = t.cat(z_samples, dim=0)
     z_new = z[:, -new_tokens:]
     zs[level] = t.cat([zs[level], z_new], dim=1)
+    if z.is_cuda:
+        # the window's conditioner ran on the f16-split conv kernels: fail here, not a job later, if it was handed activations
+        # outside the half range (a host-coherent flag: no wait, no queue touched)
+        from . import hip_ops
+        hip_ops.check_split_overflow(wait=False)
     return zs
 
 
@@ -221,28 +226,42 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 errors.append(e)
                 cond.notify_all()
 
-    # Software-pipelined launches for the lowest level (the long pole) ONLY WHILE IT RUNS ALONE.  Its waiting launches keep
-    # most compute units occupied for good; a concurrent level's attention launch (216 registers per lane: an otherwise
-    # empty compute unit per workgroup) then hardly ever finds room -- measured on the 6-second job: 80 s plain, 176 s with
-    # level 0 pipelined from the start (level 1 at 1700 instead of 6300 tokens/s).  The engine is asked before every window;
-    # its pair of streams is made when the launches are switched on, not earlier: two more hardware queues in the process
-    # -- even idle ones -- slowed the concurrent levels' plain chains 2.5x (profiles/r04_pipe_in_job.log: first level-0 window
-    # 47.8 s instead of 18.7 s).  The first pipelined window compares the two launch forms in situ and keeps the faster
-    # (ConditionalAutoregressive2D._decode).
-    if _want_pipelined_launches(hps) and getattr(priors[lowest], "prior", None) is not None:
-        priors[lowest].prior.pipeline_launches = lambda: all(l in finished for l in sample_levels if l != lowest)
+    # Software-pipelined launches for the (at most two) lowest levels whose engines can have them -- the 1b upsamplers, the
+    # long poles of the job -- from the moment every OTHER level has finished.  A pipelined engine's waiting launches keep
+    # compute units half occupied for good; the levels next to it must fit beside them: the upsamplers' own launches do (the
+    # lean wide-value attention, <= 168 registers per lane: attention.hip), the top prior's 16-wave kernels do not -- measured
+    # in round 3 on the 6-second job: 80 s plain, 176 s with level 0 pipelined next to the top level's plain chain.  The
+    # sampler's answer is the REGIME the launches would run in: 2 = another pipelined level runs beside this one, 1 = alone
+    # (round 4 ran only the alone regime: 31 % of the job had levels 1 and 0 side by side on plain chains at 2.28 instead of
+    # 1.56 ms per step).  The engine is asked before every window (and every 512 steps of a window on the plain chain); its
+    # pair of streams is made when the launches are switched on and released when they go off or the job ends: two more
+    # hardware queues in the process -- even idle ones -- slowed the concurrent levels' plain chains 2.5x
+    # (profiles/r04_pipe_in_job.log).  The first pipelined window of a regime compares the two launch forms in situ and
+    # keeps the faster (ConditionalAutoregressive2D._decode).
+    if _want_pipelined_launches(hps):
+        cands = [l for l in sorted(sample_levels)
+                 if getattr(getattr(priors[l], "prior", None), "pipeline_candidate", False)][:int(hps.get("pipeline_max_engines", 2))]
+        others = [l for l in sample_levels if l not in cands]
+        for l in cands:
+            priors[l].prior.pipeline_launches = (
+                lambda l=l: (1 + sum(1 for m in cands if m != l and m not in finished)) if all(m in finished for m in others) else 0)
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
     # (level, window start, seconds into the job at which the window's sampling began / ended) per window: diagnostics
     timeline, t_job = [], time.perf_counter()
     _sample_levels_pipelined.timeline = timeline
     threads = [threading.Thread(target=worker, args=(l,), name=f"level{l}") for l in levels]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    if on_gpu:
-        t.cuda.synchronize(device)
+    try:
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if on_gpu:
+            t.cuda.synchronize(device)
+    finally:
+        # nothing of the pipelined launches outlives the job: the next job's upper levels run plain chains again, and an idle
+        # pair of streams in the process slows those (the reference's loop is re-entrant too: jukebox/sample.py:90-121)
+        _release_pipelines(priors, sample_levels)
     if errors:
         raise errors[0]
     return zs_local
@@ -254,6 +273,16 @@ def torch_cuda_current_stream(device):
 
 def _shard_labels(labels, lo, hi):
     return dict(y=labels["y"][lo:hi].contiguous(), info=labels["info"][lo:hi])
+
+
+def _release_pipelines(priors, levels):
+    """Every engine of these levels back on the plain chain, its pair of streams and graphs released (release_pipeline)."""
+    for level in levels:
+        ar = getattr(priors[level], "prior", None)
+        if ar is not None:
+            ar.pipeline_launches = None
+            if callable(getattr(ar, "release_pipeline", None)):
+                ar.release_pipeline()
 
 
 def _want_pipelined_launches(hps):
@@ -289,6 +318,7 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
     # Software-pipelined launches (one engine per process at a time): the lowest level sampled has by far the most token
     # steps (x4 per level) and is the long pole of the job; when the levels run one after the other, each in its turn.
     ar = lambda p: getattr(p, "prior", None)               # the autoregressive model that owns the engine
+    _release_pipelines(priors, sample_levels)              # a job starts with no pair of streams in the process
     for level in sample_levels:
         if ar(priors[level]) is not None:
             ar(priors[level]).pipeline_launches = False if pipelined else None   # (the level pipeline sets the lowest level's)
@@ -318,8 +348,7 @@ def _sample(zs, labels, sampling_kwargs, priors, sample_levels, hps, save=True, 
             finally:
                 if ar(prior) is not None:
                     ar(prior).pipeline_launches = False        # the next level's engine may take them over
-                    for eng in list(getattr(ar(prior), "_engines", {}).values()):     # (split-batch tails included)
-                        eng.set_pipelined(False)
+                    ar(prior).release_pipeline()               # (split-batch tails included)
         if not hps.get("keep_priors_resident", False):
             prior.cpu()                          # sample.py:104: drops the engine's device copies
             empty_cache()

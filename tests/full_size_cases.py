@@ -31,6 +31,17 @@ CASES = {
                        t0=700, n_steps=48, N=3, seed=7, enc_len=512, merged_decoder=True),
 }
 
+# Whole greedy windows from the UNMODIFIED reference (tests/golden/gen_whole_window.py: CPU hours here, zero GPU minutes): the
+# two geometries that carry the 20-second job, N = 2, every token of the window
+WHOLE = {
+    # BASELINE config 4's dominant model, a whole first window: ConditionalAutoregressive2D.sample (autoregressive.py:199-249)
+    "upsampler_whole": dict(W=1920, depth=72, heads=1, attn_order=2, blocks=128, seq=8192, bins=2048, prime_len=None, y_cond=True,
+                            t0=0, N=2, seed=23),
+    # BASELINE config 3: primed_sample (autoregressive.py:251-359) over 384 lyric tokens in chunks of 32, then 6144 music tokens
+    "1b_lyrics_top_whole": dict(W=2048, depth=72, heads=2, attn_order=12, blocks=64, seq=6528, bins=2127, prime_len=384, y_cond=True,
+                                t0=384, N=2, seed=21),
+}
+
 _ORDERS = {
     2: lambda d: [1, 2, 3][d % 3],
     10: lambda d: [*[1, 2, 3, 1, 2, 3, 1, 2, 3], *[1, 2, 3, 1, 2, 3, 1, 2, 3, 6] * 7][d % 79],

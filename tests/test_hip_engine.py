@@ -5,6 +5,8 @@ Parity bars (SURVEY.md section 7 'hard parts', BASELINE.json north_star):
   * fp32 mode: logits within 2e-4 of the reference and greedy tokens identical wherever the reference's
     top-1/top-2 logit gap exceeds 1e-3 (an argmax flip inside that margin is a tie, not an error);
   * fp16 mode: logits within 3e-2 of the oracle's half-rounding emulation while the streams agree."""
+import time
+
 import numpy as np
 import pytest
 
@@ -262,6 +264,68 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N):
     assert not np.array_equal(outs["chain"][0][0][:, 200:], np.zeros_like(outs["chain"][0][0][:, 200:]))
 
 
+def test_a_released_pair_leaves_the_other_engines_plain_chains_alone(PE, monkeypatch):
+    """Second job of a process = first job (BENCH_r04: the upper levels of every job after the first ran 3.8x / 1.8x slower,
+    because the pair of streams of the lowest level's pipelined launches outlived the job).  Upsampler geometry; two engines
+    decode side by side on plain chains, each on a stream of its own (the upper levels of a job), timed (a) before any pair
+    exists, (b) after a third engine made a pair, used it and SWITCHED IT OFF -- jb_engine_pipeline(h, 0) releases streams,
+    hardware queues and graphs --, (c) once more after a second make / use / release cycle.  (b) and (c) must be within 10 %
+    of (a); what the same chains cost while an idle pair exists is printed.  The pair's life is checked through
+    jb_engine_pipeline_resident, and the plain graph runs under use_graph = 3 while the launches are switched on."""
+    monkeypatch.delenv("JB_PIPELINE_LAUNCHES", raising=False)
+    rng = np.random.default_rng(5)
+    width, depth, bins, seq, blocks, N = 1920, 12, 512, 1024, 16, 16
+    sd = to_dev(_random_sd(rng, width, depth, bins, seq, 2, scale=0.02))
+    xc = torch.from_numpy((rng.standard_normal((N, seq, width)) * 0.1).astype(np.float32))
+
+    def make():
+        e = PE(sd, "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=1, attn_order=2, blocks=blocks,
+               y_cond=False, fp16=True, chunk_cap=64)
+        e.set_cond(xc, None)
+        e.set_sampling(temp=0.98, seed=5)
+        return e
+
+    a, b, c = make(), make(), make()
+    sb, sc = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def side_by_side(n=384):
+        for e, st in ((b, sb), (c, sc)):                       # graphs captured / warm outside the timed steps
+            with torch.cuda.stream(st):
+                e.decode(0, 8)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for e, st in ((b, sb), (c, sc)):
+            with torch.cuda.stream(st):
+                e.decode(8, n)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+
+    side_by_side(64)
+    before = min(side_by_side() for _ in range(2))
+    tokens_plain = None
+    after = []
+    for cycle in range(2):
+        assert not a.pipeline_resident
+        assert a.set_pipelined(True) and not a.pipeline_resident           # the pair is made by the first pipelined decode
+        a.decode(0, 64, plain=True)                                          # use_graph = 3: the plain graph, no pair yet
+        torch.cuda.synchronize()
+        assert not a.pipeline_resident
+        if tokens_plain is None:
+            tokens_plain = a.tokens[:, :64].clone()
+        a.decode(0, 64)
+        assert a.pipelined and a.pipeline_resident and a.pipe_error() == 0
+        assert torch.equal(a.tokens[:, :64], tokens_plain), "pipelined launches of a fresh pair: same tokens"
+        idle = side_by_side()
+        assert a.set_pipelined(False) is False and not a.pipeline_resident
+        after.append(min(side_by_side() for _ in range(2)))
+    print("two plain chains side by side, ms per step: before any pair %.4f, next to an idle pair %.4f, after release %s"
+          % (before, idle, ["%.4f" % x for x in after]))
+    for x in after:
+        assert x < 1.10 * before, (before, after)
+    for e in (a, b, c):
+        e.close()
+
+
 def test_pipelined_timeout_is_recovered_on_the_plain_chain(monkeypatch):
     """ConditionalAutoregressive2D._run: when a pipelined launch gives up waiting for its producer (the engine's error word is
     set; bounded polls, no hang) the window's tokens are void -- the sampler decodes the window again on the plain launch
@@ -290,11 +354,11 @@ def test_pipelined_timeout_is_recovered_on_the_plain_chain(monkeypatch):
     injected = []
     real_decode = PriorEngine.decode
 
-    def decode(self, t0, n_steps, use_graph=True):
+    def decode(self, t0, n_steps, use_graph=True, plain=False):
         if self.pipelined and not injected:
             injected.append((t0, n_steps))
             self.pipe_words[18 * self.launches_per_step * 32] = 7          # "slot 6 timed out"
-        return real_decode(self, t0, n_steps, use_graph)
+        return real_decode(self, t0, n_steps, use_graph, plain)
 
     monkeypatch.setattr(PriorEngine, "decode", decode)
     got = model.primed_sample(N, prime, **kw).cpu()

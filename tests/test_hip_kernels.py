@@ -285,6 +285,50 @@ def test_conv_stack_ops_f16_split(H, Ci, Co, T, scale):
     print("f16-split conv stack Ci=%d scale=%g: worst error %.2e of the output scale" % (Ci, scale, worst))
 
 
+@pytest.mark.parametrize("wscale", [1e-5, 1e-3, 1.0, 3e4, 1e7])
+def test_conv_stack_f16_split_is_invariant_to_the_weights_scale(H, wscale):
+    """A trained layer's weights can sit far below a half's normal range (|w| < 6e-5: hi halves subnormal, 11 bits gone) or
+    above its largest value; the split image therefore holds s * w for the power of two s that puts max |w| into [128, 256)
+    and the kernel multiplies the accumulators by 1 / s (jb_gemm_args.w_split_unscale).  Scaling the weights by ANY factor must
+    leave the error against float64 where it is at O(1) weights (<= 2e-6 of the output scale: the fp32 accumulation's own
+    rounding), with a 2^20 spread of magnitudes inside one matrix, for the dilated k=3 form with the input ReLU and for the
+    transposed convolution through tap views."""
+    rng = np.random.default_rng(7)
+    N, Ci, Co, T = 2, 256, 72, 150
+    x = rng.standard_normal((N, Ci, T)).astype(np.float32)
+    xr = dev(np.transpose(x, (0, 2, 1)).reshape(N * T, Ci))
+    w = (rng.standard_normal((Co, Ci, 3)) / np.sqrt(3 * Ci)).astype(np.float32)
+    w[:, ::7] *= np.float32(2.0 ** -20)                                    # some input channels a million times weaker
+    w = (w * np.float32(wscale)).astype(np.float32)
+    want = np.transpose(_conv1d_f64(np.maximum(x.astype(np.float64), 0), w, np.zeros(Co, np.float32), 1, 9, 9), (0, 2, 1)).reshape(N * T, Co)
+    pw = H.pack_conv_taps(dev(w), torch.float32, split=True)
+    assert 128.0 <= np.abs(w).max() / pw.unscale < 256.0
+    got = H.gemm(xr, pw, n_seq=N, t_in=T, shifts=(-9, 0, 9), pre_relu=True).cpu().numpy().astype(np.float64)
+    e = relerr(got, want)
+    # ... and each weak channel alone: its contribution is not lost in the strong ones' rounding of the IMAGE (the split keeps
+    # 2^-22 relative precision per weight down to 2^-22 of the largest)
+    x_weak = np.zeros_like(x)
+    x_weak[:, ::7] = x[:, ::7]
+    want_w = np.transpose(_conv1d_f64(np.maximum(x_weak.astype(np.float64), 0), w, np.zeros(Co, np.float32), 1, 9, 9), (0, 2, 1)).reshape(N * T, Co)
+    got_w = H.gemm(dev(np.transpose(x_weak, (0, 2, 1)).reshape(N * T, Ci)), pw, n_seq=N, t_in=T, shifts=(-9, 0, 9),
+                   pre_relu=True).cpu().numpy().astype(np.float64)
+    e_weak = relerr(got_w, want_w)
+    wt = (rng.standard_normal((Ci, Co, 4)) / np.sqrt(2 * Ci)).astype(np.float32) * np.float32(wscale)
+    b = (rng.standard_normal(Co) * wscale).astype(np.float32)
+    want_t = _conv_transpose1d_f64(x.astype(np.float64), wt, b, 2, 1)
+    pwt = H.pack_conv_taps(dev(wt), torch.float32, transposed=True, split=True)
+    out = torch.empty((N * 2 * T, Co), dtype=torch.float32, device="cuda")
+    H.gemm(xr, H.tap_view(pwt, [1, 3]), bias=dev(b), out=out, n_seq=N, t_in=T, t_out=T, shifts=(0, -1), out_stride=2, out_offset=0,
+           out_rows_per_seq=2 * T)
+    H.gemm(xr, H.tap_view(pwt, [0, 2]), bias=dev(b), out=out, n_seq=N, t_in=T, t_out=T, shifts=(1, 0), out_stride=2, out_offset=1,
+           out_rows_per_seq=2 * T)
+    e_t = relerr(np.transpose(out.cpu().numpy().reshape(N, 2 * T, Co), (0, 2, 1)), want_t)
+    H.check_split_overflow()
+    print("f16-split conv, weights x %g: error %.2e (dilated k=3), %.2e (the 2^-20 channels alone), %.2e (transposed) of the "
+          "output scale" % (wscale, e, e_weak, e_t))
+    assert e < 2e-6 and e_weak < 2e-6 and e_t < 2e-6
+
+
 def test_gemm_split_reports_activations_outside_the_half_range(H):
     """The f16-split path cannot represent |x| > 65504: a launch that sees such an activation (or a NaN) raises the sticky device
     flag behind jb_gemm_split_overflow, hip_ops.check_split_overflow turns it into an exception and clears it; values up to the
@@ -307,8 +351,11 @@ def test_gemm_split_reports_activations_outside_the_half_range(H):
     H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1))
     with pytest.raises(L.JukeboxHipError):
         H.check_split_overflow()
-    with pytest.raises(AssertionError):                              # weights are checked when they are packed
-        H.pack_conv_taps(w * 1e7, torch.float32, split=True)
+    # weights have no range limit: the image holds s * w (s a power of two that puts max |w| into [128, 256)), checked finite
+    big = H.pack_conv_taps(w * 1e7, torch.float32, split=True)
+    assert big.unscale > 1.0 and 128.0 <= float((w * 1e7).abs().max()) / big.unscale < 256.0
+    with pytest.raises(AssertionError):
+        H.pack_conv_taps(w * float("inf"), torch.float32, split=True)
 
 
 def test_gemm_split_refuses_what_it_cannot_take(H):

@@ -450,9 +450,10 @@ def test_engine_cache_is_bounded_lru(monkeypatch):
 
 def test_in_situ_choice_between_the_launch_forms():
     """ConditionalAutoregressive2D._decode: the first window an engine runs with pipelined launches measures both forms on
-    its own steps (16 untimed + 384 timed pipelined steps, 128 plain ones) and keeps pipelined launches only when they are
-    >= 3 % faster, retrying once on a fresh pair of streams; every position of the window is decoded exactly once, in order,
-    and the verdict holds for the engine's later windows."""
+    its own steps (16 untimed + 384 timed pipelined steps, 16 untimed + 128 timed plain ones on the plain chain's graph, the
+    pair kept meanwhile) and keeps pipelined launches only when they are >= 3 % faster, retrying once on a fresh pair of
+    streams; every position of the window is decoded exactly once, in order, and the verdict holds for the engine's later
+    windows (until the pair is released)."""
     from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
 
     class FakeEngine:
@@ -464,11 +465,11 @@ def test_in_situ_choice_between_the_launch_forms():
             self.pipelined = bool(on)
             self.fresh += bool(fresh)
             return self.pipelined
-        def decode(self, t0, n):
-            self.calls.append((t0, n, self.pipelined))
-        def timed_decode(self, t0, n):
-            self.decode(t0, n)
-            return (self.rates.pop(0) if self.pipelined else 1.87) * 1e-3
+        def decode(self, t0, n, plain=False):
+            self.calls.append((t0, n, self.pipelined and not plain))
+        def timed_decode(self, t0, n, plain=False):
+            self.decode(t0, n, plain=plain)
+            return (self.rates.pop(0) if self.pipelined and not plain else 1.87) * 1e-3
 
     class Host:
         _decode = AR._decode
@@ -551,11 +552,11 @@ def test_window_switches_to_pipelined_launches_when_the_upper_levels_finish():
         def set_pipelined(self, on, fresh=False):
             self.pipelined = bool(on)
             return self.pipelined
-        def decode(self, t0, n):
-            self.calls.append((t0, n, self.pipelined))
-        def timed_decode(self, t0, n):
-            self.decode(t0, n)
-            return (1.56 if self.pipelined else 1.87) * 1e-3
+        def decode(self, t0, n, plain=False):
+            self.calls.append((t0, n, self.pipelined and not plain))
+        def timed_decode(self, t0, n, plain=False):
+            self.decode(t0, n, plain=plain)
+            return (1.56 if self.pipelined and not plain else 1.87) * 1e-3
 
     class Host:
         _decode, _decode_window, _apply_pipeline = AR._decode, AR._decode_window, AR._apply_pipeline
@@ -575,7 +576,8 @@ def test_window_switches_to_pipelined_launches_when_the_upper_levels_finish():
     h._decode_window(eng, 4096, 4096)
     covered(eng, 4096, 4096)
     assert eng.calls[:3] == [(4096, C, False), (4096 + C, C, False), (4096 + 2 * C, C, False)]
-    assert eng.calls[3] == (4096 + 3 * C, 16, True) and eng.calls[4][1:] == (384, True) and eng.calls[5][1:] == (128, False)
+    assert eng.calls[3] == (4096 + 3 * C, 16, True) and eng.calls[4][1:] == (384, True)
+    assert eng.calls[5][1:] == (16, False) and eng.calls[6][1:] == (128, False)        # the plain chain: 16 untimed steps first
     assert eng._pipe_verdict is True and eng.calls[-1][2] is True and h.pipeline_report["kept"] is True
     # they never do: plain chunks to the end, the last call takes what is left (>= one chunk), nothing is switched on
     h, eng = Host(), FakeEngine()
@@ -604,6 +606,69 @@ def test_window_switches_to_pipelined_launches_when_the_upper_levels_finish():
             h.pipeline_launches, eng.pipelined, eng._pipe_verdict = (lambda: True), True, True
         h._decode_window(eng, 0, 4096)
         assert eng.calls == [(0, 4096, setup == "on")]
+
+
+def test_a_finished_level_releases_its_pipelined_pair():
+    """Nothing of the pipelined launches outlives the phase that uses them (the reference's loop is re-entrant:
+    jukebox/sample.py:90-121): ConditionalAutoregressive2D.release_pipeline switches every engine of the prior off -- which
+    releases its pair of streams in the library -- and forgets the in-situ verdict with the pair it was measured on, except on an
+    engine where a wait once timed out; sample._release_pipelines does that for every level of a job and drops the sampler's
+    say; the level pipeline calls it when its threads have joined (also when one of them raised)."""
+    from jukebox_amd import sample as S
+    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
+
+    class FakeEngine:
+        def __init__(self, verdict, timed_out=False):
+            self.pipelined, self._pipe_verdict, self.off = True, verdict, 0
+            if timed_out:
+                self._pipe_timed_out = True
+        def set_pipelined(self, on, fresh=False):
+            self.off += not on
+            self.pipelined = bool(on)
+            return self.pipelined
+
+    class FakeAR:
+        release_pipeline = AR.release_pipeline
+        def __init__(self):
+            self._engines = {1: FakeEngine(True), 2: FakeEngine(False), 3: FakeEngine(False, timed_out=True)}
+            self.pipeline_launches = lambda: True
+
+    class FakePrior:
+        def __init__(self):
+            self.prior = FakeAR()
+
+    priors = [FakePrior(), FakePrior(), FakePrior()]
+    S._release_pipelines(priors, [0, 1])
+    for lvl in (0, 1):
+        ar = priors[lvl].prior
+        assert ar.pipeline_launches is None
+        assert [e.pipelined for e in ar._engines.values()] == [False] * 3 and all(e.off == 1 for e in ar._engines.values())
+        assert [e._pipe_verdict for e in ar._engines.values()] == [None, None, False]
+    assert callable(priors[2].prior.pipeline_launches) and all(e.pipelined for e in priors[2].prior._engines.values())
+
+    # the level pipeline: released when the job ends, and when a level's thread raises
+    import jukebox_amd.sample as SM
+    from jukebox_amd.hparams import Hyperparams
+    released = []
+    real = SM._release_pipelines
+    SM._release_pipelines = lambda pr, lv: released.append(tuple(lv))
+    try:
+        class Boom(RuntimeError):
+            pass
+
+        class P:
+            raw_to_tokens, n_ctx, x_cond, cond_downsample = 8, 64, False, 4
+            prior = None
+            def sample(self, *a, **k):
+                raise Boom("level failed")
+        hps = Hyperparams(sample_length=1024, hop_fraction=[0.5, 0.5], pipeline_chunk=0)
+        zs = [torch.zeros(2, 0, dtype=torch.long), torch.zeros(2, 0, dtype=torch.long)]
+        with pytest.raises(Exception):
+            SM._sample_levels_pipelined(zs, [dict(y=torch.zeros(2, 4), info=[{}, {}])] * 2, [dict(max_batch_size=16)] * 2, [P(), P()],
+                                        [0, 1], hps, Hyperparams(n_samples=2), 0, 2, "cpu")
+        assert released == [(0, 1)]
+    finally:
+        SM._release_pipelines = real
 
 
 def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
