@@ -708,7 +708,17 @@ def test_attn_decode_wide(H, func, d, W_, bc, T):
     for t in ts:
         q = h16(rng.standard_normal((N, 1, d)).astype(np.float32))
         t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
-        got = H.attn_decode_wide(func, dev(q[:, 0], f16), kc, vw, dev(res, f16), dev(bp), bc, t_dev, T).float().cpu().numpy()
+        got_t = H.attn_decode_wide(func, dev(q[:, 0], f16), kc, vw, dev(res, f16), dev(bp), bc, t_dev, T)
+        if d == 480:
+            # the lean form (query through LDS, <= 168 registers per lane: the default at 480 channels) and the fat form are the
+            # same arithmetic in the same order
+            L.lib().jb_tune_attn_decode_wide_lean(0)
+            try:
+                fat = H.attn_decode_wide(func, dev(q[:, 0], f16), kc, vw, dev(res, f16), dev(bp), bc, t_dev, T)
+            finally:
+                L.lib().jb_tune_attn_decode_wide_lean(1)
+            assert torch.equal(got_t, fat), (func, t, "lean and fat kernels differ")
+        got = got_t.float().cpu().numpy()
         idx = decode_key_index(func, t, bc, prime_r if func == 7 else None)
         if idx is None:
             a = np.zeros((N, W_), np.float32)

@@ -484,6 +484,8 @@ def test_in_situ_choice_between_the_launch_forms():
 
     for rates, kept, fresh in (([1.61], True, 0), ([2.95, 1.60], True, 1), ([2.95, 3.0], False, 1)):
         h, eng = Host(), FakeEngine(rates)
+        h.pipeline_launches = lambda: True
+        h._apply_pipeline(eng)                                # (the sampler's say comes first, as in _run / _decode_window)
         h._decode(eng, 4096, 4096)
         covered(eng, 4096, 4096)
         assert eng._pipe_verdict is kept and eng.pipelined is kept and eng.fresh == fresh, rates
@@ -495,13 +497,34 @@ def test_in_situ_choice_between_the_launch_forms():
         assert eng.pipelined is kept
         h._decode(eng, 4096, 4096)
         assert len(eng.calls) == n_calls + 1                  # one call, nothing measured again
+        # ... within the REGIME it was measured in: when the sampler names another one (a level finished: this engine now
+        # runs alone), the verdict -- also one against pipelined launches -- is open again and the next long call measures
+        eng.rates = [1.5]
+        h.pipeline_launches = lambda: 2
+        h._apply_pipeline(eng)
+        assert eng._pipe_verdict is None and eng.pipelined and eng._pipe_regime == 2
+        h._decode(eng, 0, 4096)
+        assert eng._pipe_verdict is True and h.pipeline_report["regime"] == 2 and h.pipeline_report["pipelined_ms"] == [1.5]
+        assert [r["regime"] for r in h.pipeline_reports] == [True, 2]
     bad = FakeEngine([1.6])
     bad.pipe_error = lambda: 19 if len(bad.calls) >= 2 else 0  # a wait times out inside the timed steps
     Host()._decode(bad, 0, 4096)
     assert bad.calls == [(0, 16, True), (16, 384, True)] and not hasattr(bad, "_pipe_verdict")   # stops: the caller redoes the window
-    short = FakeEngine([])
-    Host()._decode(short, 0, 700)                             # too short to measure on: decoded as asked
-    assert short.calls == [(0, 700, True)] and not hasattr(short, "_pipe_verdict")
+    # a call of 256..1023 steps (one published chunk of a tapped window) measures on 8 + 112 pipelined and 8 + 64 plain steps,
+    # without a second attempt where the call is too short for one
+    short = FakeEngine([1.6])
+    Host()._decode(short, 0, 256)
+    assert short.calls == [(0, 8, True), (8, 112, True), (120, 8, False), (128, 64, False), (192, 64, True)] and short._pipe_verdict is True
+    short = FakeEngine([2.9])
+    Host()._decode(short, 0, 256)
+    assert short._pipe_verdict is False and short.calls[-1] == (192, 64, False) and short.fresh == 1 and not short.pipelined
+    short = FakeEngine([2.9, 1.6])
+    Host()._decode(short, 0, 700)                             # ... and with one where it fits
+    covered(short, 0, 700)
+    assert short._pipe_verdict is True and short.fresh == 1
+    tiny = FakeEngine([])
+    Host()._decode(tiny, 0, 200)                              # too short to measure on: decoded as asked
+    assert tiny.calls == [(0, 200, True)] and not hasattr(tiny, "_pipe_verdict")
 
 
 def test_f16_split_arithmetic_keeps_fp32_accuracy():
@@ -591,21 +614,29 @@ def test_window_switches_to_pipelined_launches_when_the_upper_levels_finish():
     h._decode_window(eng, 4096, 4096)
     covered(eng, 4096, 4096)
     assert eng.calls[0] == (4096, 16, True)
-    # alone from a chunk boundary with < 1024 steps left: pipelined without a measurement, the next window measures
+    # alone from a chunk boundary with 512 steps left: the short form of the measurement (8 + 112 pipelined, 8 + 64 plain steps)
     h, eng = Host(), FakeEngine()
     h.pipeline_launches = lambda: len(eng.calls) >= 7
     h._decode_window(eng, 0, 4096)
     covered(eng, 0, 4096)
-    assert eng.calls[-1] == (7 * C, C, True) and not hasattr(eng, "_pipe_verdict")
-    # no opinion / a verdict against them / an engine that already has them: one call
-    for setup in ("none", "verdict", "on"):
+    assert eng.calls[7:] == [(7 * C, 8, True), (7 * C + 8, 112, True), (7 * C + 120, 8, False), (7 * C + 128, 64, False),
+                             (7 * C + 192, C - 192, True)] and eng._pipe_verdict is True
+    # no opinion / an engine that already has them: one call
+    for setup in ("none", "on"):
         h, eng = Host(), FakeEngine()
-        if setup == "verdict":
-            h.pipeline_launches, eng._pipe_verdict = (lambda: False), False
         if setup == "on":
-            h.pipeline_launches, eng.pipelined, eng._pipe_verdict = (lambda: True), True, True
+            h.pipeline_launches, eng.pipelined, eng._pipe_verdict, eng._pipe_regime = (lambda: True), True, True, True
         h._decode_window(eng, 0, 4096)
         assert eng.calls == [(0, 4096, setup == "on")]
+    # a verdict against them stands within its regime -- plain chunks, the sampler is asked again between them -- and falls
+    # with it: when the other pipelined level finishes (regime 2 -> 1) the rest of the window is measured afresh
+    h, eng = Host(), FakeEngine()
+    eng._pipe_verdict, eng._pipe_regime = False, 2
+    h.pipeline_launches = lambda: 2 if len(eng.calls) < 3 else 1
+    h._decode_window(eng, 0, 4096)
+    covered(eng, 0, 4096)
+    assert eng.calls[:3] == [(0, C, False), (C, C, False), (2 * C, C, False)] and eng.calls[3] == (3 * C, 16, True)
+    assert eng._pipe_verdict is True and eng._pipe_regime == 1 and h.pipeline_report["regime"] == 1
 
 
 def test_a_finished_level_releases_its_pipelined_pair():
@@ -673,8 +704,8 @@ def test_a_finished_level_releases_its_pipelined_pair():
 
 def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
     """jb_engine_pipeline's host logic (no launch happens before the first decode): which engines are eligible (fp16, <= 16
-    samples, wide-value layers of one 480-channel head, key sets <= 128), ONE owner per process, release by switching off
-    or by destroying the engine, JB_PIPELINE_LAUNCHES=0 forbids, enable = 2 is accepted on an engine without streams,
+    samples, wide-value layers of one 480-channel head, key sets <= 128), TWO owners per process (one with the fat attention
+    kernel), release by switching off or by destroying the engine, JB_PIPELINE_LAUNCHES=0 forbids, enable = 2 is accepted on an engine without streams,
     jb_engine_pipelined reports the effective state."""
     from jukebox_amd import _lib as L
     from jukebox_amd import engine as E
@@ -707,25 +738,39 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
         e.set_cond(None, None)
         return e
 
-    a, b = engine(), engine()
+    a, b, c3 = engine(), engine(), engine()
     assert not a.pipelined and not b.pipelined                     # opt-in: nothing asks by default
     assert a.set_pipelined(True) is True and a.pipelined and L.lib().jb_engine_pipelined(a.handle) == 1
     assert L.lib().jb_engine_pipelined(b.handle) == 0 and L.lib().jb_engine_pipeline(a.handle, 3) != 0     # modes 0 / 1 / 2 only
-    assert b.set_pipelined(True) is False and not b.pipelined      # one owner per process
+    assert not a.pipeline_resident                                 # the pair of streams is made by the first pipelined decode
+    assert b.set_pipelined(True) is True and b.pipelined           # TWO owners per process (lean attention kernel) ...
+    assert c3.set_pipelined(True) is False and not c3.pipelined    # ... and no third
+    assert a.set_pipelined(True) is True                           # asking again changes nothing
     assert a.set_pipelined(False) is False
-    assert b.set_pipelined(True) is True
+    assert c3.set_pipelined(True) is True
     assert a.set_pipelined(True) is False
-    b.close()                                                      # destroying the owner releases the right
+    b.close()                                                      # destroying an owner releases its right
     assert a.set_pipelined(True, fresh=True) is True               # enable = 2 on an engine that never made its streams
     a.set_pipelined(False)
+    c3.set_pipelined(False)
+    L.lib().jb_tune_attn_decode_wide_lean(0)                       # the fat attention kernel needs empty compute units: one owner
+    try:
+        b = engine()
+        assert a.set_pipelined(True) is True and b.set_pipelined(True) is False
+        a.set_pipelined(False)
+        assert b.set_pipelined(True) is True
+        b.close()
+    finally:
+        L.lib().jb_tune_attn_decode_wide_lean(1)
+    c3.close()
     for kw in (dict(heads=2, W=256), dict(fp16=False), dict(n_batch=32), dict(T=16384, blocks=64)):   # last: 256-key block sets
         e = engine(**kw)
         assert e.set_pipelined(True) is False and not e.pipelined, kw
         e.close()
     monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "0")
     assert a.set_pipelined(True) is False
-    monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1")                # every eligible engine asks as it is created; the first wins
-    c, d = engine(), engine()
-    assert c.pipelined and not d.pipelined
-    for e in (a, c, d):
+    monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1")                # every eligible engine asks as it is created; the first two win
+    c, d, f = engine(), engine(), engine()
+    assert c.pipelined and d.pipelined and not f.pipelined
+    for e in (a, c, d, f):
         e.close()

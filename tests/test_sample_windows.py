@@ -162,6 +162,58 @@ def test_pipelined_levels_on_cpu(chunk):
         assert sorted(a.calls) == sorted(b.calls)
 
 
+def test_level_pipeline_names_the_regime_of_pipelined_launches():
+    """The level pipeline's say on software-pipelined launches (sample._sample_levels_pipelined): the two lowest levels whose
+    models can have them (`prior.prior.pipeline_candidate`: the upsamplers) are told "not now" (0) while any OTHER level -- the
+    top prior, whose kernels do not fit beside a pipelined engine's waiting launches -- still runs, then the regime: 2 while the
+    other candidate is still sampling beside them, 1 once they are alone.  The top level is never asked.  Nothing of it
+    outlives the job (release_pipeline, pipeline_launches back to None)."""
+    top = 8192 + 1024
+    priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=top)
+    hps.keep_priors_resident, hps.pipeline_levels, hps.pipeline_chunk = True, True, 256
+    sk[2]["max_batch_size"] = 3
+
+    class FakeAR:
+        def __init__(self, candidate):
+            self.pipeline_candidate, self.pipeline_launches, self.released = candidate, None, 0
+        def release_pipeline(self):
+            self.released += 1
+
+    import threading
+    seen = {0: [], 1: [], 2: []}
+    started = {1: threading.Event(), 0: threading.Event()}
+
+    def after_publish(prior, n_done):        # an upper level's first window does not end before the level below has started
+        if prior.level in (1, 2) and 2048 <= n_done < 8192:
+            started[prior.level - 1].wait(timeout=20)
+
+    for p in priors:
+        p.prior = FakeAR(p.level != 2)
+        p.after_publish = after_publish
+        orig = p.sample
+
+        def wrapped(*a, _orig=orig, _p=p, **k):
+            w = _p.prior.pipeline_launches
+            seen[_p.level].append(w() if callable(w) else w)
+            if _p.level in started:
+                started[_p.level].set()
+            out = _orig(*a, **k)
+            seen[_p.level].append(w() if callable(w) else w)
+            return out
+        p.sample = wrapped
+    zs = S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
+    check_levels(zs, 2, top)
+    assert all(x is False for x in seen[2]), seen[2]                 # the top prior: plain chain, never a candidate
+    for l in (0, 1):
+        assert set(seen[l]) <= {0, 1, 2}, (l, seen[l])
+        assert seen[l] == sorted(seen[l], key=lambda r: {0: 0, 2: 1, 1: 2}[r]), (l, seen[l])     # 0 -> 2 -> 1, never back
+    assert seen[1][0] == 0                                           # "not now" while the top level runs
+    assert 1 in seen[0] and 2 in seen[0] + seen[1]                   # level 0 ends alone; the two ran side by side before
+    assert 1 not in seen[1]                                          # level 1 always has level 0 beside it
+    for p in priors:
+        assert p.prior.pipeline_launches is None and p.prior.released >= 2      # job start + job end
+
+
 def test_pipelined_levels_refuse_a_total_length_below_a_lower_context():
     """A job shorter than a lower level's context (here level 1: 8192 tokens = 2048 top-level codes, the top level has 757)
     fails in the sequential loop on get_z_conds' length assertion; the level pipeline must fail too, not wait for upper-level

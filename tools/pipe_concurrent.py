@@ -1,6 +1,8 @@
-"""Three upsampler engines decoding side by side from three host threads, as the level pipeline runs them; engine 0 asks for
-pipelined launches, engine 1 asks too and is refused (one pipelined engine per process), engine 2 is plain: ms per step
-each, whether an engine has pipelined launches, and the error words."""
+"""Upsampler engines decoding side by side from their own host threads, as the level pipeline runs them: ms per step each,
+whether an engine has pipelined launches, and the error words, for
+  A  two engines on plain chains            B  two engines on pipelined launches (two owners per process: lean attention)
+  C  one pipelined, one plain               D  one engine alone, pipelined / plain
+Usage: python tools/pipe_concurrent.py [depth]"""
 import sys, threading, time
 import torch
 sys.path.insert(0, ".")
@@ -11,16 +13,17 @@ dev = torch.device("cuda:0")
 cfg = dict(CFGS["up"], depth=int(sys.argv[1]) if len(sys.argv) > 1 else 12, seq_len=2048, blocks=32)
 sd = random_state(cfg, dev)
 engs = []
-for i in range(3):
+for i in range(2):
     e = PriorEngine(sd, "", n_batch=16, fp16=True, chunk_cap=64, **cfg)
     e.set_cond(torch.randn(16, cfg["seq_len"], cfg["width"], device=dev) * 0.01, torch.randn(16, 1, cfg["width"], device=dev) * 0.01)
     e.set_sampling(temp=0.99, seed=i)
     engs.append(e)
-print("pipelined launches granted:", [e.set_pipelined(i < 2) for i, e in enumerate(engs)], flush=True)
-STEPS = 256
+STEPS = 384
+streams = [torch.cuda.Stream(priority=-1) for _ in engs]
 
 
-def run(eng, stream, out, key):
+def run(i, out):
+    eng, stream = engs[i], streams[i]
     with torch.cuda.stream(stream):
         eng.decode(1024, 8)
         stream.synchronize()
@@ -28,14 +31,25 @@ def run(eng, stream, out, key):
         for c in range(2):
             eng.decode(1024 + c * STEPS, STEPS)
         stream.synchronize()
-        out[key] = ((time.perf_counter() - t) / (2 * STEPS) * 1e3, eng.pipelined, eng.pipe_error())
+        out[i] = (round((time.perf_counter() - t) / (2 * STEPS) * 1e3, 3), eng.pipelined, eng.pipe_error())
 
 
-for prios in ((-1, -1, 0), (0, 0, 0), (-1, 0, 0)):
-    streams = [torch.cuda.Stream(priority=p) for p in prios]
+def case(name, modes):
+    for e, m in zip(engs, modes):
+        if m is not None:
+            e.set_pipelined(bool(m))
     out = {}
-    ths = [threading.Thread(target=run, args=(engs[i], streams[i], out, i)) for i in range(3)]
+    ths = [threading.Thread(target=run, args=(i, out)) for i, m in enumerate(modes) if m is not None]
     for th in ths: th.start()
     for th in ths: th.join()
-    print("priorities", prios, {k: (round(v[0], 3), v[1], v[2]) for k, v in sorted(out.items())}, flush=True)
-    break      # an engine keeps the stream it was first used on
+    print(name, dict(sorted(out.items())), flush=True)
+    for e in engs:
+        e.set_pipelined(False)
+
+
+for rep in range(2):
+    case("A two plain chains        ", (0, 0))
+    case("B two pipelined engines   ", (1, 1))
+    case("C pipelined next to plain ", (1, 0))
+    case("D alone, pipelined        ", (1, None))
+    case("D alone, plain            ", (0, None))
