@@ -427,6 +427,11 @@ def main():
     breakdown["level0_launch_form"] = "pipelined" if kept else "plain chain"
     if report:
         breakdown["level0_in_situ_comparison_ms_per_step"] = report
+    # every in-situ comparison of the last jobs, per level (regime 2: the two upsampler levels pipelined side by side; 1: alone)
+    for l in (1, 0):
+        reps = getattr(getattr(priors[l], "prior", None), "pipeline_reports", None)
+        if reps:
+            breakdown[f"level{l}_in_situ_comparisons"] = reps[-4:]
     if kept and eng.set_pipelined(True):
         eng.decode(4096, 16)
         step_ms = eng.timed_decode(4096, 256) * 1e3

@@ -118,6 +118,10 @@ void jb_tune_gemm_lds(int min_rows);
 /* fp16 problems of one tap at unit strides (rows = (sequence, position), any pitch between sequences) with at least
  * `min_rows` output rows use the LDS-DMA 128x128-tile kernel (default 256; < 0: never).  Bit-identical to the other kernels. */
 void jb_tune_gemm_glds(int min_rows);
+/* fp16 decode projections over 129 .. 160 k-tiles (5b_lyrics, K = 4800; <= 16 rows): 1 = 8-wave workgroups that walk their
+ * k-tiles through two register stages (two workgroups per compute unit, every column tile resident at once; default), 0 = the
+ * 16-wave kernels.  Another summation order: results agree to rounding, not bit for bit. */
+void jb_tune_gemv_long(int on);
 
 /* Weight-streaming skinny GEMM for the decode step (n_rows <= 64): out = act(LN?(x) @ W + b) (+ res),
  * one workgroup per 16 output columns, waves split K.  With ln_gamma != NULL the LayerNorm of
@@ -179,11 +183,12 @@ int jb_attn_decode_wide(int attn_func, const void* q, int64_t ldq, const void* k
                         const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
                         int width, int block_ctx, const int* t_dev, int max_len, void* stream);
 int jb_attn_decode_wide_supported(int attn_func, int d_head, int width, int block_ctx, int max_len);
-/* 480-channel heads (the 1b upsamplers): 1 (default) = the lean form of the kernel -- the query row goes through LDS instead
- * of 60 registers per lane, <= 168 registers: a workgroup then shares a compute unit with a waiting projection workgroup of a
- * pipelined chain, which is what lets TWO engines of a process run pipelined launches (jb_engine_pipeline) and keeps a plain
- * chain next to a pipelined engine from starving; 0 = the fat form (198-216 registers per lane: one workgroup per otherwise
- * empty compute unit; jb_engine_pipeline then admits one engine).  Same arithmetic in the same order: bit-identical. */
+/* 480-channel heads (the 1b upsamplers): 1 = the lean form of the kernel -- the query row goes through LDS instead of 60
+ * registers per lane, <= 168 registers: a workgroup then shares a compute unit with a waiting projection workgroup of a
+ * pipelined chain, which is what lets TWO engines of a process run pipelined launches side by side (jb_engine_pipeline); 0
+ * (default) = the fat form (198-216 registers per lane: one workgroup per otherwise empty compute unit, jb_engine_pipeline
+ * then admits one engine; 2 % faster per step for an engine that has the GPU to itself).  Same arithmetic in the same
+ * order: bit-identical.  Read when a launch is enqueued, i.e. when an engine's graphs are captured. */
 void jb_tune_attn_decode_wide_lean(int on);
 
 /* Tuning hook: workgroup size (multiple of 64, <= 1024) and key/value row pairs in flight per wave (2, 4 or 8) of

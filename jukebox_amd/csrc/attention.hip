@@ -714,9 +714,11 @@ extern "C" int jb_attn_decode_wide(int attn_func, const void* q, int64_t ldq, co
                                     width, block_ctx, t_dev, max_len, nullptr, stream);
 }
 
-// 480-channel heads (the 1b upsamplers): the lean form of the kernel (query through LDS, <= 168 registers per lane: shares a
-// compute unit with a waiting projection workgroup of a pipelined chain).  jb_tune_attn_decode_wide_lean.
-static int g_wide_lean = 1;
+// 480-channel heads (the 1b upsamplers): 1 = the lean form of the kernel (query through LDS, <= 168 registers per lane: shares a
+// compute unit with a waiting projection workgroup of a pipelined chain: what two pipelined engines side by side need), 0
+// (default) = the fat form, 0.4 us per launch faster for an engine that has the GPU to itself (1.557 against 1.587 ms per
+// upsampler step, profiles/r05_bench_engine_lean_vs_fat_attention.log).  jb_tune_attn_decode_wide_lean.
+static int g_wide_lean = 0;
 extern "C" void jb_tune_attn_decode_wide_lean(int on) { g_wide_lean = on ? 1 : 0; }
 int jb_attn_decode_wide_lean() { return g_wide_lean; }
 

@@ -226,21 +226,26 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 errors.append(e)
                 cond.notify_all()
 
-    # Software-pipelined launches for the (at most two) lowest levels whose engines can have them -- the 1b upsamplers, the
-    # long poles of the job -- from the moment every OTHER level has finished.  A pipelined engine's waiting launches keep
-    # compute units half occupied for good; the levels next to it must fit beside them: the upsamplers' own launches do (the
-    # lean wide-value attention, <= 168 registers per lane: attention.hip), the top prior's 16-wave kernels do not -- measured
-    # in round 3 on the 6-second job: 80 s plain, 176 s with level 0 pipelined next to the top level's plain chain.  The
-    # sampler's answer is the REGIME the launches would run in: 2 = another pipelined level runs beside this one, 1 = alone
-    # (round 4 ran only the alone regime: 31 % of the job had levels 1 and 0 side by side on plain chains at 2.28 instead of
-    # 1.56 ms per step).  The engine is asked before every window (and every 512 steps of a window on the plain chain); its
-    # pair of streams is made when the launches are switched on and released when they go off or the job ends: two more
-    # hardware queues in the process -- even idle ones -- slowed the concurrent levels' plain chains 2.5x
-    # (profiles/r04_pipe_in_job.log).  The first pipelined window of a regime compares the two launch forms in situ and
-    # keeps the faster (ConditionalAutoregressive2D._decode).
+    # Software-pipelined launches for the lowest level (the long pole of the job) ONLY WHILE IT RUNS ALONE.  A pipelined engine's
+    # waiting launches keep compute units half occupied for good, and whatever runs next to them crawls -- measured again in round 5
+    # with everything that could be in the way removed (profiles/r05_pipe_concurrent_two_engines.log, upsampler geometry, ms per
+    # step): alone 1.53 pipelined / 1.77 plain; two plain chains side by side 2.09 each; a pipelined engine next to a plain
+    # chain 5.9 / 6.8 (!); TWO pipelined engines side by side -- possible since the lean attention kernel, <= 168 registers per
+    # lane, attention.hip -- 2.02 each: 3 % better than two plain chains, which the lean kernel gives back when the level is
+    # alone (1.587 against 1.557 ms).  So the default stays one pipelined level, from the moment every other level has
+    # finished; hps.pipeline_max_engines = 2 pipelines the two lowest candidate levels side by side once the levels that are
+    # no candidates (the top prior: its 16-wave kernels do not fit beside a waiter) have finished.  The sampler's answer is
+    # the REGIME the launches would run in -- 2: another pipelined level runs beside this one, 1: alone --; a verdict of the
+    # in-situ comparison (ConditionalAutoregressive2D._decode) stands within its regime.  The engine is asked before every
+    # window (and every 512 steps of a window on the plain chain); its pair of streams is made when the launches are switched
+    # on and released when they go off or the job ends: two more hardware queues in the process -- even idle ones -- slowed the
+    # concurrent levels' plain chains 2.5x (profiles/r04_pipe_in_job.log).
+    n_pipe = int(hps.get("pipeline_max_engines", 1))
+    if _want_pipelined_launches(hps) and t.device(device).type == "cuda":
+        from . import _lib
+        _lib.lib().jb_tune_attn_decode_wide_lean(1 if n_pipe > 1 else 0)       # (read when an engine's graphs are captured)
     if _want_pipelined_launches(hps):
-        cands = [l for l in sorted(sample_levels)
-                 if getattr(getattr(priors[l], "prior", None), "pipeline_candidate", False)][:int(hps.get("pipeline_max_engines", 2))]
+        cands = [l for l in sorted(sample_levels) if getattr(getattr(priors[l], "prior", None), "pipeline_candidate", False)][:n_pipe]
         others = [l for l in sample_levels if l not in cands]
         for l in cands:
             priors[l].prior.pipeline_launches = (

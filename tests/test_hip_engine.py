@@ -271,7 +271,9 @@ def test_two_pipelined_engines_side_by_side(PE, monkeypatch):
     lean wide-value attention kernel (<= 168 registers per lane: a workgroup fits beside a waiting projection workgroup; the
     fat form needs empty compute units and two engines' waiters can leave none).  Prints ms per step side by side and alone."""
     import threading
+    from jukebox_amd import _lib as L
     monkeypatch.delenv("JB_PIPELINE_LAUNCHES", raising=False)
+    L.lib().jb_tune_attn_decode_wide_lean(1)        # (read when an engine's launches are captured; the default is the fat form)
     rng = np.random.default_rng(9)
     width, depth, bins, seq, blocks, N = 1920, 12, 512, 2048, 32, 16
     sd = to_dev(_random_sd(rng, width, depth, bins, seq, 2, scale=0.02))
@@ -324,6 +326,15 @@ def test_two_pipelined_engines_side_by_side(PE, monkeypatch):
     assert not errs and torch.equal(engs[0].tokens[:, :T0 + STEPS], want[0])
     for e in engs:
         e.close()
+    L.lib().jb_tune_attn_decode_wide_lean(0)
+    # with the fat kernel the library admits ONE pipelined engine (an attention workgroup needs an empty compute unit)
+    e0, e1 = (PE(sd, "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=1, attn_order=2, blocks=blocks,
+                 y_cond=False, fp16=True, chunk_cap=64) for _ in range(2))
+    for e in (e0, e1):
+        e.set_cond(torch.zeros(N, seq, width), None)
+    assert e0.set_pipelined(True) and not e1.set_pipelined(True)
+    e0.close()
+    e1.close()
 
 
 def test_a_released_pair_leaves_the_other_engines_plain_chains_alone(PE, monkeypatch):
@@ -424,7 +435,9 @@ def test_pipelined_timeout_is_recovered_on_the_plain_chain(monkeypatch):
 
     monkeypatch.setattr(PriorEngine, "decode", decode)
     got = model.primed_sample(N, prime, **kw).cpu()
-    assert injected == [(40, 260)] and model.pipeline_report.get("timed_out") and not eng.pipelined and eng.pipe_error() == 0
+    # (the first pipelined call of the window: the 8 untimed steps of the in-situ comparison's short form)
+    assert injected == [(40, 8)] and model.pipeline_report.get("timed_out") and not eng.pipelined and eng.pipe_error() == 0
+    assert eng._pipe_timed_out and not eng.pipeline_resident            # the pair is gone, the engine keeps the plain chain
     assert torch.equal(got, want)
     model.pipeline_launches = lambda: True                 # the sampler asks again for the next window: this engine stays plain
     again = model.primed_sample(N, prime, **kw).cpu()

@@ -343,6 +343,7 @@ def test_gemm_split_reports_activations_outside_the_half_range(H):
     H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1), pre_relu=True)   # the negative outlier dies in the ReLU
     H.check_split_overflow()
     H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1))
+    torch.cuda.synchronize()                 # the flag is a host-coherent word: the call reads what FINISHED launches have stored
     assert L.lib().jb_gemm_split_overflow(0) == 1 and L.lib().jb_gemm_split_overflow(0) == 1      # sticky until reset
     with pytest.raises(L.JukeboxHipError):
         H.check_split_overflow()
@@ -351,6 +352,19 @@ def test_gemm_split_reports_activations_outside_the_half_range(H):
     H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1))
     with pytest.raises(L.JukeboxHipError):
         H.check_split_overflow()
+    H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1), pre_relu=True)   # fmaxf(NaN, 0) = 0: judged BEFORE the ReLU (torch's relu keeps a NaN)
+    with pytest.raises(L.JukeboxHipError):
+        H.check_split_overflow()
+    x[9, 5] = -float("inf")                                             # relu(-inf) = 0: fine under the input ReLU
+    H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1), pre_relu=True)
+    H.check_split_overflow()
+    x[9, 5] = 0.0
+    x[3, 1] = 70000.0                                                   # too large for a half, not clipped by the ReLU
+    H.gemm(x, pw, n_seq=2, t_in=50, shifts=(-1, 0, 1), pre_relu=True)
+    assert L.lib().jb_gemm_split_overflow(0) in (0, 1)                  # (not waited for: whatever has finished)
+    with pytest.raises(L.JukeboxHipError):
+        H.check_split_overflow()                                        # waits, reads, clears
+    H.check_split_overflow(wait=False)
     # weights have no range limit: the image holds s * w (s a power of two that puts max |w| into [128, 256)), checked finite
     big = H.pack_conv_taps(w * 1e7, torch.float32, split=True)
     assert big.unscale > 1.0 and 128.0 <= float((w * 1e7).abs().max()) / big.unscale < 256.0
@@ -429,6 +443,40 @@ def test_gemv_ln_folded(H, name, dt, tol, rows, K, J):
     if rows * K * (2 if f16 else 4) < 100 * 1024:          # the in-kernel path stages the rows in LDS
         cls = H.gemv(dev(x, dt), H.pack_conv1d_w(dev(W), dt), bias=dev(b), ln=(dev(g), dev(be)), act=L.ACT_QUICK_GELU)
         assert relerr(got, cls.float().cpu().numpy()) < tol
+
+
+@pytest.mark.parametrize("rows,K,J", [(3, 4800, 272), (16, 4800, 64), (3, 4800, 4800), (8, 5120, 48), (3, 4128, 32)])
+def test_gemv_long_rows_on_8_waves(H, rows, K, J):
+    """jb_tune_gemv_long(1): projections over 129 .. 160 k-tiles (5b_lyrics, K = 4800) on 8-wave workgroups that walk their k-tiles
+    through two register stages (gemv_long_kernel) instead of the 16-wave kernels -- the folded-LayerNorm form and the plain form with
+    bias + residual, against the same references and bars as the 16-wave kernels, and against those kernels' own outputs (another
+    summation order of the eight / sixteen partial tiles: equal to output rounding)."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(rows * 11 + K + J)
+    dt, tol = torch.float16, 3e-3
+    x = h16(rng.standard_normal((rows, K)).astype(np.float32) * 1.5 + rng.standard_normal((rows, 1)).astype(np.float32) * 4)
+    W = h16((rng.standard_normal((K, J)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(J).astype(np.float32)
+    g = (1 + 0.2 * rng.standard_normal(K)).astype(np.float32)
+    be = (0.2 * rng.standard_normal(K)).astype(np.float32)
+    R = h16(rng.standard_normal((rows, J)).astype(np.float32))
+    f = H.FoldedLN(dev(W), dev(b), dev(g), dev(be), dt)
+    pw = H.pack_conv1d_w(dev(W), dt)
+    outs = {}
+    try:
+        for long_rows in (0, 1):
+            L.lib().jb_tune_gemv_long(long_rows)
+            folded = H.gemv(dev(x, dt), None, ln_fold=f, act=L.ACT_QUICK_GELU).float().cpu().numpy()
+            plain = H.gemv(dev(x, dt), pw, bias=dev(b), res=dev(R, dt)).float().cpu().numpy()
+            outs[long_rows] = (folded, plain)
+    finally:
+        L.lib().jb_tune_gemv_long(1)             # the default
+    want_f = O.quick_gelu(h16(h16(O.layer_norm(x, g, be)) @ W + h16(b)), fp16=True)
+    want_p = h16(R + h16(x @ W + h16(b)))
+    for long_rows in (0, 1):
+        assert relerr(outs[long_rows][0], want_f) < tol and relerr(outs[long_rows][1], want_p) < tol, long_rows
+    assert relerr(outs[1][0], outs[0][0]) < 1e-3 and relerr(outs[1][1], outs[0][1]) < 1e-3
+    assert not np.array_equal(outs[1][1], np.zeros_like(outs[1][1]))
 
 
 def test_gemv_ln_folded_rejects_unsupported_shapes(H):
@@ -710,14 +758,14 @@ def test_attn_decode_wide(H, func, d, W_, bc, T):
         t_dev = torch.tensor([t], dtype=torch.int32, device="cuda")
         got_t = H.attn_decode_wide(func, dev(q[:, 0], f16), kc, vw, dev(res, f16), dev(bp), bc, t_dev, T)
         if d == 480:
-            # the lean form (query through LDS, <= 168 registers per lane: the default at 480 channels) and the fat form are the
-            # same arithmetic in the same order
-            L.lib().jb_tune_attn_decode_wide_lean(0)
+            # the lean form (query through LDS, <= 168 registers per lane: what two pipelined engines side by side need) and the
+            # fat form (the default) are the same arithmetic in the same order
+            L.lib().jb_tune_attn_decode_wide_lean(1)
             try:
-                fat = H.attn_decode_wide(func, dev(q[:, 0], f16), kc, vw, dev(res, f16), dev(bp), bc, t_dev, T)
+                lean = H.attn_decode_wide(func, dev(q[:, 0], f16), kc, vw, dev(res, f16), dev(bp), bc, t_dev, T)
             finally:
-                L.lib().jb_tune_attn_decode_wide_lean(1)
-            assert torch.equal(got_t, fat), (func, t, "lean and fat kernels differ")
+                L.lib().jb_tune_attn_decode_wide_lean(0)
+            assert torch.equal(got_t, lean), (func, t, "lean and fat kernels differ")
         got = got_t.float().cpu().numpy()
         idx = decode_key_index(func, t, bc, prime_r if func == 7 else None)
         if idx is None:

@@ -639,6 +639,21 @@ def test_window_switches_to_pipelined_launches_when_the_upper_levels_finish():
     assert eng._pipe_verdict is True and eng._pipe_regime == 1 and h.pipeline_report["regime"] == 1
 
 
+def test_pipeline_candidates_by_geometry():
+    """ConditionalAutoregressive2D.pipeline_candidate mirrors the library's eligibility rule on the model's geometry: the 1b
+    upsamplers (one 480-channel head, width 1920, block_ctx 64, 128 blocks) are candidates; the top priors (2 / 8 heads), the
+    small prior (256-channel head) and an upsampler-shaped model whose transpose pattern would see > 128 keys are not."""
+    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
+    with torch.device("meta"):
+        up = AR((8192,), 2048, width=1920, depth=2, heads=1, attn_order=2, blocks=128, x_cond=True, y_cond=True)
+        top = AR((6528,), 2127, width=2048, depth=2, heads=2, attn_order=12, blocks=64, x_cond=True, y_cond=True, prime_len=384)
+        small = AR((8192,), 1024, width=1024, depth=2, heads=1, attn_order=2, blocks=64)
+        long_blocks = AR((16384,), 2048, width=1920, depth=2, heads=1, attn_order=2, blocks=256, x_cond=True, y_cond=True)
+        enc = AR((512,), 80, width=1920, depth=2, heads=1, attn_order=2, blocks=8, only_encode=True)
+    assert up.pipeline_candidate and not top.pipeline_candidate and not small.pipeline_candidate
+    assert not long_blocks.pipeline_candidate and not enc.pipeline_candidate
+
+
 def test_a_finished_level_releases_its_pipelined_pair():
     """Nothing of the pipelined launches outlives the phase that uses them (the reference's loop is re-entrant:
     jukebox/sample.py:90-121): ConditionalAutoregressive2D.release_pipeline switches every engine of the prior off -- which
@@ -740,6 +755,7 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
 
     a, b, c3 = engine(), engine(), engine()
     assert not a.pipelined and not b.pipelined                     # opt-in: nothing asks by default
+    L.lib().jb_tune_attn_decode_wide_lean(1)                       # the lean attention kernel: two owners per process
     assert a.set_pipelined(True) is True and a.pipelined and L.lib().jb_engine_pipelined(a.handle) == 1
     assert L.lib().jb_engine_pipelined(b.handle) == 0 and L.lib().jb_engine_pipeline(a.handle, 3) != 0     # modes 0 / 1 / 2 only
     assert not a.pipeline_resident                                 # the pair of streams is made by the first pipelined decode
@@ -753,15 +769,12 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
     assert a.set_pipelined(True, fresh=True) is True               # enable = 2 on an engine that never made its streams
     a.set_pipelined(False)
     c3.set_pipelined(False)
-    L.lib().jb_tune_attn_decode_wide_lean(0)                       # the fat attention kernel needs empty compute units: one owner
-    try:
-        b = engine()
-        assert a.set_pipelined(True) is True and b.set_pipelined(True) is False
-        a.set_pipelined(False)
-        assert b.set_pipelined(True) is True
-        b.close()
-    finally:
-        L.lib().jb_tune_attn_decode_wide_lean(1)
+    L.lib().jb_tune_attn_decode_wide_lean(0)                       # the fat attention kernel (the default) needs empty compute
+    b = engine()                                                   # units: one owner
+    assert a.set_pipelined(True) is True and b.set_pipelined(True) is False
+    a.set_pipelined(False)
+    assert b.set_pipelined(True) is True
+    b.close()
     c3.close()
     for kw in (dict(heads=2, W=256), dict(fp16=False), dict(n_batch=32), dict(T=16384, blocks=64)):   # last: 256-key block sets
         e = engine(**kw)
@@ -769,8 +782,8 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
         e.close()
     monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "0")
     assert a.set_pipelined(True) is False
-    monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1")                # every eligible engine asks as it is created; the first two win
-    c, d, f = engine(), engine(), engine()
-    assert c.pipelined and d.pipelined and not f.pipelined
-    for e in (a, c, d, f):
+    monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1")                # every eligible engine asks as it is created; the first wins
+    c, d = engine(), engine()
+    assert c.pipelined and not d.pipelined
+    for e in (a, c, d):
         e.close()

@@ -171,6 +171,7 @@ def test_level_pipeline_names_the_regime_of_pipelined_launches():
     top = 8192 + 1024
     priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=top)
     hps.keep_priors_resident, hps.pipeline_levels, hps.pipeline_chunk = True, True, 256
+    hps.pipeline_max_engines = 2             # (the default, 1, is the second half of this test)
     sk[2]["max_batch_size"] = 3
 
     class FakeAR:
@@ -212,6 +213,27 @@ def test_level_pipeline_names_the_regime_of_pipelined_launches():
     assert 1 not in seen[1]                                          # level 1 always has level 0 beside it
     for p in priors:
         assert p.prior.pipeline_launches is None and p.prior.released >= 2      # job start + job end
+    # the default: ONE pipelined level -- the lowest candidate, only once every other level has finished (regime 1); the level
+    # above it is told nothing but "plain chain"
+    priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=top)
+    hps.keep_priors_resident, hps.pipeline_levels, hps.pipeline_chunk = True, True, 256
+    sk[2]["max_batch_size"] = 3
+    seen = {0: [], 1: [], 2: []}
+    for p in priors:
+        p.prior = FakeAR(p.level != 2)
+        orig = p.sample
+
+        def wrapped1(*a, _orig=orig, _p=p, **k):
+            w = _p.prior.pipeline_launches
+            seen[_p.level].append(w() if callable(w) else w)
+            out = _orig(*a, **k)
+            seen[_p.level].append(w() if callable(w) else w)
+            return out
+        p.sample = wrapped1
+    zs = S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
+    check_levels(zs, 2, top)
+    assert all(x is False for x in seen[2] + seen[1]), (seen[2][:4], seen[1][:4])
+    assert set(seen[0]) <= {0, 1} and seen[0][-1] == 1 and seen[0] == sorted(seen[0])
 
 
 def test_pipelined_levels_refuse_a_total_length_below_a_lower_context():

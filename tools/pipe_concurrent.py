@@ -47,9 +47,12 @@ def case(name, modes):
         e.set_pipelined(False)
 
 
+from jukebox_amd import _lib as L
+L.lib().jb_tune_attn_decode_wide_lean(1)         # two pipelined engines need the lean attention kernel
 for rep in range(2):
     case("A two plain chains        ", (0, 0))
     case("B two pipelined engines   ", (1, 1))
-    case("C pipelined next to plain ", (1, 0))
+    if rep == 0:
+        case("C pipelined next to plain ", (1, 0))
     case("D alone, pipelined        ", (1, None))
     case("D alone, plain            ", (0, None))

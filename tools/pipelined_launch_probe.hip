@@ -470,7 +470,8 @@ int main(int argc, char** argv) {
     std::vector<__half> h(N_EL);
     for (int i = 0; i < N_EL; ++i) h[i] = __float2half((float)((i & 7)));
     __half* act; unsigned *flags, *tickets, *err, *abortf; float* sink; u32x4* wts;
-    const size_t W_MAX_PHASE = 11059200;                         // 1920 x 2880 f16
+    const bool layers = argc > 6 && atoi(argv[6]) != 0;          // argv[6] = 1: cycles of phases that model a whole layer (below)
+    const size_t W_MAX_PHASE = layers ? 25804800 : 11059200;     // 1920 x 2880 f16 (1920 x 6720 for the 3-phase layer's first phase)
     CK(hipMalloc(&act, 2 * N_EL * 2)); CK(hipMalloc(&flags, K * PAD * 4)); CK(hipMalloc(&tickets, K * PAD * 4));
     CK(hipMalloc(&err, 4)); CK(hipMalloc(&abortf, 4)); CK(hipMalloc(&sink, 4));
     CK(hipMalloc(&wts, W_MAX_PHASE * K)); CK(hipMemset(wts, 1, W_MAX_PHASE * K));
@@ -488,7 +489,25 @@ int main(int argc, char** argv) {
     // argv[5] = 1: the same 1920 x 1920 matrix on 60 / 120 / 240 workgroups (32 / 16 / 8 columns each) and the weightless phase on as
     // many: does the phase get cheaper when fewer workgroups fetch the 61-KB activation block?
     const bool sweep = argc > 5 && atoi(argv[5]) != 0;
-    const std::vector<Shape> shapes = sweep
+    // argv[6] = 1 (round 5): a LAYER as a cycle of phases with their own workgroup counts and cold bytes per slot, protocol 1,
+    // two graphs on two streams -- the cost model of the engine's pipelined launches.  What a phase streams before its poll:
+    //   today, 4 phases:   wide c_attn W x (2S + W) on 180 workgroups | attention: K + the v' slice of ~53 keys (the mean over the
+    //                      three patterns and a window) per (sample, slice): 64 workgroups x 100 KB | c_fc | mlp.c_proj
+    //   3 phases: c_attn + u = W'fc x + the v'' = W'fc (Wp Wv) columns: W x (2S + 3W) on 420 workgroups |
+    //                      attention producing x1 AND h_raw = u + sum p v'': 128 workgroups x 100 KB | mlp.c_proj with the LN /
+    //                      gelu prologue (same bytes)
+    // Every phase still all-gathers the 61-KB activation block of its producer and writes its slice of the next one.
+    std::vector<std::vector<Shape>> cycles;
+    if (layers) {
+        // (workgroup counts rounded to divisors of the block with whole 8-byte words per slice: 192 for 180, 384 / 480 for 420)
+        cycles.push_back({{192, 11059200, "c_attn"}, {64, 6553600, "attention"}, {120, 7372800, "c_fc"}, {120, 7372800, "c_proj"}});
+        cycles.push_back({{384, 25804800, "c_attn+u+v''"}, {128, 13107200, "attention x1+h_raw"}, {120, 7372800, "c_proj"}});
+        cycles.push_back({{480, 25804800, "c_attn+u+v''"}, {128, 13107200, "attention x1+h_raw"}, {120, 7372800, "c_proj"}});
+        cycles.push_back({{240, 25804800, "c_attn+u+v'' on 32-column tiles"}, {128, 13107200, "attention x1+h_raw"}, {120, 7372800, "c_proj"}});
+    }
+    const std::vector<Shape> shapes = layers ? std::vector<Shape>{{-1, 0, "today: 4 phases per layer"}, {-2, 0, "3 phases, first on 384 wgs"},
+                                                                  {-3, 0, "3 phases, first on 480 wgs"},
+                                                                  {-4, 0, "3 phases, first on 240 wgs"}} : sweep
         ? std::vector<Shape>{{60, 7372800, "1920x1920 on 60 workgroups"}, {120, 7372800, "1920x1920 on 120 workgroups"},
                              {240, 7372800, "1920x1920 on 240 workgroups"}, {60, 0, "no weights, 60 workgroups"},
                              {120, 0, "no weights, 120 workgroups"}, {240, 0, "no weights, 240 workgroups"}}
@@ -522,7 +541,11 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(tagged, t.data(), t.size() * 4, hipMemcpyHostToDevice));
         }
         CK(hipDeviceSynchronize());
+        const std::vector<Shape>* cyc = sh.G < 0 ? &cycles[-sh.G - 1] : nullptr;
+        const Args a_uniform = a;
         auto launch_j = [&](int j, hipStream_t s) {
+            Args a = a_uniform;
+            if (cyc) { const Shape& c = (*cyc)[j % cyc->size()]; a.G = c.G; a.w_phase_u4 = c.wbytes / 16; }
             if (v == 1) { if (m.wait) launch<1, true>(a, j, s); else launch<1, false>(a, j, s); }
             else if (v == 2) { if (m.wait) launch<2, true>(a, j, s); else launch<2, false>(a, j, s); }
             else if (v == 3) { if (m.wait) launch<3, true>(a, j, s); else launch<3, false>(a, j, s); }
@@ -580,6 +603,9 @@ int main(int argc, char** argv) {
         }
         unsigned errs = 0, ab = 0;
         CK(hipMemcpy(&errs, err, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ab, abortf, 4, hipMemcpyDeviceToHost));
+        if (cyc) printf("%-34s V%d %-28s %6.2f us/phase = %6.2f us per LAYER of %zu phases  (checksum errors %u, aborted %u)\n", sh.what, v,
+                        m.name, ms * 1e3 / ((double)R * K), ms * 1e3 / ((double)R * K) * cyc->size(), cyc->size(), errs, ab);
+        else
         printf("%-30s G=%3d V%d %-28s %6.2f us/phase  (checksum errors %u, aborted %u)\n", sh.what, sh.G, v, m.name,
                ms * 1e3 / ((double)R * K), errs, ab);
         fflush(stdout);
