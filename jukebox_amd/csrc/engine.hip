@@ -221,21 +221,25 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
             const JbPipe* pipe = next();
             if (mine) JB_TRY(jb_attn_decode_wide_impl(L.attn_func, c.q, S, L.kcache, L.vcache_w, L.cache_cap, c.x_a, W, L.b_proj, c.x_b,
                                                       W, N, S, W, c.block_ctx, c.t_dev, c.seq_len, pipe, s));
-        } else if (parity >= 0) {
-            jb_set_error("jb_engine: pipelined launches need wide-value layers throughout");
-            return JB_ERR_UNSUPPORTED;
         } else if (parts > 0) {
+            if (parity >= 0) {
+                jb_set_error("jb_engine: the key-split attention has no pipelined form");
+                return JB_ERR_UNSUPPORTED;
+            }
+            (void)next();
             JB_TRY(jb_attn_decode_split(L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att_parts, c.att_ml, N, H, d,
                                         c.block_ctx, c.t_dev, layer_max_keys(c, L), parts, s));
             g.x_parts = c.att_parts; g.x_ml = c.att_ml; g.n_parts = parts; g.n_head = H; g.d_head = d;
         } else {
-            JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, att_ld, N, H, d,
-                                  c.block_ctx, c.t_dev, c.seq_len, s));
+            // multi-head layers: attention into c.att (pitch att_ld, pad columns stay zero), then attn.c_proj + residual
+            const JbPipe* pipe = next();
+            if (mine) JB_TRY(jb_attn_decode_impl(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, att_ld, N, H, d,
+                                                 c.block_ctx, c.t_dev, c.seq_len, pipe, s));
             g.x = c.att; g.ldx = att_ld;
             const int KT = c.dtype == JB_F16 ? 32 : 16;
             if (att_ld % KT == 0 && att_ld - S < KT) g.K = att_ld;
         }
-        if (!layer_wide(c, L)) JB_TRY(jb_gemv(&g, s));
+        if (!layer_wide(c, L)) { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
         // ln_1 + mlp.c_fc + quick_gelu
         g = {};
         fill_ln_proj(g, c, L, 1);
@@ -267,8 +271,26 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
 
 // Software-pipelined launches of the decode step.  Available where every launch of the step has a
 // pipelined form: fp16, <= 16 samples, wide-value layers throughout (one head of 480 channels), widths of 33..64 k-tiles.
+// ... or (multi-head engines: 5b_lyrics' top prior) five launches per layer with the MFMA decode attention: fp16, <= 16 samples, folded
+// LayerNorm, no key-split layer, heads of 150 (ragged) / 256 / 512 channels, projections of 33..64 or 129..160 k-tiles.
+static bool pipeline_eligible_multi_head(const JbEngine* e) {
+    const jb_engine_cfg& c = e->cfg;
+    if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || !c.x_out_packed || c.width % 32 || c.n_mlp % 32) return false;
+    const int att_ld = c.att_ld ? c.att_ld : c.n_state, d = c.n_state / c.n_head;
+    auto lnf_ok = [](int nkt) { return (nkt >= 33 && nkt <= 64) || (nkt >= 129 && nkt <= 160); };
+    auto proj_ok = [](int nkt) { return nkt >= 1; };              // 4 / 8 waves (any length) or 16 waves (129..160 k-tiles), fp16
+    const int nkt_logits = c.width / 16;                          // fp32 head: no 16-wave pipelined form
+    if (!lnf_ok(c.width / 32) || att_ld % 32 || !proj_ok(att_ld / 32) || att_ld - c.n_state >= 32 || !proj_ok(c.n_mlp / 32) ||
+        (nkt_logits > 128 && nkt_logits <= 160)) return false;
+    if (!jb_attn_decode_pipe_supported(c.dtype, d, c.n_state, att_ld, c.n_state)) return false;
+    for (const jb_layer& L : e->layers)
+        if (layer_wide(c, L) || layer_split_parts(c, L) != 0 || !L.w_attn_f || !L.w_fc_f) return false;
+    return true;
+}
+
 static bool pipeline_eligible(const JbEngine* e) {
     const jb_engine_cfg& c = e->cfg;
+    if (pipeline_eligible_multi_head(e)) return true;
     if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || c.n_head != 1 || c.n_state != 480 || !c.x_out_packed) return false;
     if (c.width % 32 || c.n_mlp % 32 || c.width / 32 < 33 || c.width / 32 > 64 || c.n_mlp / 32 < 33 || c.n_mlp / 32 > 64) return false;
     for (const jb_layer& L : e->layers)
@@ -280,7 +302,8 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     JB_REQUIRE(handle, "null engine");
     JbEngine* e = (JbEngine*)handle;
     if (enable && !pipeline_eligible(e)) JB_UNSUPPORTED("this engine's decode step has launches without a pipelined form (needs pipe_words, "
-                                                        "fp16, <= 16 samples, wide-value layers of one 480-channel head, 33..64 k-tiles)");
+                                                        "fp16, <= 16 samples, and either wide-value layers of one 480-channel head on "
+                                                        "33..64 k-tiles or folded-LayerNorm multi-head layers without key splits)");
     // ONE pipelined engine per process.  Its waiting launch holds up to 180 workgroup slots while it spins; the producer it
     // waits for -- in particular the attention launch, 198 registers per lane: one workgroup per otherwise empty compute
     // unit -- must still find room.  One waiter leaves >= 76 compute units free of waiters; the waiters of two engines can

@@ -1421,7 +1421,10 @@ static int launch_gemv_lnf_nf(const GemvParams& p, int njt, int nf, hipStream_t 
         if constexpr (MT == 1 && NW == 8 && sizeof(T) == 2) {
             if (nf == 8) { gemv_lnf_kernel<T, 1, 8, 8, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
         }
-        jb_set_error("jb_gemv: a pipelined launch of the folded-LayerNorm projection takes fp16, <= 16 rows, 33..64 k-tiles");
+        if constexpr (MT == 1 && NW == 16 && sizeof(T) == 2) {       // 129 .. 160 k-tiles (5b_lyrics: K = 4800)
+            if (nf == 10) { gemv_lnf_kernel<T, 1, 16, 10, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+        }
+        jb_set_error("jb_gemv: a pipelined launch of the folded-LayerNorm projection takes fp16, <= 16 rows, 33..64 or 129..160 k-tiles");
         return JB_ERR_UNSUPPORTED;
     }
     if (nf == 8) gemv_lnf_kernel<T, MT, NW, 8><<<njt, NW * 64, lds, s>>>(p);
@@ -1461,8 +1464,8 @@ static int launch_gemv_fast(const GemvParams& p, int njt, size_t lds, hipStream_
 template <typename T, int MT, int NW, bool LNS>
 static int launch_gemv_inst(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
     if (p.pipe.slot >= 0) {
-        if constexpr (MT == 1 && NW == 8 && !LNS) {
-            if (p.fast) { gemv_kernel<T, 1, 8, false, true, 0, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+        if constexpr (MT == 1 && (NW == 8 || NW == 4) && !LNS) {
+            if (p.fast) { gemv_kernel<T, 1, NW, false, true, 0, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
         }
         jb_set_error("jb_gemv: a pipelined launch of the plain projection takes <= 16 rows, >= 32 whole k-tiles, aligned operands");
         return JB_ERR_UNSUPPORTED;
@@ -1498,6 +1501,14 @@ static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
     int nw = p.nkt >= 32 ? 8 : 4;
     if (!ln && mt == 1 && p.fast && p.nkt > 128 && p.nkt <= 160) {
         p.lds_pitch = 0;
+        if (p.pipe.slot >= 0) {
+            if constexpr (sizeof(T) == 2) {
+                gemv_kernel<T, 1, 16, false, true, 0, true><<<njt, 16 * 64, (size_t)16 * 64 * sizeof(f32x4), s>>>(p);
+                return JB_OK;
+            }
+            jb_set_error("jb_gemv: a pipelined launch of the 16-wave projection takes fp16");
+            return JB_ERR_UNSUPPORTED;
+        }
         return launch_gemv_fast<T, 1, 16, false, true, 0>(p, njt, (size_t)16 * 64 * sizeof(f32x4), s);
     }
     if (ln && nw == 8) {   // keep the staged rows + partial tiles within the 160 KiB of LDS
