@@ -118,6 +118,15 @@ extern "C" int jb_engine_launches_per_step(void* handle) {
     return n;
 }
 
+// Completion slots of a pipelined step: its launches alternate between two streams whose graphs are replayed step after step, so
+// a step must hold an EVEN number of them -- multi-head engines (5 L + 2 launches) end in one pad launch that only waits and publishes.
+static int pipe_slots(const JbEngine* e) { const int n = jb_engine_launches_per_step((void*)e); return n + (n & 1); }
+__global__ void pipe_pad_kernel(JbPipe pipe) {
+    const unsigned own = jb_pipe_own(pipe);
+    jb_pipe_wait(pipe, own);
+    jb_pipe_publish(pipe, own);
+}
+
 #define JB_TRY(call)                \
     do {                            \
         int rc__ = (call);          \
@@ -187,7 +196,7 @@ static int enqueue_embed(JbEngine* e, int t0, hipStream_t s) {
 static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
     const jb_engine_cfg& c = e->cfg;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
-    const int n_slots = jb_engine_launches_per_step(e);
+    const int n_slots = pipe_slots(e);
     int slot = 0;
     // completion protocol (common.h): 1 -- a flag word per ticket shard, polled by eight lanes -- for engines of >= 8 samples
     // (every launch of their step has >= 8 workgroups, so every shard has a member); 0 -- the two-level ticket with one flag --
@@ -265,6 +274,13 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
         if (mine) JB_TRY(jb_sample_step_impl(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds,
                                              c.preds_n_stride, c.dtype, c.x_a, c.x_emb, c.pos_emb, c.x_cond, c.xc_n_stride,
                                              c.xc_t_stride, W, c.seq_len, c.ticket, pipe, s));
+    }
+    if (slot < n_slots) {                      // an odd number of launches: the pad launch makes the step's slots even (pipe_slots)
+        const JbPipe* pipe = next();
+        if (pipe && mine) {
+            pipe_pad_kernel<<<8, 64, 0, s>>>(*pipe);
+            JB_CHECK_LAUNCH();
+        }
     }
     return JB_OK;
 }
@@ -370,7 +386,7 @@ static int streams_overlap(hipStream_t a, hipStream_t b, unsigned* scratch /* de
 // with that mask: two masks that differ (each all compute units but one) are two queues of their own.  The
 // pair is still verified with the handshake above.  The caller's stream only forks to and joins from them with events.
 static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mutex
-    unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(jb_engine_launches_per_step(e)) - JB_PIPE_PAD + 8;
+    unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(pipe_slots(e)) - JB_PIPE_PAD + 8;
     // every pair of the process gets two masks nobody else has (each leaves out ONE compute unit): should the runtime key
     // hardware queues by mask, two engines' pairs still never meet in one queue
     static int g_pairs = 0;
@@ -401,8 +417,6 @@ static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mu
 
 // The engine's pair of streams and its two parity graphs (once).
 static int prepare_pipeline(JbEngine* e) {
-    const int n_slots = jb_engine_launches_per_step(e);
-    JB_REQUIRE(n_slots % 2 == 0, "pipelined launches need an even number of launches per step");
     if (e->pstream[0] && e->pexec[0] && e->pexec[1]) return JB_OK;
     // one engine at a time: the handshake synchronises, and another thread's synchronous calls must not fall into this
     // thread's capture
@@ -431,7 +445,7 @@ static int prepare_pipeline(JbEngine* e) {
 // ~130 steps of every call whenever its hardware queue shared a pipe with one of the pair's: profiles/r04_pipe_in_job.log,
 // cases B / E against A / D).  The calling thread belongs to this level anyway.
 static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s, bool use_graph = true) {
-    const int n_slots = jb_engine_launches_per_step(e);
+    const int n_slots = pipe_slots(e);
     JB_TRY(prepare_pipeline(e));
     // completion counts and tickets start from zero in every call
     JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));
