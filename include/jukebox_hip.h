@@ -112,6 +112,10 @@ void jb_tune_gemm_lds(int min_rows);
 /* fp16 problems of one tap at unit strides (rows = (sequence, position), any pitch between sequences) with at least
  * `min_rows` output rows use the LDS-DMA 128x128-tile kernel (default 256; < 0: never).  Bit-identical to the other kernels. */
 void jb_tune_gemm_glds(int min_rows);
+/* fp16 decode projections over 129 .. 160 k-tiles (5b_lyrics, K = 4800; <= 16 rows): 1 = 8-wave workgroups that walk their
+ * k-tiles through two register stages (two workgroups per compute unit, every column tile resident at once), 0 = the 16-wave
+ * kernels (default).  Another summation order: results agree to rounding, not bit for bit. */
+void jb_tune_gemv_long(int on);
 
 /* Weight-streaming skinny GEMM for the decode step (n_rows <= 64): out = act(LN?(x) @ W + b) (+ res),
  * one workgroup per 16 output columns, waves split K.  With ln_gamma != NULL the LayerNorm of

@@ -1276,6 +1276,143 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     }
 }
 
+// Long rows (129 .. 160 k-tiles: 5b_lyrics, K = 4800) on workgroups that leave room.  The 16-wave kernels above keep every
+// fragment of a tile in registers: one workgroup fills a compute unit, the 300 column tiles of a 4800-wide projection take two
+// rounds on 256 compute units, and the next launch of a pipelined chain is never resident while this one streams (round 4:
+// pipelined launches bit-identical and no faster, profiles/r04_multi_head_pipelined_bench_engine_5b.log).  Here a tile is 8 waves
+// and a wave walks its <= NF * NB k-tiles through TWO register stages of NF fragments: the fragments of batches 0 and 1 are
+// requested up front, batch b + 2 is requested into a stage as soon as batch b has been multiplied out of it -- the same bytes
+// in flight per wave as before, half the waves per tile, two tiles per compute unit, all 300 resident at once.  MT = 1 (<= 16 rows),
+// whole k-tiles, aligned rows (the callers' fast-path conditions).  LNF: folded LayerNorm (statistics on the matrix cores, as
+// gemv_lnf_kernel); else the plain projection (bias / activation / residual / second output, as gemv_kernel).  The partial tiles of
+// 8 waves are summed in wave order: results differ from the 16-wave kernels' in the last bits (another association), not in accuracy.
+template <typename T, int NW, int NF, int NB, bool LNF, bool PIPE>
+__global__ __launch_bounds__(NW * 64) void gemv_long_kernel(GemvParams p) {
+    using V = typename Frag<T>::vec;
+    constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
+    static_assert(NB >= 2, "two register stages");
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    f32x4* s_acc = reinterpret_cast<f32x4*>(s_dyn);                               // [NW][64]
+    float* s_sum = reinterpret_cast<float*>(s_dyn + NW * 64 * sizeof(f32x4));     // [NW][16]   (LNF)
+    float* s_sq = s_sum + NW * 16;                                                // [NW][16]   (LNF)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int jt = blockIdx.x;
+    const T* x = (const T*)p.x;
+    const int kt0 = (wave * p.nkt) / NW, kt1 = ((wave + 1) * p.nkt) / NW;
+    const T* wbase = (const T*)p.W + ((int64_t)jt * p.nkt) * (64 * E) + (int64_t)lane * E;
+    const int64_t xrow = (int64_t)min(c, p.n_rows - 1) * p.ldx;
+
+    V wf[2][NF], xf[2][NF];
+    auto issue_w = [&](int st, int b) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+            wf[st][i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)min(kt0 + b * NF + i, p.nkt - 1) * (64 * E)));
+    };
+    auto issue_x = [&](int st, int b) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int k0 = min(kt0 + b * NF + i, p.nkt - 1) * KT + g * E;
+            if constexpr (PIPE) xf[st][i] = jb_ld_frag_sc1<T>(x, xrow + k0);      // the producer launch's rows
+            else xf[st][i] = ld_frag<T>(x + xrow + k0);
+        }
+    };
+    unsigned pipe_own = 0;
+    if constexpr (PIPE) pipe_own = jb_pipe_own(p.pipe);
+    // the position (k / v append, the last layer's cond row) is asked for FIRST: the second output's operand needs it for its address,
+    // and a request made behind the weights would make that address wait for all of them.  (PIPE: it is the producer's, after the wait.)
+    int t = 0;
+    if constexpr (!PIPE) { if (p.epi.qkv_split || p.epi.add2) t = *p.t_dev; }
+    // requests complete in the order they were made: ask in the order of use (batch 0's weights and rows, then batch 1's), so that
+    // waiting for batch 0 leaves batch 1 in flight.  PIPE: the rows can only be asked for after the wait; the weights go first.
+    if constexpr (PIPE) { issue_w(0, 0); issue_w(1, 1); }
+    else { issue_w(0, 0); issue_x(0, 0); jb_issue_fence(); issue_w(1, 1); issue_x(1, 1); }
+    EpiOperands<T, 1, NW * 64, PIPE> eo;        // 256 output elements: one per thread of the first four waves (EPT = 1 for NW >= 4)
+    eo.request(p, jt, 1);
+    jb_issue_fence();
+    if constexpr (PIPE) {
+        jb_pipe_wait(p.pipe, pipe_own);
+        issue_x(0, 0);
+        issue_x(1, 1);
+    }
+    if constexpr (PIPE) { if (p.epi.qkv_split || p.epi.add2) t = (int)jb_ld_word(reinterpret_cast<const unsigned*>(p.t_dev)); }
+    float e_add2 = 0.f;
+    if constexpr (!LNF) {
+        int emt, er, el;
+        epi_coords<PIPE>(threadIdx.x, emt, er, el);
+        const int row = el & 15, j = jt * 16 + (el >> 4) * 4 + er;
+        const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
+        e_add2 = p.epi.add2 ? p.epi.add2[(int64_t)rc * p.epi.add2_n + (int64_t)t * p.epi.add2_t + jc] : 0.f;
+    }
+
+    V ones;
+#pragma unroll
+    for (int e = 0; e < E; ++e) ones[e] = (T)1.0f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, a1 = acc, a2 = acc;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int st = b & 1;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const bool valid = kt0 + b * NF + i < kt1;                        // tiles past the wave's range: loaded (clamped), zeroed
+            if constexpr (LNF) {
+                const V xm = keep_frag<T>(valid, xf[st][i]);
+                acc = jb_mfma(wf[st][i], xm, acc);
+                a1 = jb_mfma(ones, xm, a1);
+                a2 = jb_mfma(xm, xm, a2);
+            } else {
+                acc = jb_mfma(keep_frag<T>(valid, wf[st][i]), xf[st][i], acc);
+            }
+        }
+        // the stage is free: request batch b + 2 NOW, before the other stage is multiplied (scheduling barriers pin the requests between
+        // the two batches' MFMAs; without them the scheduler sank every reload behind the multiplication of both first batches)
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 2 < NB) { issue_w(st, b + 2); issue_x(st, b + 2); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    s_acc[wave * 64 + lane] = acc;
+    if constexpr (LNF) {
+        if (g == 0) s_sum[wave * 16 + c] = a1[0];
+        if (g == (c >> 2)) {                            // this lane holds the Gram diagonal of row c in register c & 3
+            const int r = c & 3;
+            s_sq[wave * 16 + c] = r == 0 ? a2[0] : (r == 1 ? a2[1] : (r == 2 ? a2[2] : a2[3]));
+        }
+    }
+    __syncthreads();
+    eo.finish(p);
+    const float* sa = reinterpret_cast<const float*>(s_acc);
+    if (wave < 4) {
+        int mt, r, l;
+        epi_coords<PIPE>(threadIdx.x, mt, r, l);
+        const int row = l & 15, j = jt * 16 + (l >> 4) * 4 + r;
+        float v = 0.f, sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            v += sa[(w * 64 + l) * 4 + r];
+            if constexpr (LNF) { sm += s_sum[w * 16 + row]; sq += s_sq[w * 16 + row]; }
+        }
+        if constexpr (LNF) {
+            const float mean = sm / (float)p.K;
+            const float var = fmaxf(sq / (float)p.K - mean * mean, 0.f);
+            v = (v - mean * eo.c1[0]) / sqrtf(var + p.ln_eps);
+        }
+        const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
+        if constexpr (PIPE) {
+            const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
+            pipe_store4<T>(p.epi, xo, xo + e_add2, row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J);
+        } else if (row < p.n_rows && j < p.epi.J) {
+            epilogue_store1<T>(p.epi, v, row, j, cache_row, eo.bias[0], eo.res[0], e_add2);
+        }
+    }
+    if constexpr (PIPE) jb_pipe_publish(p.pipe, pipe_own);
+}
+
+// 1: rows of 129 .. 160 k-tiles (fp16, <= 16 rows) take gemv_long_kernel (8 waves, two register stages) instead of the 16-wave
+// kernels; 0: the 16-wave kernels (default until the 8-wave form has been measured on the GPU: jb_tune_gemv_long)
+static int g_gemv_long = 0;
+extern "C" void jb_tune_gemv_long(int on) { g_gemv_long = on; }
+
 // attn.c_proj of the decode step fed by the KEY-SPLIT decode attention (jb_attn_decode_split): the B operand rows are
 // formed on the fly from the n_parts (<= 4) partial softmax states of each (sample, head) --
 //     x[n][k] = sum_s w_s * parts[n][s][k],   w_s = l_s * exp(m_s - m) / sum_s' l_s' * exp(m_s' - m),  m = max_s m_s
@@ -1438,6 +1575,14 @@ static int launch_gemv_lnf(const GemvParams& p, int njt, int nf, int nw, hipStre
     const int mt = (p.n_rows + 15) / 16;
     if (nw == 16) {
         if (mt != 1) { jb_set_error("jb_gemv: folded LayerNorm over > 16 k-tiles per wave takes n_rows <= 16"); return JB_ERR_UNSUPPORTED; }
+        if constexpr (sizeof(T) == 2) {
+            if (g_gemv_long && p.nkt <= 160) {          // 8 waves x 4 batches of 5 k-tiles
+                const size_t lds = (size_t)8 * 64 * sizeof(f32x4) + (size_t)2 * 8 * 16 * sizeof(float);
+                if (p.pipe.slot >= 0) gemv_long_kernel<T, 8, 5, 4, true, true><<<njt, 8 * 64, lds, s>>>(p);
+                else gemv_long_kernel<T, 8, 5, 4, true, false><<<njt, 8 * 64, lds, s>>>(p);
+                return JB_OK;
+            }
+        }
         return launch_gemv_lnf_nf<T, 1, 16>(p, njt, nf, s);
     }
     if (nw == 8) return mt == 1 ? launch_gemv_lnf_nf<T, 1, 8>(p, njt, nf, s) : launch_gemv_lnf_nf<T, 2, 8>(p, njt, nf, s);
@@ -1501,6 +1646,14 @@ static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
     int nw = p.nkt >= 32 ? 8 : 4;
     if (!ln && mt == 1 && p.fast && p.nkt > 128 && p.nkt <= 160) {
         p.lds_pitch = 0;
+        if constexpr (sizeof(T) == 2) {
+            if (g_gemv_long) {                          // 8 waves x 4 batches of 5 k-tiles
+                const size_t lds = (size_t)8 * 64 * sizeof(f32x4);
+                if (p.pipe.slot >= 0) gemv_long_kernel<T, 8, 5, 4, false, true><<<njt, 8 * 64, lds, s>>>(p);
+                else gemv_long_kernel<T, 8, 5, 4, false, false><<<njt, 8 * 64, lds, s>>>(p);
+                return JB_OK;
+            }
+        }
         if (p.pipe.slot >= 0) {
             if constexpr (sizeof(T) == 2) {
                 gemv_kernel<T, 1, 16, false, true, 0, true><<<njt, 16 * 64, (size_t)16 * 64 * sizeof(f32x4), s>>>(p);

@@ -221,8 +221,9 @@ def test_wide_value_engine_refuses_prefill_behind_decoded_positions(PE):
     assert int(eng.t_dev.item()) == 10
 
 
-@pytest.mark.parametrize("N,width,heads", [(16, 1920, 1), (3, 1920, 1), (3, 4800, 8), (8, 4800, 8), (16, 2048, 2)])
-def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, heads):
+@pytest.mark.parametrize("N,width,heads,long_rows", [(16, 1920, 1, 0), (3, 1920, 1, 0), (3, 4800, 8, 0), (8, 4800, 8, 0), (16, 2048, 2, 0),
+                                                     (3, 4800, 8, 1), (8, 4800, 8, 1)])
+def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, heads, long_rows):
     """Software-pipelined launches (jb_engine_pipeline: the launches of a step alternate between two streams, launch j+1
     waits on launch j's completion word instead of on a kernel boundary): same kernels' arithmetic in the same order, so
     logits and tokens are BIT-identical to the plain chain -- upsampler geometry (one 480-channel head, wide-value layers),
@@ -230,6 +231,8 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, hea
     share per GPU) runs completion protocol 1 (a flag word per ticket shard), N = 3 (config 5's) the two-level ticket.
     Multi-head engines (five launches per layer, MFMA decode attention): the 5b_lyrics geometry -- 4800 wide, 8 heads of 150
     channels, 16-wave projections -- at N = 3 / 8, and two heads of 256 channels at 2048 wide."""
+    from jukebox_amd import _lib as L
+    L.lib().jb_tune_gemv_long(long_rows)          # 1: the 4800-wide projections on 8-wave workgroups (gemv_long_kernel), both launch forms
     rng = np.random.default_rng(21)
     depth, bins, seq, blocks = (6 if width == 1920 else 3), 512, 1024, 16
     sd = to_dev(_random_sd(rng, width, depth, bins, seq, 2, scale=0.02 if width == 1920 else 0.012))
@@ -258,6 +261,7 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, hea
         assert eng.pipe_error() == 0
         outs[mode] = res
         eng.close()
+    L.lib().jb_tune_gemv_long(0)
     for (z0, p0), (z1, p1) in zip(outs["chain"], outs["pipelined"]):
         assert np.array_equal(z0, z1), "tokens differ between the plain chain and pipelined launches"
         assert np.array_equal(p0, p1), "logits differ between the plain chain and pipelined launches"

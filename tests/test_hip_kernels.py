@@ -384,6 +384,40 @@ def test_gemv_ln_folded(H, name, dt, tol, rows, K, J):
         assert relerr(got, cls.float().cpu().numpy()) < tol
 
 
+@pytest.mark.parametrize("rows,K,J", [(3, 4800, 272), (16, 4800, 64), (3, 4800, 4800), (8, 5120, 48), (3, 4128, 32)])
+def test_gemv_long_rows_on_8_waves(H, rows, K, J):
+    """jb_tune_gemv_long(1): projections over 129 .. 160 k-tiles (5b_lyrics, K = 4800) on 8-wave workgroups that walk their k-tiles
+    through two register stages (gemv_long_kernel) instead of the 16-wave kernels -- the folded-LayerNorm form and the plain form with
+    bias + residual, against the same references and bars as the 16-wave kernels, and against those kernels' own outputs (another
+    summation order of the eight / sixteen partial tiles: equal to output rounding)."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(rows * 11 + K + J)
+    dt, tol = torch.float16, 3e-3
+    x = h16(rng.standard_normal((rows, K)).astype(np.float32) * 1.5 + rng.standard_normal((rows, 1)).astype(np.float32) * 4)
+    W = h16((rng.standard_normal((K, J)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(J).astype(np.float32)
+    g = (1 + 0.2 * rng.standard_normal(K)).astype(np.float32)
+    be = (0.2 * rng.standard_normal(K)).astype(np.float32)
+    R = h16(rng.standard_normal((rows, J)).astype(np.float32))
+    f = H.FoldedLN(dev(W), dev(b), dev(g), dev(be), dt)
+    pw = H.pack_conv1d_w(dev(W), dt)
+    outs = {}
+    try:
+        for long_rows in (0, 1):
+            L.lib().jb_tune_gemv_long(long_rows)
+            folded = H.gemv(dev(x, dt), None, ln_fold=f, act=L.ACT_QUICK_GELU).float().cpu().numpy()
+            plain = H.gemv(dev(x, dt), pw, bias=dev(b), res=dev(R, dt)).float().cpu().numpy()
+            outs[long_rows] = (folded, plain)
+    finally:
+        L.lib().jb_tune_gemv_long(0)
+    want_f = O.quick_gelu(h16(h16(O.layer_norm(x, g, be)) @ W + h16(b)), fp16=True)
+    want_p = h16(R + h16(x @ W + h16(b)))
+    for long_rows in (0, 1):
+        assert relerr(outs[long_rows][0], want_f) < tol and relerr(outs[long_rows][1], want_p) < tol, long_rows
+    assert relerr(outs[1][0], outs[0][0]) < 1e-3 and relerr(outs[1][1], outs[0][1]) < 1e-3
+    assert not np.array_equal(outs[1][1], np.zeros_like(outs[1][1]))
+
+
 def test_gemv_ln_folded_rejects_unsupported_shapes(H):
     from jukebox_amd import _lib as L
     assert not H.ln_fold_supported(torch.float16, 100, 64, 16)        # K not a whole number of k-tiles
