@@ -172,12 +172,18 @@ __global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ld
 // are zeroed, which removes their products whatever the key registers hold.  Heads start at odd multiples of 4 bytes,
 // so the 16-byte loads are only dword-aligned (global memory takes that).
 typedef f16x8 __attribute__((aligned(4))) f16x8_a4;
-template <int ND32, bool RAGGED>
+// PIPE: one launch of a software-pipelined chain (common.h, JbPipe; multi-head engines): the query and this position's k / v rows
+// are the producer launch's (c_attn), so the launch waits first and then reads the query and EVERY cache row write-through (sc1)
+// -- simpler than the wide kernel's split into earlier rows (plain, before the wait) and the new row; what pipelining hides here
+// is the launch itself.  The output leaves write-through, then the workgroup publishes.
+template <int ND32, bool RAGGED, bool PIPE = false>
 __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f16* __restrict__ q, int64_t ldq,
                                                                const f16* __restrict__ kc, const f16* __restrict__ vc, int cap,
                                                                f16* __restrict__ out, int64_t ldo, int n_head, int bc,
-                                                               const int* __restrict__ t_dev, int d_head) {
+                                                               const int* __restrict__ t_dev, int d_head, JbPipe pipe) {
     const int d = RAGGED ? d_head : ND32 * 32;
+    unsigned pipe_own = 0;
+    if constexpr (PIPE) { pipe_own = jb_pipe_own(pipe); jb_pipe_wait(pipe, pipe_own); }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* s_ml = smem;                      // [nw][2]
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     for (int dt = 0; dt < ND32; ++dt) {
         const int cb = dt * 32 + g * 8;
         foff[dt] = RAGGED ? min(cb, d - 8) : cb;
-        qf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(qrow + foff[dt]) : ld_frag<f16>(qrow + cb);
+        if constexpr (PIPE) qf[dt] = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + h * d + foff[dt]);
+        else qf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(qrow + foff[dt]) : ld_frag<f16>(qrow + cb);
     }
     jb_issue_fence();
     if constexpr (RAGGED) {
@@ -211,13 +218,17 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     const KeySet ks = decode_key_set(func, t, bc, cap);
     f16* o = out + (int64_t)n * ldo + h * d;
     if (ks.count == 0) {
-        for (int i = threadIdx.x; i < d; i += blockDim.x) o[i] = (f16)0;
+        for (int i = threadIdx.x; i < d; i += blockDim.x) {
+            if constexpr (PIPE) jb_st_sc1(out, (int64_t)n * ldo + h * d + i, (f16)0); else o[i] = (f16)0;
+        }
+        if constexpr (PIPE) jb_pipe_publish(pipe, pipe_own);
         return;
     }
     const float scale = 1.0f / sqrtf(sqrtf((float)d));
     const float scale2 = scale * scale;
     const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
     const f16* vbase = vc + ((int64_t)n * cap) * S + h * d;
+    const int64_t kv0 = ((int64_t)n * cap) * S + h * d;       // (PIPE: element offset of this (sample, head)'s rows in either cache)
     const int c0 = min(lane * 8, d - 8);     // this lane's value channels (lanes past d/8 compute unused duplicates)
 
     float m_w = -INFINITY, l_w = 0.f;
@@ -234,14 +245,17 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
         const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * S;
         f16x8 kf[ND32];
 #pragma unroll
-        for (int dt = 0; dt < ND32; ++dt)
-            kf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(kr + foff[dt]) : ld_frag<f16>(kr + dt * 32 + g * 8);
+        for (int dt = 0; dt < ND32; ++dt) {
+            if constexpr (PIPE) kf[dt] = jb_ld_frag_sc1<f16>(kc, kv0 + (int64_t)(ks.start + ki * ks.stride) * S + foff[dt]);
+            else kf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(kr + foff[dt]) : ld_frag<f16>(kr + dt * 32 + g * 8);
+        }
         f16x8 vv[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int vi = min(kbase_i + k, ks.count - 1);
             const f16* vr = vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0;
-            vv[k] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(vr) : ld_frag<f16>(vr);
+            if constexpr (PIPE) vv[k] = jb_ld_frag_sc1<f16>(vc, kv0 + (int64_t)(ks.start + vi * ks.stride) * S + c0);
+            else vv[k] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(vr) : ld_frag<f16>(vr);
         }
         jb_issue_fence_before_use(qf[0]);        // K fragments AND value rows are in flight before the QK^T chain starts
         // ---- scores of keys g*4 + r (identical in all 16 columns) ----
@@ -298,8 +312,9 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
         float a = 0.f;
         for (int w = 0; w < nw; ++w) a += s_o[w * d + i] * expf(s_ml[2 * w] - m);
-        o[i] = (f16)(a * inv);
+        if constexpr (PIPE) jb_st_sc1(out, (int64_t)n * ldo + h * d + i, (f16)(a * inv)); else o[i] = (f16)(a * inv);
     }
+    if constexpr (PIPE) jb_pipe_publish(pipe, pipe_own);
 }
 
 // Wide-value variant for single-head layers (the upsamplers): the cache row of a key holds v' = v·Wp (W channels), the
@@ -776,6 +791,20 @@ int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const vo
 extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache,
                               const void* vcache, int cache_cap, void* out, int64_t ldo, int n_batch, int n_head,
                               int d_head, int block_ctx, const int* t_dev, int max_len, void* stream) {
+    return jb_attn_decode_impl(dtype, attn_func, q, ldq, kcache, vcache, cache_cap, out, ldo, n_batch, n_head, d_head, block_ctx,
+                               t_dev, max_len, nullptr, stream);
+}
+
+// 1 if a pipelined launch of the decode attention exists for this head size (the MFMA kernels' instantiations below)
+int jb_attn_decode_pipe_supported(int dtype, int d_head, int ldq, int ldo, int S) {
+    if (dtype != JB_F16 || !g_dec_mfma) return 0;
+    if (d_head % 32 != 0) return d_head % 2 == 0 && d_head > 128 && d_head < 160 && ldq % 2 == 0 && ldo % 2 == 0;
+    return (d_head == 256 || d_head == 512) && ldq % 8 == 0 && S % 8 == 0;
+}
+
+int jb_attn_decode_impl(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache,
+                        const void* vcache, int cache_cap, void* out, int64_t ldo, int n_batch, int n_head,
+                        int d_head, int block_ctx, const int* t_dev, int max_len, const JbPipe* pipe, void* stream) {
     JB_REQUIRE(q && kcache && vcache && out && t_dev, "null pointer");
     JB_REQUIRE(dtype == JB_F32 || dtype == JB_F16, "bad dtype");
     JB_REQUIRE(n_batch > 0 && n_head > 0 && d_head > 0 && max_len > 0, "bad dims");
@@ -790,24 +819,46 @@ extern "C" int jb_attn_decode(int dtype, int attn_func, const void* q, int64_t l
     (void)max_len;
     dim3 grid(n_batch, n_head);
     hipStream_t s = (hipStream_t)stream;
+    const JbPipe nopipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr};
+    JB_REQUIRE(!pipe || (jb_attn_decode_pipe_supported(dtype, d_head, (int)ldq, (int)ldo, n_head * d_head) &&
+                         (int64_t)n_batch * cache_cap * n_head * d_head < (1ll << 30)),
+               "a pipelined launch of the decode attention takes fp16 heads of 150 (ragged), 256 or 512 channels and caches below 2 GiB");
     if (dtype == JB_F16 && g_dec_mfma && d_head % 32 != 0 && d_head % 2 == 0 && d_head > 128 && d_head < 160 && ldq % 2 == 0 &&
         ldo % 2 == 0) {
         // ragged head size in 5 k-tiles (5b_lyrics: 150 channels per head)
         const int nwm = 8;
         size_t ldsm = (size_t)(2 * nwm + 16 * nwm + nwm * d_head) * sizeof(float);
-        attn_decode_mfma_kernel<5, true><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
-                                                                    (const f16*)vcache, cache_cap, (f16*)out, ldo, n_head,
-                                                                    block_ctx, t_dev, d_head);
+        if (pipe)
+            attn_decode_mfma_kernel<5, true, true><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+                                                                              (const f16*)vcache, cache_cap, (f16*)out, ldo, n_head,
+                                                                              block_ctx, t_dev, d_head, *pipe);
+        else
+            attn_decode_mfma_kernel<5, true><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+                                                                        (const f16*)vcache, cache_cap, (f16*)out, ldo, n_head,
+                                                                        block_ctx, t_dev, d_head, nopipe);
         JB_CHECK_LAUNCH();
         return JB_OK;
     }
     if (dtype == JB_F16 && g_dec_mfma && d_head % 32 == 0 && d_head <= 512 && ldq % 8 == 0 && (n_head * d_head) % 8 == 0) {
         const int nwm = 8;
         size_t ldsm = (size_t)(2 * nwm + 16 * nwm + nwm * d_head) * sizeof(float);
+        if (pipe) {
+            if (d_head == 256)
+                attn_decode_mfma_kernel<8, false, true><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+                                                                                   (const f16*)vcache, cache_cap, (f16*)out, ldo,
+                                                                                   n_head, block_ctx, t_dev, d_head, *pipe);
+            else if (d_head == 512)
+                attn_decode_mfma_kernel<16, false, true><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+                                                                                    (const f16*)vcache, cache_cap, (f16*)out, ldo,
+                                                                                    n_head, block_ctx, t_dev, d_head, *pipe);
+            else JB_UNSUPPORTED("a pipelined launch of the decode attention takes heads of 150 (ragged), 256 or 512 channels");
+            JB_CHECK_LAUNCH();
+            return JB_OK;
+        }
 #define JB_LAUNCH_DECM(ND)                                                                                      \
     attn_decode_mfma_kernel<ND, false><<<grid, nwm * 64, ldsm, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache, \
                                                            (const f16*)vcache, cache_cap, (f16*)out, ldo, n_head, \
-                                                           block_ctx, t_dev, d_head)
+                                                           block_ctx, t_dev, d_head, nopipe)
         switch (d_head / 32) {
             case 1: JB_LAUNCH_DECM(1); break;
             case 2: JB_LAUNCH_DECM(2); break;

@@ -284,6 +284,10 @@ __device__ __forceinline__ void jb_pipe_publish(const JbPipe& P, unsigned own) {
 
 // library-internal forms of the decode step's launches that take a pipeline slot (pipe == NULL: the exported behaviour)
 int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream);
+int jb_attn_decode_impl(int dtype, int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache, int cache_cap,
+                        void* out, int64_t ldo, int n_batch, int n_head, int d_head, int block_ctx, const int* t_dev, int max_len,
+                        const JbPipe* pipe, void* stream);
+int jb_attn_decode_pipe_supported(int dtype, int d_head, int ldq, int ldo, int S);
 int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache_w, int cache_cap,
                              const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
                              int width, int block_ctx, const int* t_dev, int max_len, const JbPipe* pipe, void* stream);

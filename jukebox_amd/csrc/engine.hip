@@ -143,6 +143,15 @@ extern "C" int jb_engine_launches_per_step(void* handle) {
     return n;
 }
 
+// Completion slots of a pipelined step: its launches alternate between two streams whose graphs are replayed step after step, so
+// a step must hold an EVEN number of them -- multi-head engines (5 L + 2 launches) end in one pad launch that only waits and publishes.
+static int pipe_slots(const JbEngine* e) { const int n = jb_engine_launches_per_step((void*)e); return n + (n & 1); }
+__global__ void pipe_pad_kernel(JbPipe pipe) {
+    const unsigned own = jb_pipe_own(pipe);
+    jb_pipe_wait(pipe, own);
+    jb_pipe_publish(pipe, own);
+}
+
 #define JB_TRY(call)                \
     do {                            \
         int rc__ = (call);          \
@@ -212,7 +221,7 @@ static int enqueue_embed(JbEngine* e, int t0, hipStream_t s) {
 static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
     const jb_engine_cfg& c = e->cfg;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
-    const int n_slots = jb_engine_launches_per_step(e);
+    const int n_slots = pipe_slots(e);
     int slot = 0;
     // completion protocol (common.h): 1 -- a flag word per ticket shard, polled by eight lanes -- for engines of >= 8 samples
     // (every launch of their step has >= 8 workgroups, so every shard has a member); 0 -- the two-level ticket with one flag --
@@ -246,21 +255,25 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
             const JbPipe* pipe = next();
             if (mine) JB_TRY(jb_attn_decode_wide_impl(L.attn_func, c.q, S, L.kcache, L.vcache_w, L.cache_cap, c.x_a, W, L.b_proj, c.x_b,
                                                       W, N, S, W, c.block_ctx, c.t_dev, c.seq_len, pipe, s));
-        } else if (parity >= 0) {
-            jb_set_error("jb_engine: pipelined launches need wide-value layers throughout");
-            return JB_ERR_UNSUPPORTED;
         } else if (parts > 0) {
+            if (parity >= 0) {
+                jb_set_error("jb_engine: the key-split attention has no pipelined form");
+                return JB_ERR_UNSUPPORTED;
+            }
+            (void)next();
             JB_TRY(jb_attn_decode_split(L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att_parts, c.att_ml, N, H, d,
                                         c.block_ctx, c.t_dev, layer_max_keys(c, L), parts, s));
             g.x_parts = c.att_parts; g.x_ml = c.att_ml; g.n_parts = parts; g.n_head = H; g.d_head = d;
         } else {
-            JB_TRY(jb_attn_decode(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, att_ld, N, H, d,
-                                  c.block_ctx, c.t_dev, c.seq_len, s));
+            // multi-head layers: attention into c.att (pitch att_ld, pad columns stay zero), then attn.c_proj + residual
+            const JbPipe* pipe = next();
+            if (mine) JB_TRY(jb_attn_decode_impl(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, att_ld, N, H, d,
+                                                 c.block_ctx, c.t_dev, c.seq_len, pipe, s));
             g.x = c.att; g.ldx = att_ld;
             const int KT = c.dtype == JB_F16 ? 32 : 16;
             if (att_ld % KT == 0 && att_ld - S < KT) g.K = att_ld;
         }
-        if (!layer_wide(c, L)) JB_TRY(jb_gemv(&g, s));
+        if (!layer_wide(c, L)) { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
         // ln_1 + mlp.c_fc + quick_gelu
         g = {};
         fill_ln_proj(g, c, L, 1);
@@ -287,13 +300,38 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
                                              c.preds_n_stride, c.dtype, c.x_a, c.x_emb, c.pos_emb, c.x_cond, c.xc_n_stride,
                                              c.xc_t_stride, W, c.seq_len, c.ticket, pipe, s));
     }
+    if (slot < n_slots) {                      // an odd number of launches: the pad launch makes the step's slots even (pipe_slots)
+        const JbPipe* pipe = next();
+        if (pipe && mine) {
+            pipe_pad_kernel<<<8, 64, 0, s>>>(*pipe);
+            JB_CHECK_LAUNCH();
+        }
+    }
     return JB_OK;
 }
 
 // Software-pipelined launches of the decode step.  Available where every launch of the step has a
 // pipelined form: fp16, <= 16 samples, wide-value layers throughout (one head of 480 channels), widths of 33..64 k-tiles.
+// ... or (multi-head engines: 5b_lyrics' top prior) five launches per layer with the MFMA decode attention: fp16, <= 16 samples, folded
+// LayerNorm, no key-split layer, heads of 150 (ragged) / 256 / 512 channels, projections of 33..64 or 129..160 k-tiles.
+static bool pipeline_eligible_multi_head(const JbEngine* e) {
+    const jb_engine_cfg& c = e->cfg;
+    if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || !c.x_out_packed || c.width % 32 || c.n_mlp % 32) return false;
+    const int att_ld = c.att_ld ? c.att_ld : c.n_state, d = c.n_state / c.n_head;
+    auto lnf_ok = [](int nkt) { return (nkt >= 33 && nkt <= 64) || (nkt >= 129 && nkt <= 160); };
+    auto proj_ok = [](int nkt) { return nkt >= 1; };              // 4 / 8 waves (any length) or 16 waves (129..160 k-tiles), fp16
+    const int nkt_logits = c.width / 16;                          // fp32 head: no 16-wave pipelined form
+    if (!lnf_ok(c.width / 32) || att_ld % 32 || !proj_ok(att_ld / 32) || att_ld - c.n_state >= 32 || !proj_ok(c.n_mlp / 32) ||
+        (nkt_logits > 128 && nkt_logits <= 160)) return false;
+    if (!jb_attn_decode_pipe_supported(c.dtype, d, c.n_state, att_ld, c.n_state)) return false;
+    for (const jb_layer& L : e->layers)
+        if (layer_wide(c, L) || layer_split_parts(c, L) != 0 || !L.w_attn_f || !L.w_fc_f) return false;
+    return true;
+}
+
 static bool pipeline_eligible(const JbEngine* e) {
     const jb_engine_cfg& c = e->cfg;
+    if (pipeline_eligible_multi_head(e)) return true;
     if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || c.n_head != 1 || c.n_state != 480 || !c.x_out_packed) return false;
     if (c.width % 32 || c.n_mlp % 32 || c.width / 32 < 33 || c.width / 32 > 64 || c.n_mlp / 32 < 33 || c.n_mlp / 32 > 64) return false;
     for (const jb_layer& L : e->layers)
@@ -305,7 +343,8 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     JB_REQUIRE(handle, "null engine");
     JbEngine* e = (JbEngine*)handle;
     if (enable && !pipeline_eligible(e)) JB_UNSUPPORTED("this engine's decode step has launches without a pipelined form (needs pipe_words, "
-                                                        "fp16, <= 16 samples, wide-value layers of one 480-channel head, 33..64 k-tiles)");
+                                                        "fp16, <= 16 samples, and either wide-value layers of one 480-channel head on "
+                                                        "33..64 k-tiles or folded-LayerNorm multi-head layers without key splits)");
     // At most TWO pipelined engines per process.  A waiting launch holds up to 180 workgroup slots (8 waves at 88 registers per
     // lane: two such workgroups fill a compute unit) while it spins, and the producer it waits for must still find room.  The
     // waiters of two engines take <= 360 of the chip's 512 such slots, so >= 152 compute units keep half of their registers
@@ -317,9 +356,13 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     JB_REQUIRE(enable >= 0 && enable <= 2, "enable must be 0, 1 or 2");
     std::lock_guard<std::mutex> lock(g_pipe_mutex);
     if (enable) {
-        if (!pipe_owner(e) && !jb_attn_decode_wide_lean() && (g_pipe_owners[0] || g_pipe_owners[1]))
-            JB_UNSUPPORTED("another engine of this process runs pipelined launches, and the fat attention kernel "
-                           "(jb_tune_attn_decode_wide_lean(0)) admits one at a time");
+        // (multi-head engines -- 16-wave attention and projection workgroups that fill a compute unit -- share with nobody)
+        const bool other = (g_pipe_owners[0] && g_pipe_owners[0] != e) || (g_pipe_owners[1] && g_pipe_owners[1] != e);
+        bool other_multi_head = false;
+        for (void* o : g_pipe_owners) other_multi_head = other_multi_head || (o && o != e && pipeline_eligible_multi_head((JbEngine*)o));
+        if (other && (!jb_attn_decode_wide_lean() || pipeline_eligible_multi_head(e) || other_multi_head))
+            JB_UNSUPPORTED("another engine of this process runs pipelined launches, and only two single-head engines on the lean "
+                           "attention kernel (jb_tune_attn_decode_wide_lean(1)) can share the GPU that way");
         if (!pipe_own(e)) JB_UNSUPPORTED("two other engines of this process run pipelined launches (two at a time: switch one off "
                                          "or destroy it first)");
         if (enable == 2) release_pipeline(e);   // a fresh pair of streams and fresh graphs at the next decode
@@ -379,7 +422,7 @@ static int streams_overlap(hipStream_t a, hipStream_t b, unsigned* scratch /* de
 // pair is still verified with the handshake above.  The caller's stream never waits on them: a pipelined decode drains the
 // caller's stream, runs on the pair and returns when the pair is done (decode_pipelined).
 static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mutex
-    unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(jb_engine_launches_per_step(e)) - JB_PIPE_PAD + 8;
+    unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(pipe_slots(e)) - JB_PIPE_PAD + 8;
     // every pair of the process gets two masks nobody else has (each leaves out ONE compute unit): should the runtime key
     // hardware queues by mask, two engines' pairs still never meet in one queue
     static int g_pairs = 0;
@@ -410,8 +453,6 @@ static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mu
 
 // The engine's pair of streams and its two parity graphs (once).
 static int prepare_pipeline(JbEngine* e) {
-    const int n_slots = jb_engine_launches_per_step(e);
-    JB_REQUIRE(n_slots % 2 == 0, "pipelined launches need an even number of launches per step");
     if (e->pstream[0] && e->pexec[0] && e->pexec[1]) return JB_OK;
     // one engine at a time: the handshake synchronises, and another thread's synchronous calls must not fall into this
     // thread's capture
@@ -440,7 +481,7 @@ static int prepare_pipeline(JbEngine* e) {
 // ~130 steps of every call whenever its hardware queue shared a pipe with one of the pair's: profiles/r04_pipe_in_job.log,
 // cases B / E against A / D).  The calling thread belongs to this level anyway.
 static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s, bool use_graph = true) {
-    const int n_slots = jb_engine_launches_per_step(e);
+    const int n_slots = pipe_slots(e);
     JB_TRY(prepare_pipeline(e));
     // completion counts and tickets start from zero in every call
     JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));

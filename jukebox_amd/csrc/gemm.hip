@@ -1578,7 +1578,10 @@ static int launch_gemv_lnf_nf(const GemvParams& p, int njt, int nf, hipStream_t 
         if constexpr (MT == 1 && NW == 8 && sizeof(T) == 2) {
             if (nf == 8) { gemv_lnf_kernel<T, 1, 8, 8, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
         }
-        jb_set_error("jb_gemv: a pipelined launch of the folded-LayerNorm projection takes fp16, <= 16 rows, 33..64 k-tiles");
+        if constexpr (MT == 1 && NW == 16 && sizeof(T) == 2) {       // 129 .. 160 k-tiles (5b_lyrics: K = 4800)
+            if (nf == 10) { gemv_lnf_kernel<T, 1, 16, 10, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+        }
+        jb_set_error("jb_gemv: a pipelined launch of the folded-LayerNorm projection takes fp16, <= 16 rows, 33..64 or 129..160 k-tiles");
         return JB_ERR_UNSUPPORTED;
     }
     if (nf == 8) gemv_lnf_kernel<T, MT, NW, 8><<<njt, NW * 64, lds, s>>>(p);
@@ -1593,9 +1596,10 @@ static int launch_gemv_lnf(const GemvParams& p, int njt, int nf, int nw, hipStre
     if (nw == 16) {
         if (mt != 1) { jb_set_error("jb_gemv: folded LayerNorm over > 16 k-tiles per wave takes n_rows <= 16"); return JB_ERR_UNSUPPORTED; }
         if constexpr (sizeof(T) == 2) {
-            if (g_gemv_long && p.nkt <= 160 && p.pipe.slot < 0) {          // 8 waves x 4 batches of 5 k-tiles
+            if (g_gemv_long && p.nkt <= 160) {          // 8 waves x 4 batches of 5 k-tiles
                 const size_t lds = (size_t)8 * 64 * sizeof(f32x4) + (size_t)2 * 8 * 16 * sizeof(float);
-                gemv_long_kernel<T, 8, 5, 4, true, false><<<njt, 8 * 64, lds, s>>>(p);
+                if (p.pipe.slot >= 0) gemv_long_kernel<T, 8, 5, 4, true, true><<<njt, 8 * 64, lds, s>>>(p);
+                else gemv_long_kernel<T, 8, 5, 4, true, false><<<njt, 8 * 64, lds, s>>>(p);
                 return JB_OK;
             }
         }
@@ -1625,8 +1629,8 @@ static int launch_gemv_fast(const GemvParams& p, int njt, size_t lds, hipStream_
 template <typename T, int MT, int NW, bool LNS>
 static int launch_gemv_inst(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
     if (p.pipe.slot >= 0) {
-        if constexpr (MT == 1 && NW == 8 && !LNS) {
-            if (p.fast) { gemv_kernel<T, 1, 8, false, true, 0, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+        if constexpr (MT == 1 && (NW == 8 || NW == 4) && !LNS) {
+            if (p.fast) { gemv_kernel<T, 1, NW, false, true, 0, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
         }
         jb_set_error("jb_gemv: a pipelined launch of the plain projection takes <= 16 rows, >= 32 whole k-tiles, aligned operands");
         return JB_ERR_UNSUPPORTED;
@@ -1663,11 +1667,20 @@ static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
     if (!ln && mt == 1 && p.fast && p.nkt > 128 && p.nkt <= 160) {
         p.lds_pitch = 0;
         if constexpr (sizeof(T) == 2) {
-            if (g_gemv_long && p.pipe.slot < 0) {       // 8 waves x 4 batches of 5 k-tiles
+            if (g_gemv_long) {                          // 8 waves x 4 batches of 5 k-tiles
                 const size_t lds = (size_t)8 * 64 * sizeof(f32x4);
-                gemv_long_kernel<T, 8, 5, 4, false, false><<<njt, 8 * 64, lds, s>>>(p);
+                if (p.pipe.slot >= 0) gemv_long_kernel<T, 8, 5, 4, false, true><<<njt, 8 * 64, lds, s>>>(p);
+                else gemv_long_kernel<T, 8, 5, 4, false, false><<<njt, 8 * 64, lds, s>>>(p);
                 return JB_OK;
             }
+        }
+        if (p.pipe.slot >= 0) {
+            if constexpr (sizeof(T) == 2) {
+                gemv_kernel<T, 1, 16, false, true, 0, true><<<njt, 16 * 64, (size_t)16 * 64 * sizeof(f32x4), s>>>(p);
+                return JB_OK;
+            }
+            jb_set_error("jb_gemv: a pipelined launch of the 16-wave projection takes fp16");
+            return JB_ERR_UNSUPPORTED;
         }
         return launch_gemv_fast<T, 1, 16, false, true, 0>(p, njt, (size_t)16 * 64 * sizeof(f32x4), s);
     }

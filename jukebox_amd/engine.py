@@ -211,7 +211,8 @@ class PriorEngine:
             self.att_ml = e(N, self.H, 4, 2, dtype=torch.float32)
         # completion words of software-pipelined launches (jb_engine_pipeline): counts + tickets per launch slot, error word last
         # (+ room for the JB_PIPE_DEBUG stamps: 4 x int64 per slot behind the error group)
-        self.pipe_words = torch.zeros((18 * (5 * self.depth + 2) + 1) * 32 + (5 * self.depth + 2) * 8, dtype=torch.int32, device=dev)
+        # (an odd number of launches per step gets one pad slot: 5 * depth + 3 covers every engine)
+        self.pipe_words = torch.zeros((18 * (5 * self.depth + 3) + 1) * 32 + (5 * self.depth + 3) * 8, dtype=torch.int32, device=dev)
         self.pipelined = False
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -328,17 +329,17 @@ class PriorEngine:
     def pipe_stamps(self):
         """JB_PIPE_DEBUG=1: (n_slots, 4) int64 ticks of the 100 MHz clock of the last pipelined step: poll entered, producer
         seen, completion published."""
-        n = self.launches_per_step
+        n = self.pipe_slots
         base = (18 * n + 1) * 32
         return self.pipe_words[base:base + n * 8].view(torch.int64).reshape(n, 4).cpu().numpy()
 
     def pipe_error(self):
         """0, or slot + 1 of a pipelined launch whose wait for its producer timed out (sticky)."""
-        return int(self.pipe_words[18 * self.launches_per_step * 32].item())
+        return int(self.pipe_words[18 * self.pipe_slots * 32].item())
 
     def clear_pipe_error(self):
         """Forget a recorded timeout (the engine must be idle).  Until then every pipelined wait gives up at once."""
-        self.pipe_words[18 * self.launches_per_step * 32] = 0
+        self.pipe_words[18 * self.pipe_slots * 32] = 0
 
     def close(self):
         if getattr(self, "handle", None):
@@ -388,6 +389,12 @@ class PriorEngine:
         out = (C.c_double * 3)()
         L.check(L.lib().jb_engine_probe_projection(self.handle, t0, n_steps, L.stream(), out))
         return out[0], int(out[1]), out[2]
+
+    @property
+    def pipe_slots(self):
+        """Completion slots of a pipelined step: its launches, plus one pad launch when their number is odd (engine.hip)."""
+        n = self.launches_per_step
+        return n + (n & 1)
 
     @property
     def launches_per_step(self):

@@ -223,25 +223,30 @@ def test_wide_value_engine_refuses_prefill_behind_decoded_positions(PE):
     assert int(eng.t_dev.item()) == 10
 
 
-@pytest.mark.parametrize("N", [16, 3])
-def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N):
+@pytest.mark.parametrize("N,width,heads,long_rows", [(16, 1920, 1, 0), (3, 1920, 1, 0), (3, 4800, 8, 0), (8, 4800, 8, 0), (16, 2048, 2, 0),
+                                                     (3, 4800, 8, 1), (8, 4800, 8, 1)])
+def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, heads, long_rows):
     """Software-pipelined launches (jb_engine_pipeline: the launches of a step alternate between two streams, launch j+1
     waits on launch j's completion word instead of on a kernel boundary): same kernels' arithmetic in the same order, so
     logits and tokens are BIT-identical to the plain chain -- upsampler geometry (one 480-channel head, wide-value layers),
     primed window + sampled decode in several calls, then a second window on the same engine.  N = 16 (BASELINE config 4's
-    share per GPU) runs completion protocol 1 (a flag word per ticket shard), N = 3 (config 5's) the two-level ticket."""
+    share per GPU) runs completion protocol 1 (a flag word per ticket shard), N = 3 (config 5's) the two-level ticket.
+    Multi-head engines (five launches per layer, MFMA decode attention): the 5b_lyrics geometry -- 4800 wide, 8 heads of 150
+    channels, 16-wave projections -- at N = 3 / 8, and two heads of 256 channels at 2048 wide."""
+    from jukebox_amd import _lib as L
+    L.lib().jb_tune_gemv_long(long_rows)          # 1: the 4800-wide projections on 8-wave workgroups (gemv_long_kernel), both launch forms
     rng = np.random.default_rng(21)
-    width, depth, bins, seq, blocks = 1920, 6, 512, 1024, 16
-    sd = to_dev(_random_sd(rng, width, depth, bins, seq, 2, scale=0.02))
+    depth, bins, seq, blocks = (6 if width == 1920 else 3), 512, 1024, 16
+    sd = to_dev(_random_sd(rng, width, depth, bins, seq, 2, scale=0.02 if width == 1920 else 0.012))
     xc = torch.from_numpy((rng.standard_normal((N, seq, width)) * 0.1).astype(np.float32))
     prime = torch.from_numpy(rng.integers(0, bins, (N, 200))).cuda()
     outs = {}
     for mode in ("chain", "pipelined"):
         monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1" if mode == "pipelined" else "0")
-        eng = PE(sd, "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=1, attn_order=2, blocks=blocks,
+        eng = PE(sd, "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=heads, attn_order=2, blocks=blocks,
                  y_cond=False, fp16=True, want_preds=True, chunk_cap=64)
         eng.set_cond(xc, None)
-        assert eng.pipelined == (mode == "pipelined") and eng.launches_per_step == 4 * depth + 2
+        assert eng.pipelined == (mode == "pipelined") and eng.launches_per_step == (4 if heads == 1 else 5) * depth + 2
         eng.set_sampling(temp=0.98, seed=5)
         res = []
         for window in range(2):
@@ -258,6 +263,7 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N):
         assert eng.pipe_error() == 0
         outs[mode] = res
         eng.close()
+    L.lib().jb_tune_gemv_long(1)                  # the default
     for (z0, p0), (z1, p1) in zip(outs["chain"], outs["pipelined"]):
         assert np.array_equal(z0, z1), "tokens differ between the plain chain and pipelined launches"
         assert np.array_equal(p0, p1), "logits differ between the plain chain and pipelined launches"
