@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
     const int64_t lo_image = (int64_t)p.njt * p.nkt * 512;      // f16 elements from a tap's hi image to its lo image
     const float relu_floor = p.pre_relu ? 0.f : -INFINITY;      // the input ReLU as a branch-free max
     const float neg_limit = p.pre_relu ? -INFINITY : -65504.0f;
+    const bool check = blockIdx.y == 0;                         // (wave-uniform) this workgroup looks for activations outside the half range
     int64_t woff[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) woff[jt] = ((int64_t)min(jt_base + jt, p.njt - 1) * p.nkt) * 512 + (int64_t)lane * 8;
@@ -430,14 +431,24 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
         };
         auto multiply = [&](const f16x8 (&wh)[4], const f16x8 (&wl)[4], const f32x4 (&ar)[4][2]) {
             f16x8 ah[4], al[4];
+            if (check) {
+                // judged on the value as loaded: fmaxf(NaN, 0) is 0, so a NaN under the input ReLU would pass unseen (torch's relu
+                // propagates it); what the ReLU clips anyway (x < 0) cannot overflow.  Only the workgroups of the first column
+                // block look (a wave-uniform branch): every activation row passes through them too, and the kernel is bound by
+                // the instructions it issues per element (the check in every workgroup: conditioner 78 -> 96 ms per window)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = ar[mt][e >> 2][e & 3];
+                        too_big = too_big || (aval[mt] && !(x <= 65504.0f && x >= neg_limit));
+                    }
+            }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float x = ar[mt][e >> 2][e & 3];
-                    // judged on the value as loaded: fmaxf(NaN, 0) is 0, so a NaN under the input ReLU would pass unseen
-                    // (torch's relu propagates it); what the ReLU clips anyway (x < 0) cannot overflow
-                    too_big = too_big || (aval[mt] && !(x <= 65504.0f && x >= neg_limit));
                     x = aval[mt] ? fmaxf(x, relu_floor) : 0.f;
                     const f16 h = (f16)x;
                     ah[mt][e] = h;

@@ -32,14 +32,26 @@ def get_relevant_lyric_tokens(full_tokens, n_tokens, total_length, offset, durat
     return tokens, indices
 
 
+# where unidecode's tables (x000, x001, x020) differ from "compatibility-decompose and drop what is not ASCII": letters with a
+# stroke (no decomposition), ligatures, Latin-1 symbols, dashes and quotes
 _PUNCT = {"\u2014": "--", "\u2013": "-", "\u2018": "'", "\u2019": "'", "\u201c": '"', "\u201d": '"', "\u2026": "...",
-          "\u00df": "ss", "\u00e6": "ae", "\u00c6": "AE", "\u00f8": "o", "\u00d8": "O", "\u0153": "oe", "\u0152": "OE"}
+          "\u00df": "ss", "\u00e6": "ae", "\u00c6": "AE", "\u00f8": "o", "\u00d8": "O", "\u0153": "oe", "\u0152": "OE",
+          "\u00d0": "D", "\u00f0": "d", "\u00de": "Th", "\u00fe": "th", "\u0110": "D", "\u0111": "d", "\u0126": "H", "\u0127": "h",
+          "\u0131": "i", "\u0138": "k", "\u0141": "L", "\u0142": "l", "\u0149": "'n", "\u014a": "NG", "\u014b": "ng", "\u0166": "T",
+          "\u0167": "t", "\u00a1": "!", "\u00a2": "C/", "\u00a3": "PS", "\u00a4": "$?", "\u00a5": "Y=", "\u00a6": "|", "\u00a7": "SS",
+          "\u00a8": '"', "\u00a9": "(c)", "\u00ab": "<<", "\u00ac": "!", "\u00ae": "(r)", "\u00af": "-", "\u00b0": "deg",
+          "\u00b1": "+-", "\u00b4": "'", "\u00b5": "u", "\u00b6": "P", "\u00b7": "*", "\u00b8": ",", "\u00bb": ">>", "\u00bc": "1/4",
+          "\u00bd": "1/2", "\u00be": "3/4", "\u00bf": "?", "\u00d7": "x", "\u00f7": "/", "\u2010": "-", "\u2011": "-", "\u2012": "-",
+          "\u2015": "--", "\u201a": ",", "\u201b": "'", "\u201e": ",,", "\u201f": '"', "\u2022": "*", "\u2032": "'", "\u2033": '"',
+          "\u2039": "<", "\u203a": ">"}
 
 
 def to_ascii(text):
     """Stand-in for `unidecode` (data/text_processor.py:12, not installed here): compatibility-decompose and drop the
     combining marks (e-acute -> e), plus the handful of punctuation marks / ligatures lyric sheets actually contain.
-    Identical to unidecode on ASCII and on accented Latin letters; other scripts are dropped instead of romanised."""
+    Identical to unidecode on ASCII, Latin-1 Supplement, Latin Extended-A and the dashes / quotes of General Punctuation
+    (tests/test_oracle_golden.py compares it, character by character, with an independent restatement of unidecode's tables);
+    other scripts are dropped instead of romanised."""
     import unicodedata
     text = "".join(_PUNCT.get(c, c) for c in text)
     return unicodedata.normalize("NFKD", text).encode("ascii", "ignore").decode()

@@ -365,6 +365,19 @@ def test_gemm_split_reports_activations_outside_the_half_range(H):
     with pytest.raises(L.JukeboxHipError):
         H.check_split_overflow()                                        # waits, reads, clears
     H.check_split_overflow(wait=False)
+    # only the workgroups of the FIRST column block look (every row passes through them): a wide layer (several column blocks)
+    # reports an outlier in any row, once
+    w2 = torch.randn(192, 64, 3, device="cuda") * 0.05
+    pw2 = H.pack_conv_taps(w2, torch.float32, split=True)
+    x2 = torch.randn(2 * 400, 64, device="cuda")
+    H.gemm(x2, pw2, n_seq=2, t_in=400, shifts=(-3, 0, 3))
+    H.check_split_overflow()
+    for row in (0, 399, 400, 657, 799):
+        x2[row, 17] = 1.0e6
+        H.gemm(x2, pw2, n_seq=2, t_in=400, shifts=(-3, 0, 3))
+        with pytest.raises(L.JukeboxHipError):
+            H.check_split_overflow()
+        x2[row, 17] = 0.5
     # weights have no range limit: the image holds s * w (s a power of two that puts max |w| into [128, 256)), checked finite
     big = H.pack_conv_taps(w * 1e7, torch.float32, split=True)
     assert big.unscale > 1.0 and 128.0 <= float((w * 1e7).abs().max()) / big.unscale < 256.0

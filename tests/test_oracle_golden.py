@@ -314,3 +314,21 @@ def test_cpu_baseline_window_plan_matches_the_sampling_driver():
             assert have == total
         assert tr.window_plan(total, n_ctx, hop) == (decode, primed)
         assert decode == total                    # every token of the level is decoded exactly once
+
+
+def test_ascii_stand_ins_agree():
+    """`unidecode` (the reference's data/text_processor.py:2,12; not installed in this image) has two stand-ins written
+    independently of each other: the product's `to_ascii` (NFKD decomposition + a dict of exceptions, jukebox_amd/data/labels.py)
+    and the golden generators' `unidecode_stand_in` (tests/golden/refshim.py: a per-code-point restatement of unidecode's tables
+    x000 / x001 / x020, no unicodedata).  The lyric-token goldens were produced through the second; the product must agree with it
+    on every character of those tables -- and on a lyric sheet's worth of text."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("refshim_tables", os.path.join(ROOT, "tests", "golden", "refshim.py"))
+    shim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shim)                       # (defines the tables; nothing is installed)
+    from jukebox_amd.data.labels import to_ascii
+    chars = [chr(c) for c in list(range(0x20, 0x180)) + sorted(shim._X020)]
+    bad = [(hex(ord(ch)), shim.unidecode_stand_in(ch), to_ascii(ch)) for ch in chars if shim.unidecode_stand_in(ch) != to_ascii(ch)]
+    assert not bad, bad
+    text = "Café — déjà vu… “quoted” ’tis Ærø Œuvre straße naïve Łódź Ðþ ½"
+    assert shim.unidecode_stand_in(text) == to_ascii(text) == 'Cafe -- deja vu... "quoted" \'tis AEro OEuvre strasse naive Lodz Dth 1/2'
