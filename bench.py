@@ -317,13 +317,17 @@ def dry_run(a, rank, world, device):
     """No GPU work (see --dry-run): same launcher, bootstrap, budgeted loop and JSON layout, every step a sleep."""
     n_samples = a.samples_per_gpu * world
     audio = n_samples * a.seconds
+    n_warm = 0
+    if a.warmup > 0:                          # as the real run: ONE untimed pass whenever a warm-up is asked for, whatever the budget
+        time.sleep(0.02)
+        n_warm = 1
     done, dt, per_step, _ = timed_steps(lambda: time.sleep(0.02 * (1 + rank)), max(a.steps, 1), world, device, 0.0, lambda: None)
     lo, hi = shard_range(n_samples, rank, world)          # the sampler's own partition of the samples (sample.py)
     di = dist_info(world, rank, device, per_step, hi - lo)
     if rank != 0:
         return
     line = json.dumps(dict(metric=BASELINE_METRIC, value=round(audio * done / dt, 4), unit="audio_s/s", n_gpus=world, steps=done,
-                          warmup=0, steps_requested=a.steps, warmup_requested=a.warmup, ms_per_step=round(dt / done * 1e3, 1),
+                          warmup=n_warm, steps_requested=a.steps, warmup_requested=a.warmup, ms_per_step=round(dt / done * 1e3, 1),
                           higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f16",
                           data="dry-run (no GPU work; launcher / rank bootstrap / step loop only)",
                           config=dict(workload="dry-run", samples_per_gpu=a.samples_per_gpu, n_samples=n_samples,

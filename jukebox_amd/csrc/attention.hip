@@ -753,6 +753,7 @@ int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const vo
     if (pipe) {
         JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30),
                    "a pipelined launch of the wide-value attention takes d_head = 480 and caches below 2 GiB");
+        JB_REQUIRE(pipe->proto != 1 || (int64_t)grid.x * grid.y >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
         if (lean)
             attn_decode_wide_kernel<15, true, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
                                                                              (const f16*)vcache_w, cache_cap, (const f16*)res, ldr,
@@ -820,6 +821,7 @@ int jb_attn_decode_impl(int dtype, int attn_func, const void* q, int64_t ldq, co
     dim3 grid(n_batch, n_head);
     hipStream_t s = (hipStream_t)stream;
     const JbPipe nopipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr};
+    JB_REQUIRE(!pipe || pipe->proto != 1 || (int64_t)n_batch * n_head >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
     JB_REQUIRE(!pipe || (jb_attn_decode_pipe_supported(dtype, d_head, (int)ldq, (int)ldo, n_head * d_head) &&
                          (int64_t)n_batch * cache_cap * n_head * d_head < (1ll << 30)),
                "a pipelined launch of the decode attention takes fp16 heads of 150 (ragged), 256 or 512 channels and caches below 2 GiB");

@@ -1756,6 +1756,9 @@ int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream) {
     JB_REQUIRE(!pipe || (!a->x_parts && !a->ln_gamma && a->J % 16 == 0 && a->n_rows <= 16 && a->ldo % 4 == 0 &&
                          (!a->qkv_split || a->S % 16 == 0) && (!a->out2 || a->ldo2 % 4 == 0)),
                "a pipelined launch takes the plain or the folded-LayerNorm projection, <= 16 rows, whole 16-column tiles");
+    // completion protocol 1 has a flag word per ticket shard (workgroup index mod 8): a launch of fewer than 8 workgroups would
+    // leave flags that nobody writes, and every consumer would sit out its time-out on them
+    JB_REQUIRE(!pipe || pipe->proto != 1 || njt >= 8, "completion protocol 1 needs launches of >= 8 workgroups (J >= 128)");
     p.dbg = nullptr;
 #ifdef JB_TIMING
     p.dbg = jb_dbg_ptr;

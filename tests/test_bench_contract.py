@@ -34,6 +34,14 @@ def test_single_process_line_and_budget():
     # a budget that is already spent: exactly one step is timed, the line still appears
     out = _run(["--dry-run", "--steps", "20", "--warmup", "5"], env=dict(JB_BENCH_BUDGET_S="0"))
     assert out["steps"] == 1 and out["steps_requested"] == 20
+    # ... and the warm-up pass is never dropped, whatever the budget (round 4: every builder-side line had skipped it under a short
+    # budget, i.e. timed the first job of a fresh process, and hid what the driver's later steps paid)
+    assert out["warmup"] == 1 and out["warmup_requested"] == 5
+    assert _run(["--dry-run", "--steps", "1"])["warmup"] == 0
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main_src = ast.get_source_segment(src, next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "main"))
+    assert "if a.warmup > 0:" in main_src and "budget_left() > 600" not in main_src
 
 
 def test_gpus_2_spawns_its_own_ranks():
