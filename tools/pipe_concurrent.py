@@ -2,7 +2,7 @@
 whether an engine has pipelined launches, and the error words, for
   A  two engines on plain chains            B  two engines on pipelined launches (two owners per process: lean attention)
   C  one pipelined, one plain               D  one engine alone, pipelined / plain
-Usage: python tools/pipe_concurrent.py [depth]"""
+Usage: python tools/pipe_concurrent.py [depth] [plain]        (plain: cases A and D-plain only, for a kernel trace)"""
 import sys, threading, time
 import torch
 sys.path.insert(0, ".")
@@ -49,6 +49,11 @@ def case(name, modes):
 
 from jukebox_amd import _lib as L
 L.lib().jb_tune_attn_decode_wide_lean(1)         # two pipelined engines need the lean attention kernel
+if len(sys.argv) > 2 and sys.argv[2] == "plain":
+    # for a kernel trace (tools/overlap_account.py): plain chains only -- side by side, then one alone
+    case("A two plain chains        ", (0, 0))
+    case("D alone, plain            ", (0, None))
+    sys.exit(0)
 for rep in range(2):
     case("A two plain chains        ", (0, 0))
     case("B two pipelined engines   ", (1, 1))
