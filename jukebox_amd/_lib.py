@@ -94,6 +94,7 @@ _SIGS = {
     "jb_tune_attn_decode_split_min_keys": (None, [i32]),
     "jb_tune_gemm_lds": (None, [i32]),
     "jb_tune_gemm_glds": (None, [i32]),
+    "jb_tune_gemm_8phase": (None, [i32]),
     "jb_tune_gemv_long": (None, [i32]),
     "jb_tune_attn_prefill_v2": (None, [i32]),
     "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),

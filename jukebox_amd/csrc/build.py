@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "engine.hip"]
-HEADERS = ["common.h", "gemm_glds_index.h", os.path.join("..", "..", "include", "jukebox_hip.h")]
+HEADERS = ["common.h", "gemm_glds_index.h", "gemm_8phase.h", os.path.join("..", "..", "include", "jukebox_hip.h")]
 LIB = os.path.join(HERE, "libjukebox_hip.so")
 
 

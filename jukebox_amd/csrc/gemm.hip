@@ -677,6 +677,140 @@ __global__ __launch_bounds__(256, 3) void gemm_glds_kernel(GemmParams p, int MB,
     }
 }
 
+// The prefill's big projections since round 5 (K a multiple of 128, enough 256 x 256 tiles to fill the chip): the 8-phase K-loop of
+// gemm_8phase.h -- one 8-wave workgroup per CU, 128 KiB of LDS in two stages of four half-tiles, the two wave rows half a phase
+// apart so that one group's operand reads and LDS-DMA requests run under the other's MFMA cluster.  Tile order, row addressing
+// (rows are (sequence, position) pairs with a pitch per sequence) and epilogue are gemm_glds_kernel's; same MFMA and k order per
+// output element: bit-identical to the three older kernels (tests/test_hip_kernels.py::test_gemm_8phase).
+#include "gemm_8phase.h"
+// Epilogue of gemm_8phase_kernel.  With ONE workgroup per CU nothing covers a tile's epilogue, and the MFMA result layout
+// (a lane holds 4 consecutive columns of one row: 8 bytes, 16 rows per store instruction; 2-byte stores for a q / k / v
+// split) is store-issue-bound.  So each wave first applies bias -> round -> activation in registers, parks its 128 x 64
+// sub-tile as f16 in an LDS region of its own (rows 144 bytes apart: conflict-free 8-byte writes and 16-byte reads), and
+// then moves whole 128-byte row segments: 16 bytes per lane, the residual read the same way and added in that form, the
+// q / k-cache / v-cache destination chosen per 8-column piece.  Same operations in the same order per element as
+// epilogue_store: bit-identical.  `fast` (host-checked: 8-column pieces never straddle a destination or an edge, every row
+// 16-byte aligned) selects it; otherwise epilogue_store.
+constexpr int G8_EPI_PITCH = 144;
+constexpr int G8_EPI_WAVE_BYTES = 128 * G8_EPI_PITCH;
+constexpr int G8_LDS_BYTES = 8 * G8_EPI_WAVE_BYTES > g8::LDS_BYTES ? 8 * G8_EPI_WAVE_BYTES : g8::LDS_BYTES;
+
+__global__ __launch_bounds__(512, 1) void gemm_8phase_kernel(GemmParams p, int MB, int NB, int fast_epi) {
+    using T = f16;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char s_glds[];
+    int mp, nt;
+    if (!gi::tile_of_block((int)blockIdx.x, MB, NB, &mp, &nt)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wave_m = wave >> 2, wave_n = wave & 3;
+    const int64_t m0 = (int64_t)mp * g8::BM;
+    const int jt0 = nt * g8::BJT;
+    g8::Sources src;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int64_t q = m0 + g8::a_tile_row(h, (wave * 2 + u) * 8 + gi::a_src_row(lane));
+            q = q < p.m_total ? q : p.m_total - 1;                    // rows past the end are never stored
+            const int64_t n = q / p.t_out, t = q - n * p.t_out;
+            src.a[h][u] = (const T*)p.A + (n * p.in_seq_stride + t) * p.lda + gi::a_src_seg(lane) * 8;
+            const int ti = wave * 2 + u;
+            src.w[h][u] = (const T*)p.W + ((int64_t)min(jt0 + g8::b_tile_jt(h, ti), p.njt - 1) * p.nkt + g8::b_tile_ks(ti)) * 512 + lane * 8;
+        }
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    g8::mainloop(src, p.nkt >> 1, s_glds, acc);
+    const int g = lane >> 4, c = lane & 15;
+    if (!fast_epi) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int64_t q = m0 + wave_m * 128 + mt * 16 + c;
+            if (q >= p.m_total) continue;
+            const int n = (int)(q / p.t_out), t = (int)(q - (int64_t)n * p.t_out);
+            const int64_t orow = (int64_t)n * p.out_seq_stride + t;
+            int64_t cache_row = -1;
+            if (p.epi.qkv_split) {
+                const int ct = p.cache_t0 + t;
+                if (ct < p.epi.cache_cap) cache_row = (int64_t)n * p.epi.cache_cap + ct;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int jb = (jt0 + wave_n * 4 + j) * 16 + g * 4;
+                if (jb < p.epi.J) epilogue_store<T>(p.epi, acc[j][mt], orow, jb, cache_row);
+            }
+        }
+        return;
+    }
+    __syncthreads();                                   // every wave is done with the operand stages: the regions overlap them
+    unsigned char* region = s_glds + wave * G8_EPI_WAVE_BYTES;
+    const int col0 = (jt0 + wave_n * 4) * 16;          // first column of the wave's sub-tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.epi.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias[r] = jb_round<T>(p.epi.bias[min(col0 + j * 16 + g * 4 + r, p.epi.J - 1)]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[j][mt][r];
+                if (p.epi.bias) x += bias[r];
+                x = jb_round<T>(x);
+                x = jb_apply_act<T>(x, p.epi.act);
+                o[r] = (f16)x;
+            }
+            *reinterpret_cast<f16x4*>(region + (mt * 16 + c) * G8_EPI_PITCH + (j * 16 + g * 4) * 2) = o;
+        }
+    }
+    // (a wave's LDS operations execute in order: its reads below see its own writes)
+    const int seg = lane & 7, col = col0 + seg * 8;
+    if (col >= p.epi.J) return;
+    T* dst_base = (T*)p.epi.out;
+    int64_t dst_ld = p.epi.ldo;
+    int dst_col = col;
+    bool to_cache = false;
+    if (p.epi.qkv_split && col >= p.epi.S) {
+        to_cache = true;
+        if (col < 2 * p.epi.S) { dst_base = (T*)p.epi.kcache; dst_ld = p.epi.S; dst_col = col - p.epi.S; }
+        else if (col < 2 * p.epi.S + p.epi.v_cols) { dst_base = (T*)p.epi.vcache; dst_ld = p.epi.S; dst_col = col - 2 * p.epi.S; }
+        else { dst_base = (T*)p.epi.vcache2; dst_ld = p.epi.v2w; dst_col = col - 2 * p.epi.S - p.epi.v_cols; }
+    }
+    const int64_t q0 = m0 + wave_m * 128 + (lane >> 3);
+    int n = (int)(q0 / p.t_out), t = (int)(q0 - (int64_t)n * p.t_out) - 8;      // (sequence, position) of the lane's rows: 8 apart
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int row = i * 8 + (lane >> 3);
+        t += 8;
+        while (t >= p.t_out) { t -= p.t_out; ++n; }
+        if (q0 + i * 8 >= p.m_total) break;
+        int64_t orow = (int64_t)n * p.out_seq_stride + t;
+        f16x8 v = *reinterpret_cast<const f16x8*>(region + row * G8_EPI_PITCH + seg * 16);
+        if (p.epi.res) {
+            const f16x8 rr = *reinterpret_cast<const f16x8*>((const T*)p.epi.res + orow * p.epi.ldr + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = (float)v[e], rv = (float)rr[e];
+                v[e] = (f16)((p.epi.res_scale == 1.0f) ? jb_round<T>(rv + x) : jb_round<T>(rv + jb_round<T>(p.epi.res_scale * x)));
+            }
+        }
+        if (to_cache) {
+            const int ct = p.cache_t0 + t;
+            if (ct >= p.epi.cache_cap) continue;
+            orow = (int64_t)n * p.epi.cache_cap + ct;
+        }
+        *reinterpret_cast<f16x8*>(dst_base + orow * dst_ld + dst_col) = v;
+    }
+}
+
+// problems of gemm_glds_kernel's kind with K a multiple of 128 and at least this many 256 x 256 output tiles take
+// gemm_8phase_kernel (< 0: never); jb_tune_gemm_8phase
+static int g_gemm_8phase_min_tiles = 512;
+extern "C" void jb_tune_gemm_8phase(int min_tiles) { g_gemm_8phase_min_tiles = min_tiles; }
+
 // the flat fp16 problems of >= this many rows take gemm_glds_kernel (< 0: never); jb_tune_gemm_glds
 static int g_gemm_glds_min_rows = 256;
 extern "C" void jb_tune_gemm_glds(int min_rows) { g_gemm_glds_min_rows = min_rows; }
@@ -756,6 +890,25 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
             JB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        gi::STAGE_BYTES));
             configured[dev] = true;
+        }
+        const int MB8 = (int)((p.m_total + g8::BM - 1) / g8::BM), NB8 = (p.njt + g8::BJT - 1) / g8::BJT;
+        if (a->K % 128 == 0 && g_gemm_8phase_min_tiles >= 0 && (int64_t)MB8 * NB8 >= g_gemm_8phase_min_tiles) {
+            static bool configured8[64] = {};
+            if (dev >= 0 && dev < 64 && !configured8[dev]) {     // 144 KiB of dynamic LDS: above the 64-KiB default
+                JB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_8phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           G8_LDS_BYTES));
+                configured8[dev] = true;
+            }
+            // the line-wise epilogue: 8-column pieces (16 bytes) must neither straddle an edge nor a q / k / v boundary
+            const EpiParams& e = p.epi;
+            bool fast_epi = !e.out2 && e.J % 8 == 0 && aligned_to(e.out, 16) && e.ldo % 8 == 0 &&
+                            (!e.res || (aligned_to(e.res, 16) && e.ldr % 8 == 0));
+            if (e.qkv_split)
+                fast_epi = fast_epi && e.S % 8 == 0 && e.v_cols % 8 == 0 && aligned_to(e.kcache, 16) &&
+                           (e.v_cols == 0 || aligned_to(e.vcache, 16)) && (e.v2w == 0 || (e.v2w % 8 == 0 && aligned_to(e.vcache2, 16)));
+            gemm_8phase_kernel<<<(MB8 + 7) / 8 * 8 * NB8, 512, G8_LDS_BYTES, st>>>(p, MB8, NB8, fast_epi ? 1 : 0);
+            JB_CHECK_LAUNCH();
+            return JB_OK;
         }
         const int MB = (int)((p.m_total + gi::BM - 1) / gi::BM), NB = (p.njt + gi::BJT - 1) / gi::BJT;
         gemm_glds_kernel<<<(MB + 7) / 8 * 8 * NB, 256, gi::STAGE_BYTES, st>>>(p, MB, NB);

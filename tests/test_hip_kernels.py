@@ -175,6 +175,59 @@ def test_gemm_glds(H, M, K, J):
     assert relerr(new[2], h16(A[:n_seq * t] @ W)) < 4e-3
 
 
+@pytest.mark.parametrize("M,K,J", [(1300, 256, 264), (4096, 1920, 1440), (2048, 1920, 480), (777, 128, 1000), (8192, 1920, 1920),
+                                   (3000, 384, 200)])
+def test_gemm_8phase(H, M, K, J):
+    """The prefill's big projections since round 5 (gemm_8phase_kernel: 256 x 256 tile on 8 waves, two LDS stages of four
+    half-tiles filled by LDS-DMA, the two wave rows half a phase apart; K a multiple of 128): bit-identical to gemm_glds_kernel
+    and to the register-staged kernel on ragged rows / columns (partial tiles in both directions, fewer tiles than compute
+    units), one to fifteen loop iterations, every epilogue, sequences a pitch apart -- and the same answer on every one of
+    several launches (a missed ordering between an LDS-DMA request and an operand read shows as a rare wrong tile)."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(M + K + J)
+    dt = torch.float16
+    A = h16(rng.standard_normal((M, K)).astype(np.float32))
+    W = h16((rng.standard_normal((K, J)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(J).astype(np.float32)
+    R = h16(rng.standard_normal((M, J)).astype(np.float32))
+    pw = H.pack_conv1d_w(dev(W), dt)
+    Ad, Rd, bd = dev(A, dt), dev(R, dt), dev(b)
+    n_seq, t = 4, M // 4
+    pitch = t + 7
+    Ap = torch.zeros((n_seq * pitch, K), dtype=dt, device="cuda")
+    Ap.view(n_seq, pitch, K)[:, :t] = Ad[:n_seq * t].view(n_seq, t, K)
+
+    def run():
+        out = [H.gemm(Ad, pw, bias=bd, act=L.ACT_QUICK_GELU), H.gemm(Ad, pw, bias=bd, res=Rd),
+               H.gemm(Ap, pw, n_seq=n_seq, t_in=t, in_seq_pitch=pitch)]
+        if J % 3 == 0:
+            S, cap, t0 = J // 3, t + 9, 5
+            kc = torch.zeros((n_seq, cap, S), dtype=dt, device="cuda")
+            vc = torch.zeros((n_seq, cap, S), dtype=dt, device="cuda")
+            out += [H.gemm_qkv(Ad[:n_seq * t], pw, bd, n_seq, t, S, kc, vc, t0), kc, vc]
+        return [o.float().cpu().numpy() for o in out]
+
+    try:
+        L.lib().jb_tune_gemm_glds(1)
+        L.lib().jb_tune_gemm_8phase(1)
+        new = [run() for _ in range(4)]
+        L.lib().jb_tune_gemm_8phase(-1)
+        glds = run()
+        L.lib().jb_tune_gemm_glds(-1)
+        L.lib().jb_tune_gemm_lds(1)
+        lds = run()
+    finally:
+        L.lib().jb_tune_gemm_lds(1024)
+        L.lib().jb_tune_gemm_glds(256)
+        L.lib().jb_tune_gemm_8phase(512)
+    for rep in new:
+        for a, b_, c in zip(rep, glds, lds):
+            assert np.array_equal(a, b_) and np.array_equal(a, c)
+    assert relerr(new[0][0], O.quick_gelu(h16(A @ W + h16(b)), fp16=True)) < 4e-3
+    assert relerr(new[0][1], h16(R + h16(A @ W + h16(b)))) < 4e-3
+    assert relerr(new[0][2], h16(A[:n_seq * t] @ W)) < 4e-3
+
+
 def test_conv_stack_ops_fp32(H):
     """Dilated k=3 conv, strided k=4 conv and transposed conv on channels-last rows vs torch-free numpy NCT."""
     rng = np.random.default_rng(2)

@@ -28,6 +28,9 @@
 #include <random>
 #include <vector>
 
+#include <type_traits>
+
+#include "../jukebox_amd/csrc/gemm_8phase.h"
 #include "../jukebox_amd/csrc/gemm_glds_index.h"
 #include "jukebox_hip.h"
 
@@ -51,6 +54,7 @@ struct Params {
     const float* bias;
     f16* out; long long ldo; int J;
     int MB, NB;                                 // 128-row panels, 128-column tiles
+    int stagger;                                // 8-phase kernel: the two wave groups half a phase apart (1) or in lock step (0)
 };
 
 extern __shared__ __attribute__((aligned(1024))) unsigned char s_raw[];
@@ -280,6 +284,71 @@ static void launch_tile(const Params& p, hipStream_t s) {
     HIP_OK(hipGetLastError());
 }
 
+// The 8-phase 256 x 256 kernel (jukebox_amd/csrc/gemm_8phase.h holds the K-loop the library kernel shares): K a multiple of 128.
+template <int ABL>
+__global__ __launch_bounds__(512, 1) void gemm_8phase_probe_kernel(Params p) {
+    using namespace g8;
+    const int MBt = (int)((p.m_total + BM - 1) / BM), NBt = (p.njt + BJT - 1) / BJT;
+    int mp, nt;
+    if (!gi::tile_of_block((int)blockIdx.x, MBt, NBt, &mp, &nt)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 2, wn = wave & 3;
+    const long long m0 = (long long)mp * BM;
+    const int jt0 = nt * BJT;
+    Sources src;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            long long row = m0 + a_tile_row(h, (wave * 2 + u) * 8 + gi::a_src_row(lane));
+            row = row < p.m_total ? row : p.m_total - 1;
+            src.a[h][u] = p.A + row * p.lda + gi::a_src_seg(lane) * 8;
+            const int ti = wave * 2 + u;
+            const int jt = jt0 + b_tile_jt(h, ti);
+            src.w[h][u] = p.W + ((long long)(jt < p.njt ? jt : p.njt - 1) * p.nkt + b_tile_ks(ti)) * 512 + lane * 8;
+        }
+    f4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[j][mt] = f4{0.f, 0.f, 0.f, 0.f};
+    mainloop<ABL>(src, p.nkt >> 1, s_raw, acc, p.stagger != 0);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const long long row = m0 + wm * 128 + mt * 16 + (lane & 15);
+        if (row >= p.m_total) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jb = (jt0 + wn * 4 + j) * 16 + (lane >> 4) * 4;
+            if (jb >= p.J) continue;
+            f16 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[j][mt][r];
+                if (p.bias && jb + r < p.J) x += (float)(f16)p.bias[jb + r];
+                v[r] = (f16)x;
+            }
+            f16* dst = p.out + row * p.ldo + jb;
+            if (jb + 3 < p.J) {
+                *reinterpret_cast<f16x4*>(dst) = f16x4{v[0], v[1], v[2], v[3]};
+            } else {
+                for (int r = 0; r < 4 && jb + r < p.J; ++r) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+template <int ABL = 0>
+static void launch_8phase(const Params& p, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_8phase_probe_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, g8::LDS_BYTES));
+        configured = true;
+    }
+    const int MBt = (int)((p.m_total + g8::BM - 1) / g8::BM), NBt = (p.njt + g8::BJT - 1) / g8::BJT;
+    gemm_8phase_probe_kernel<ABL><<<(MBt + 7) / 8 * 8 * NBt, 512, g8::LDS_BYTES, s>>>(p);
+    HIP_OK(hipGetLastError());
+}
+
 template <int NBUF>
 static void launch(const Params& p, hipStream_t s) {
     static bool configured = false;
@@ -342,12 +411,31 @@ static int run_shape(long long M, int K, int J) {
 
     const double flop = 2.0 * (double)M * K * J;
     int bad = 0;
+    jb_tune_gemm_8phase(-1);
+    jb_tune_gemm_glds(-1);
     const double t_lib = time_ms([&] { if (jb_gemm(&g, nullptr) != 0) { std::fprintf(stderr, "jb_gemm: %s\n", jb_last_error()); std::exit(1); } }, 20);
     std::vector<f16> r_lib((size_t)M * J), r_new((size_t)M * J);
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(r_lib.data(), o_lib, r_lib.size() * 2, hipMemcpyDeviceToHost));
     std::printf("M=%lld K=%d J=%d  library gemm_lds_kernel (256x128 tile, register staging)   %8.1f us  %7.1f TFLOP/s\n", M, K, J, t_lib * 1e3,
                 flop / (t_lib * 1e-3) / 1e12);
+    if (K % 128 == 0) {          // the library's own 8-phase kernel (line-wise epilogue through LDS), forced on at any size
+        jb_tune_gemm_glds(1);
+        jb_tune_gemm_8phase(1);
+        g.out = o_new;
+        HIP_OK(hipMemset(o_new, 0xff, (size_t)M * J * 2));
+        const double t = time_ms([&] { if (jb_gemm(&g, nullptr) != 0) { std::fprintf(stderr, "jb_gemm: %s\n", jb_last_error()); std::exit(1); } }, 20);
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(r_new.data(), o_new, r_new.size() * 2, hipMemcpyDeviceToHost));
+        long long differ = 0;
+        for (size_t i = 0; i < r_new.size(); ++i) differ += (__builtin_bit_cast(unsigned short, r_new[i]) != __builtin_bit_cast(unsigned short, r_lib[i]));
+        bad += differ != 0;
+        std::printf("M=%lld K=%d J=%d  library gemm_8phase_kernel (256x256, 8 phases, line-wise epilogue)         %8.1f us  %7.1f TFLOP/s   %s (elements differing "
+                    "from the library: %lld)\n", M, K, J, t * 1e3, flop / (t * 1e-3) / 1e12, differ == 0 ? "EQUAL" : "MISMATCH", differ);
+        g.out = o_lib;
+        jb_tune_gemm_8phase(-1);
+        jb_tune_gemm_glds(-1);
+    }
     for (int nbuf = 1; nbuf <= 2; ++nbuf) {
         HIP_OK(hipMemset(o_new, 0xff, (size_t)M * J * 2));
         const double t = time_ms([&] { if (nbuf == 1) launch<1>(p, nullptr); else launch<2>(p, nullptr); }, 20);
@@ -385,6 +473,33 @@ static int run_shape(long long M, int K, int J) {
         std::printf("M=%lld K=%d J=%d  %-30s LDS-DMA, 2 LDS buffers              %8.1f us  %7.1f TFLOP/s   %s (elements differing from the library: %lld)\n",
                     M, K, J, names[var], t * 1e3, flop / (t * 1e-3) / 1e12, differ == 0 ? "EQUAL" : "MISMATCH", differ);
     }
+    for (int stagger = 1; stagger >= 0 && K % 128 == 0; --stagger) {
+        p.stagger = stagger;
+        HIP_OK(hipMemset(o_new, 0xff, (size_t)M * J * 2));
+        const double t = time_ms([&] { launch_8phase(p, nullptr); }, 20);
+        HIP_OK(hipDeviceSynchronize());
+        long long differ = 0;
+        for (int rep = 0; rep < 3; ++rep) {          // a race shows as a rare wrong tile: compare several runs
+            HIP_OK(hipMemcpy(r_new.data(), o_new, r_new.size() * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < r_new.size(); ++i) differ += (__builtin_bit_cast(unsigned short, r_new[i]) != __builtin_bit_cast(unsigned short, r_lib[i]));
+            HIP_OK(hipMemset(o_new, 0xff, (size_t)M * J * 2));
+            for (int i = 0; i < 5; ++i) launch_8phase(p, nullptr);
+            HIP_OK(hipDeviceSynchronize());
+        }
+        bad += differ != 0;
+        std::printf("M=%lld K=%d J=%d  %-30s LDS-DMA, 8 phases, 2 stages         %8.1f us  %7.1f TFLOP/s   %s (elements differing from the library: %lld)\n",
+                    M, K, J, stagger ? "256x256 / 8 waves, 2 groups" : "256x256 / 8 waves, lock step", t * 1e3, flop / (t * 1e-3) / 1e12, differ == 0 ? "EQUAL" : "MISMATCH", differ);
+    }
+    if (K % 128 == 0 && M >= 8192) {        // ablations of the 8-phase loop (results are wrong by construction): what bounds it?
+        p.stagger = 1;
+        const double t1 = time_ms([&] { launch_8phase<1>(p, nullptr); }, 20);
+        const double t2 = time_ms([&] { launch_8phase<2>(p, nullptr); }, 20);
+        const double t3 = time_ms([&] { launch_8phase<3>(p, nullptr); }, 20);
+        const double t4 = time_ms([&] { launch_8phase<4>(p, nullptr); }, 20);
+        const double t7 = time_ms([&] { launch_8phase<7>(p, nullptr); }, 20);
+        std::printf("M=%lld K=%d J=%d  8-phase ablations, us: no LDS-DMA in the loop %.1f | no operand reads %.1f | neither %.1f | no MFMAs %.1f | barriers only %.1f\n",
+                    M, K, J, t1 * 1e3, t2 * 1e3, t3 * 1e3, t4 * 1e3, t7 * 1e3);
+    }
     HIP_OK(hipFree(dA)); HIP_OK(hipFree(dW)); HIP_OK(hipFree(dP)); HIP_OK(hipFree(db)); HIP_OK(hipFree(o_lib)); HIP_OK(hipFree(o_new));
     return bad;
 }
@@ -394,7 +509,8 @@ int main() {
     // the prefill's GEMMs: 16 samples x 2048 positions; c_attn (q, k, v), attn.c_proj / v.Wp, mlp.c_fc and mlp.c_proj of the
     // upsamplers, then ragged edges (rows and columns that are not multiples of the tile, an odd number of k-tiles)
     const long long shapes[][3] = {{32768, 1920, 1440}, {32768, 1920, 1920}, {32768, 480, 1920}, {32768, 1920, 2880},
-                                   {8192, 2048, 2048}, {6144, 4800, 4800}, {1000, 480, 200}, {130, 96, 72}};
+                                   {65536, 1920, 1440}, {65536, 1920, 1920}, {65536, 1920, 3360}, {8192, 2048, 2048}, {8192, 8192, 8192},
+                                   {6144, 4800, 4800}, {1000, 480, 200}, {1000, 384, 200}, {130, 128, 72}, {130, 96, 72}};
     for (auto& s : shapes) bad += run_shape(s[0], (int)s[1], (int)s[2]);
     std::printf(bad ? "FAILED: %d variant(s) differ\n" : "all variants equal the library kernel bit for bit\n", bad);
     return bad ? 1 : 0;
