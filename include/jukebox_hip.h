@@ -104,6 +104,12 @@ typedef struct jb_gemm_args {
      * accumulators are multiplied by it before bias, activation and residual (exact: a power of two). */
     int w_split;
     float w_split_unscale;
+    /* w_split problems: scratch of at least 4 * n_seq * t_in * K bytes (16-byte aligned), or NULL.  With it the activations are
+     * split ONCE, by a pass of their own (input ReLU and range check there), into f16 hi / lo images that the GEMM loads as
+     * finished operands -- the same operands, bit for bit, as the split inside the GEMM (which every column block of 64
+     * repeats and which bounds that kernel); without it the split stays inside the GEMM.  The scratch may be reused as soon
+     * as the launch is enqueued on the same stream. */
+    void* a_split; int64_t a_split_bytes;
 } jb_gemm_args;
 int jb_gemm(const jb_gemm_args* args /* host */, void* stream);
 /* 1 if a w_split launch since the last reset was given an activation outside the half range (|x| > 65504; under pre_relu only
@@ -123,6 +129,9 @@ void jb_tune_gemm_glds(int min_rows);
  * < 0: never).  Bit-identical to the other kernels.  Replaces the same Conv1D.forward at q > 1
  * (jukebox/transformer/ops.py:97-101). */
 void jb_tune_gemm_8phase(int min_tiles);
+/* w_split problems with a scratch buffer (jb_gemm_args.a_split): 1 = split the activations in a pass of their own (default),
+ * 0 = inside the GEMM.  Bit-identical. */
+void jb_tune_gemm_presplit(int on);
 /* fp16 decode projections over 129 .. 160 k-tiles (5b_lyrics, K = 4800; <= 16 rows): 1 = 8-wave workgroups that walk their
  * k-tiles through two register stages (two workgroups per compute unit, every column tile resident at once; default), 0 = the
  * 16-wave kernels.  Another summation order: results agree to rounding, not bit for bit. */

@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("K", i32), ("J", i32), ("n_taps", i32), ("in_stride", i32), ("shift", i32 * 4),
                 ("out_stride", i32), ("out_offset", i32), ("pre_relu", i32), ("act", i32), ("res_scale", f32),
                 ("qkv_split", i32), ("S", i32), ("kcache", vp), ("vcache", vp), ("cache_cap", i32), ("cache_t0", i32),
-                ("w_split", i32), ("w_split_unscale", f32)]
+                ("w_split", i32), ("w_split_unscale", f32), ("a_split", vp), ("a_split_bytes", i64)]
 
 
 class GemvArgs(C.Structure):
@@ -95,6 +95,7 @@ _SIGS = {
     "jb_tune_gemm_lds": (None, [i32]),
     "jb_tune_gemm_glds": (None, [i32]),
     "jb_tune_gemm_8phase": (None, [i32]),
+    "jb_tune_gemm_presplit": (None, [i32]),
     "jb_tune_gemv_long": (None, [i32]),
     "jb_tune_attn_prefill_v2": (None, [i32]),
     "jb_attn_prefill": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -230,6 +230,7 @@ struct GemmParams {
     int64_t m_total;
     unsigned* overflow;                  // gemm_split_kernel: the process's host-coherent "activation outside the half range" word
     float w_unscale;                     // gemm_split_kernel: 1 / (the power of two the weights were multiplied by when packed)
+    const void* zero_line;               // gemm_split_glds_kernel: 128 bytes of zeros (what a row outside its sequence reads)
     EpiParams epi;
 };
 
@@ -370,6 +371,40 @@ static unsigned* split_overflow_word() {
         }
     });
     return word;
+}
+
+// The activations of a w_split problem split ONCE (jb_gemm_args.a_split): gemm_split_kernel converts every activation
+// fragment it multiplies -- 32 elements per lane and k-step, ~ 7 vector instructions each, again in every one of the J / 64
+// column blocks -- and is bound by those instructions, not by the MFMAs (23 % of the f16 peak).  With a scratch buffer of the
+// activations' size the same split (input ReLU, range check, hi = half(x), lo = half((x - hi) * 2^11): bit-identical operands)
+// is done by one pass over the rows, and the GEMM (gemm_split_glds_kernel below) takes finished f16 operands through LDS-DMA.
+__global__ void split_act_kernel(const float* __restrict__ A, int64_t lda, int n_seq, int t_in, int64_t in_seq_stride, int K,
+                                 f16* __restrict__ img, int pre_relu, unsigned* overflow) {
+    const int kv = K >> 3;                                     // 8-element pieces per row
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_seq * t_in * kv) return;
+    const int64_t r = idx / kv;                                // row of the images: (sequence, position) packed
+    const int k = (int)(idx - r * kv) << 3;
+    const int64_t n = r / t_in;
+    const float* src = A + (n * in_seq_stride + (r - n * t_in)) * lda + k;      // rows between two sequences are never looked at
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+    const float relu_floor = pre_relu ? 0.f : -INFINITY, neg_limit = pre_relu ? -INFINITY : -65504.0f;
+    bool too_big = false;
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float x = e < 4 ? x0[e] : x1[e - 4];
+        too_big = too_big || !(x <= 65504.0f && x >= neg_limit);          // judged before the ReLU: fmaxf(NaN, 0) is 0
+        x = fmaxf(x, relu_floor);
+        const f16 hh = (f16)x;
+        h[e] = hh;
+        l[e] = (f16)((x - (float)hh) * 2048.0f);
+    }
+    // image: per row, per 32-channel k-tile, one 128-byte line [hi 32 halves | lo 32 halves]
+    f16* line = img + r * (2 * (int64_t)K) + (k >> 5) * 64 + (k & 31);
+    *reinterpret_cast<f16x8*>(line) = h;
+    *reinterpret_cast<f16x8*>(line + 32) = l;
+    if (too_big) __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmParams p) {
@@ -683,6 +718,106 @@ __global__ __launch_bounds__(256, 3) void gemm_glds_kernel(GemmParams p, int MB,
 // (rows are (sequence, position) pairs with a pitch per sequence) and epilogue are gemm_glds_kernel's; same MFMA and k order per
 // output element: bit-identical to the three older kernels (tests/test_hip_kernels.py::test_gemm_8phase).
 #include "gemm_8phase.h"
+// The conv stacks' GEMM on pre-split activations (jb_gemm_args.a_split; round 5).  split_act_kernel has written, per input row
+// and 32-channel k-tile, one 128-byte line [hi 32 halves | lo 32 halves]; the weights' hi and lo images are 1-KiB MFMA-order
+// tiles as ever.  That is gemm_glds_kernel's stage exactly -- a 128-row activation panel of 128-byte lines, 16 weight tiles --
+// with "k-tile 0 / 1 of the K-step" read as "hi / lo of ONE k-tile": same LDS-DMA pieces, same XOR-swizzled image, same
+// conflict-free operand reads (gemm_glds_index.h), and per stage 48 MFMAs per wave instead of 32:
+//     acc += w_hi a_hi;   acc2 += w_hi a_lo;   acc2 += w_lo a_hi          (gemm_split_kernel's three, in its order)
+// Taps: a stage belongs to one (tap, k-tile); the lanes' source rows are the tap's shifted rows, rows outside their sequence
+// read a line of zeros; a tap that is out of range for all 128 rows of the tile is skipped (workgroup-uniform vote).
+// Operands, MFMAs and their order per output element are gemm_split_kernel's: bit-identical (tests/test_hip_kernels.py).
+__global__ __launch_bounds__(256, 2) void gemm_split_glds_kernel(GemmParams p, int MB, int NB) {
+    using namespace gi;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char s_glds[];
+    int mp, nt;
+    if (!tile_of_block((int)blockIdx.x, MB, NB, &mp, &nt)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wave_m = wave >> 1, wave_n = wave & 1;
+    const int64_t m0 = (int64_t)mp * BM;
+    const int jt0 = nt * BJT;
+    // the four activation pieces of this wave: (sequence, position) of the lane's row in each
+    int pn[4], pt[4];
+    bool pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t q = m0 + (wave * 4 + u) * 8 + a_src_row(lane);
+        pv[u] = q < p.m_total;
+        const int64_t qq = pv[u] ? q : 0;
+        pn[u] = (int)(qq / p.t_out);
+        pt[u] = (int)(qq - (int64_t)pn[u] * p.t_out);
+    }
+    const f16* img = (const f16*)p.A;                           // [n_seq * t_in][nkt][hi 32 | lo 32]
+    const int64_t row_pitch = 2 * (int64_t)p.K;
+    const int64_t lo_image = (int64_t)p.njt * p.nkt * 512;      // f16 elements from a tap's hi image to its lo image
+    int64_t w_off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ti = wave * 4 + u, jt = ti >> 1;              // stage tile (jt, ks): ks = 0 the hi image's tile, ks = 1 the lo image's
+        w_off[u] = (ti & 1 ? lo_image : 0) + ((int64_t)min(jt0 + jt, p.njt - 1) * p.nkt) * 512 + lane * 8;
+    }
+    f32x4 acc[4][4], acc2[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[j][mt] = acc2[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < p.n_taps; ++tap) {
+        const f16* a_src[4];
+        int a_step[4];                                         // halves per k-tile: a line of the image, or the one line of zeros again
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tin = pt[u] * p.in_stride + p.shift[tap];
+            const bool ok = pv[u] && tin >= 0 && tin < p.t_in;
+            any = any || ok;
+            a_src[u] = (ok ? img + ((int64_t)pn[u] * p.t_in + tin) * row_pitch : (const f16*)p.zero_line) + a_src_seg(lane) * 8;
+            a_step[u] = ok ? 64 : 0;
+        }
+        if (!__syncthreads_or((int)any)) continue;             // (see gemm_kernel: dilations beyond the sequence)
+        const f16* wtap = reinterpret_cast<const f16*>((const float*)p.W + (int64_t)tap * p.tap_stride);
+        for (int kt = 0; kt < p.nkt; ++kt) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jb_glds16(a_src[u] + (int64_t)kt * a_step[u], s_glds + (wave * 4 + u) * 1024);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jb_glds16(wtap + w_off[u] + (int64_t)kt * 512, s_glds + A_BYTES + (wave * 4 + u) * 1024);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's share of the stage has landed ...
+            __syncthreads();                                            // ... everybody's has
+            f16x8 ah[4], al[4], wh[4], wl[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                ah[mt] = *reinterpret_cast<const f16x8*>(s_glds + a_byte(frag_row(wave_m, mt, lane), frag_seg(0, lane)));
+                al[mt] = *reinterpret_cast<const f16x8*>(s_glds + a_byte(frag_row(wave_m, mt, lane), frag_seg(1, lane)));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wh[j] = *reinterpret_cast<const f16x8*>(s_glds + w_byte(wave_n * 4 + j, 0, lane));
+                wl[j] = *reinterpret_cast<const f16x8*>(s_glds + w_byte(wave_n * 4 + j, 1, lane));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    acc[j][mt] = jb_mfma(wh[j], ah[mt], acc[j][mt]);
+                    acc2[j][mt] = jb_mfma(wh[j], al[mt], acc2[j][mt]);
+                    acc2[j][mt] = jb_mfma(wl[j], ah[mt], acc2[j][mt]);
+                }
+            __syncthreads();                                            // nobody still reads the stage the next step overwrites
+        }
+    }
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int64_t q = m0 + wave_m * 64 + mt * 16 + c;
+        if (q >= p.m_total) continue;
+        const int n = (int)(q / p.t_out), t = (int)(q - (int64_t)n * p.t_out);
+        const int64_t orow = (int64_t)n * p.out_seq_stride + (int64_t)t * p.out_stride + p.out_offset;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jb = (jt0 + wave_n * 4 + j) * 16 + g * 4;
+            if (jb < p.epi.J) epilogue_store<float>(p.epi, (acc[j][mt] + acc2[j][mt] * (1.0f / 2048.0f)) * p.w_unscale, orow, jb, -1);
+        }
+    }
+}
+
 // Epilogue of gemm_8phase_kernel.  With ONE workgroup per CU nothing covers a tile's epilogue, and the MFMA result layout
 // (a lane holds 4 consecutive columns of one row: 8 bytes, 16 rows per store instruction; 2-byte stores for a q / k / v
 // split) is store-issue-bound.  So each wave first applies bias -> round -> activation in registers, parks its 128 x 64
@@ -821,6 +956,11 @@ extern "C" void jb_tune_gemm_lds(int min_rows) { g_gemm_lds_min_rows = min_rows;
 
 static inline bool aligned_to(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
+// w_split problems that come with a scratch buffer (jb_gemm_args.a_split) split their activations once, in a pass of their own
+// (0: never -- the in-kernel split); jb_tune_gemm_presplit
+static int g_gemm_presplit = 1;
+extern "C" void jb_tune_gemm_presplit(int on) { g_gemm_presplit = on; }
+
 extern "C" int jb_gemm_split_overflow(int reset) {
     unsigned* w = split_overflow_word();
     if (!w) {
@@ -869,10 +1009,35 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     p.overflow = nullptr;
     p.w_unscale = a->w_split_unscale != 0.f ? a->w_split_unscale : 1.0f;
+    p.zero_line = nullptr;
     if (a->w_split) {
         p.overflow = split_overflow_word();
         JB_REQUIRE(p.overflow, "no host-coherent memory for the f16-split overflow flag");
-        gemm_split_kernel<<<grid, 256, 0, st>>>(p);
+        const int64_t img = (int64_t)a->n_seq * a->t_in * a->K;              // elements; the image holds 2 halves for each
+        if (a->a_split && a->a_split_bytes >= img * 4 && aligned_to(a->a_split, 128) && g_gemm_presplit) {
+            static const void* zero_lines[64] = {};
+            int dev = 0;
+            JB_HIP(hipGetDevice(&dev));
+            JB_REQUIRE(dev >= 0 && dev < 64, "device index");
+            if (!zero_lines[dev]) {
+                void* z = nullptr;
+                JB_HIP(hipMalloc(&z, 128));
+                JB_HIP(hipMemset(z, 0, 128));
+                JB_HIP(hipDeviceSynchronize());
+                zero_lines[dev] = z;
+            }
+            f16* image = (f16*)a->a_split;
+            const int64_t pieces = img / 8;
+            split_act_kernel<<<(unsigned)((pieces + 255) / 256), 256, 0, st>>>((const float*)a->A, a->lda, a->n_seq, a->t_in, a->in_seq_stride, a->K,
+                                                                               image, a->pre_relu, p.overflow);
+            JB_CHECK_LAUNCH();
+            p.A = image;
+            p.zero_line = zero_lines[dev];
+            const int MB = (int)((p.m_total + gi::BM - 1) / gi::BM), NB = (p.njt + gi::BJT - 1) / gi::BJT;
+            gemm_split_glds_kernel<<<(MB + 7) / 8 * 8 * NB, 256, gi::STAGE_BYTES, st>>>(p, MB, NB);
+        } else {
+            gemm_split_kernel<<<grid, 256, 0, st>>>(p);
+        }
         JB_CHECK_LAUNCH();
         return JB_OK;
     }

@@ -152,6 +152,9 @@ def gemm(A, pw, bias=None, out=None, res=None, n_seq=1, t_in=None, t_out=None, s
     a.pre_relu, a.act, a.res_scale = int(pre_relu), act, res_scale
     a.w_split = int(pw.split)
     a.w_split_unscale = float(pw.unscale)
+    if pw.split:            # scratch for the activations' hi / lo images (same bytes as the fp32 rows); the caching allocator recycles it
+        scratch = torch.empty(n_seq * t_in * pw.K, dtype=torch.float32, device=A.device)
+        a.a_split, a.a_split_bytes = scratch.data_ptr(), scratch.numel() * 4
     L.check(L.lib().jb_gemm(C.byref(a), L.stream()))
     return out
 

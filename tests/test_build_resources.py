@@ -12,9 +12,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "jukebox_amd", "csrc")
 HOT = {
-    "gemm.hip": ["gemm_glds_kernel", "gemm_lds_kernelIDF16_", "gemm_lds_kernelIf", "gemm_kernelIDF16_Lb1", "gemm_kernelIfLb1", "gemv_lnf_kernelIDF16_Li1ELi8ELi8",
+    "gemm.hip": ["gemm_glds_kernel", "gemm_8phase_kernel", "gemm_lds_kernelIDF16_", "gemm_lds_kernelIf", "gemm_kernelIDF16_Lb1", "gemm_kernelIfLb1", "gemv_lnf_kernelIDF16_Li1ELi8ELi8",
                  "gemv_lnf_kernelIDF16_Li1ELi16ELi10", "gemv_kernelIDF16_Li1ELi8ELb0ELb1ELi0", "gemv_kernelIfLi1ELi8ELb0ELb1ELi0",
-                 "gemv_kernelIDF16_Li1ELi16ELb0ELb1ELi0", "gemv_merge_kernelILi1ELi8", "gemm_split_kernel"],
+                 "gemv_kernelIDF16_Li1ELi16ELb0ELb1ELi0", "gemv_merge_kernelILi1ELi8", "gemm_split_kernel", "gemm_split_glds_kernel"],
     "attention.hip": ["attn_decode_wide_kernelILi15", "attn_decode_mfma_kernelILi8", "attn_decode_mfma_kernelILi5ELb1",
                       "attn_decode_split_kernelILi8", "attn_prefill_v2_kernelILi30", "attn_prefill_v2_kernelILi16"],
 }

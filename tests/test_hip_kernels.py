@@ -338,6 +338,70 @@ def test_conv_stack_ops_f16_split(H, Ci, Co, T, scale):
     print("f16-split conv stack Ci=%d scale=%g: worst error %.2e of the output scale" % (Ci, scale, worst))
 
 
+@pytest.mark.parametrize("Ci,Co,T", [(64, 72, 150), (1024, 256, 520)])
+def test_conv_stack_presplit_equals_the_split_inside_the_gemm(H, Ci, Co, T):
+    """jb_gemm_args.a_split (round 5): the activations of a w_split problem split once, by a pass of their own, into f16 hi / lo
+    images that the GEMM loads as finished operands.  Same operands, same MFMAs in the same order: the outputs must EQUAL those
+    of the split inside the GEMM bit for bit -- dilated k=3 with the input ReLU and a residual (dilations beyond the
+    sequence), the strided and the transposed convolution, sequences a pitch apart with rubbish between them (which the pass
+    must not look at: it would raise the range flag) -- and the range flag must come up from the pass as it does from the GEMM
+    (a value beyond the half range; a NaN under the input ReLU)."""
+    from jukebox_amd import _lib as L
+    rng = np.random.default_rng(Ci + T)
+    N = 3
+    x = (3.0 * rng.standard_normal((N * T, Ci))).astype(np.float32)
+    xr = dev(x)
+    pitch = T + 5
+    xp = torch.full((N * pitch, Ci), float("nan"), dtype=torch.float32, device="cuda")       # rubbish between the sequences
+    xp.view(N, pitch, Ci)[:, :T] = xr.view(N, T, Ci)
+    w3 = (rng.standard_normal((Co, Ci, 3)) / np.sqrt(3 * Ci)).astype(np.float32)
+    w4 = (rng.standard_normal((Co, Ci, 4)) / np.sqrt(4 * Ci)).astype(np.float32)
+    wt = (rng.standard_normal((Ci, Co, 4)) / np.sqrt(2 * Ci)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    R = rng.standard_normal((N * T, Co)).astype(np.float32)
+    p3 = H.pack_conv_taps(dev(w3), torch.float32, split=True)
+    p4 = H.pack_conv_taps(dev(w4), torch.float32, split=True)
+    pt = H.pack_conv_taps(dev(wt), torch.float32, transposed=True, split=True)
+
+    def run():
+        outs = []
+        for dil in (1, 27, 243):
+            outs.append(H.gemm(xr, p3, bias=dev(b), res=dev(R), res_scale=0.5, n_seq=N, t_in=T, shifts=(-dil, 0, dil), pre_relu=True))
+        outs.append(H.gemm(xp, p3, bias=dev(b), n_seq=N, t_in=T, shifts=(-3, 0, 3), in_seq_pitch=pitch))
+        outs.append(H.gemm(xr, p4, bias=dev(b), n_seq=N, t_in=T, t_out=T // 2, in_stride=2, shifts=(-1, 0, 1, 2)))
+        out = torch.empty((N * 2 * T, Co), dtype=torch.float32, device="cuda")
+        H.gemm(xr, H.tap_view(pt, [1, 3]), bias=dev(b), out=out, n_seq=N, t_in=T, t_out=T, shifts=(0, -1), out_stride=2, out_offset=0,
+               out_rows_per_seq=2 * T)
+        H.gemm(xr, H.tap_view(pt, [0, 2]), bias=dev(b), out=out, n_seq=N, t_in=T, t_out=T, shifts=(1, 0), out_stride=2, out_offset=1,
+               out_rows_per_seq=2 * T)
+        outs.append(out)
+        H.check_split_overflow()                           # nothing out of range, the rubbish rows were not looked at
+        return [o.cpu().numpy() for o in outs]
+
+    try:
+        L.lib().jb_tune_gemm_presplit(1)
+        pre = run()
+        L.lib().jb_tune_gemm_presplit(0)
+        inside = run()
+        for a, c in zip(pre, inside):
+            assert np.array_equal(a, c)
+        for on in (1, 0):
+            L.lib().jb_tune_gemm_presplit(on)
+            for bad, relu in ((7e4, False), (float("nan"), True), (-7e4, False)):
+                xb = xr.clone()
+                xb[T + 3, 5] = bad
+                H.gemm(xb, p3, n_seq=N, t_in=T, shifts=(-1, 0, 1), pre_relu=relu)
+                with pytest.raises(L.JukeboxHipError):
+                    H.check_split_overflow()
+            xb = xr.clone()
+            xb[T + 3, 5] = -7e4                            # what the input ReLU clips cannot overflow
+            H.gemm(xb, p3, n_seq=N, t_in=T, shifts=(-1, 0, 1), pre_relu=True)
+            H.check_split_overflow()
+    finally:
+        L.lib().jb_tune_gemm_presplit(1)
+        L.lib().jb_gemm_split_overflow(1)
+
+
 @pytest.mark.parametrize("wscale", [1e-5, 1e-3, 1.0, 3e4, 1e7])
 def test_conv_stack_f16_split_is_invariant_to_the_weights_scale(H, wscale):
     """A trained layer's weights can sit far below a half's normal range (|w| < 6e-5: hi halves subnormal, 11 bits gone) or
