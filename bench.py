@@ -358,6 +358,8 @@ def main():
     n_samples = a.samples_per_gpu * world
     hps = Hyperparams(n_samples=n_samples, sample_length=sample_length, hop_fraction=[0.5, 0.5, 0.125], sr=sr, name="bench",
                       keep_priors_resident=True, pipeline_levels=not a.no_pipeline, seed=0)
+    if os.environ.get("JB_PIPELINE_MAX_ENGINES"):         # experiments: how many levels may run pipelined launches side by side
+        hps.pipeline_max_engines = int(os.environ["JB_PIPELINE_MAX_ENGINES"])
     labels = synthetic_labels(priors, n_samples, 180 * sr if not tiny else 3 * 4608, device)
     sk = S.default_sampling_kwargs(a.model if not tiny else "1b_lyrics")
     audio_seconds_per_step = n_samples * sample_length / sr

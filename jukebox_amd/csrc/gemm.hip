@@ -1016,15 +1016,19 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
         const int64_t img = (int64_t)a->n_seq * a->t_in * a->K;              // elements; the image holds 2 halves for each
         if (a->a_split && a->a_split_bytes >= img * 4 && aligned_to(a->a_split, 128) && g_gemm_presplit) {
             static const void* zero_lines[64] = {};
+            static std::mutex zero_mutex;                       // (the levels' host threads may meet here on their first conv stack)
             int dev = 0;
             JB_HIP(hipGetDevice(&dev));
             JB_REQUIRE(dev >= 0 && dev < 64, "device index");
-            if (!zero_lines[dev]) {
-                void* z = nullptr;
-                JB_HIP(hipMalloc(&z, 128));
-                JB_HIP(hipMemset(z, 0, 128));
-                JB_HIP(hipDeviceSynchronize());
-                zero_lines[dev] = z;
+            {
+                std::lock_guard<std::mutex> lock(zero_mutex);
+                if (!zero_lines[dev]) {
+                    void* z = nullptr;
+                    JB_HIP(hipMalloc(&z, 128));
+                    JB_HIP(hipMemset(z, 0, 128));
+                    JB_HIP(hipDeviceSynchronize());
+                    zero_lines[dev] = z;
+                }
             }
             f16* image = (f16*)a->a_split;
             const int64_t pieces = img / 8;

@@ -162,7 +162,8 @@ class ConditionalAutoregressive2D(nn.Module):
         bool, or a callable that is asked again before every decode call and answers with a falsy value (not now) or with a
         REGIME -- any truthy, comparable token that names the conditions the launches would run under (the level pipeline:
         how many pipelined engines share the GPU).  The verdict of the in-situ comparison (`_decode`) against them stands
-        within the regime it was measured in; a new regime is measured afresh."""
+        within the regime it was measured in; a new regime is measured afresh ON A NEW PAIR, made after `pipeline_prepare(regime)`
+        (if the sampler set one) has chosen the kernel forms for that regime."""
         want = getattr(self, "pipeline_launches", None)
         if callable(want):
             want = want()
@@ -170,9 +171,16 @@ class ConditionalAutoregressive2D(nn.Module):
             eng._pipe_regime = want
             if not getattr(eng, "_pipe_timed_out", False):
                 eng._pipe_verdict = None
+            if eng.pipelined:
+                # the pair's graphs were captured for the OTHER regime's kernel forms (`pipeline_prepare`: the lean attention
+                # kernel beside another pipelined level, the fat one alone): release it, the switch below makes a new one
+                eng.set_pipelined(False)
         if want and getattr(eng, "_pipe_verdict", None) is False:
             want = False
         if want is not None and eng.pipelined != bool(want):
+            prepare = getattr(self, "pipeline_prepare", None)
+            if want and callable(prepare):
+                prepare(want)                      # (kernel forms are chosen when the pair's graphs are captured: next decode)
             eng.set_pipelined(bool(want))
 
     def release_pipeline(self):

@@ -241,13 +241,20 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # on and released when they go off or the job ends: two more hardware queues in the process -- even idle ones -- slowed the
     # concurrent levels' plain chains 2.5x (profiles/r04_pipe_in_job.log).
     n_pipe = int(hps.get("pipeline_max_engines", 1))
+    prepare = None
     if _want_pipelined_launches(hps) and t.device(device).type == "cuda":
         from . import _lib
-        _lib.lib().jb_tune_attn_decode_wide_lean(1 if n_pipe > 1 else 0)       # (read when an engine's graphs are captured)
+        # The kernel form goes with the REGIME, and is read when a pair's graphs are captured: the lean attention kernel (a
+        # workgroup fits beside a waiting projection workgroup: what lets two pipelined engines share the GPU) costs the level
+        # that runs alone 2 % (1.587 against 1.557 ms per step), so regime 2 captures the lean form, regime 1 the fat one, and a
+        # change of regime makes a new pair (ConditionalAutoregressive2D._apply_pipeline).
+        _lib.lib().jb_tune_attn_decode_wide_lean(0)
+        prepare = lambda regime: _lib.lib().jb_tune_attn_decode_wide_lean(1 if regime == 2 else 0)
     if _want_pipelined_launches(hps):
         cands = [l for l in sorted(sample_levels) if getattr(getattr(priors[l], "prior", None), "pipeline_candidate", False)][:n_pipe]
         others = [l for l in sample_levels if l not in cands]
         for l in cands:
+            priors[l].prior.pipeline_prepare = prepare
             priors[l].prior.pipeline_launches = (
                 lambda l=l: (1 + sum(1 for m in cands if m != l and m not in finished)) if all(m in finished for m in others) else 0)
     early_audio = {}
@@ -286,6 +293,7 @@ def _release_pipelines(priors, levels):
         ar = getattr(priors[level], "prior", None)
         if ar is not None:
             ar.pipeline_launches = None
+            ar.pipeline_prepare = None
             if callable(getattr(ar, "release_pipeline", None)):
                 ar.release_pipeline()
 

@@ -527,6 +527,56 @@ def test_in_situ_choice_between_the_launch_forms():
     assert tiny.calls == [(0, 200, True)] and not hasattr(tiny, "_pipe_verdict")
 
 
+def test_a_change_of_regime_makes_a_new_pair_with_that_regimes_kernel_forms():
+    """ConditionalAutoregressive2D._apply_pipeline, round 5: the kernel forms of a pipelined pair are chosen when its graphs are
+    captured (the lean attention kernel beside another pipelined level, the fat one alone: sample._sample_levels_pipelined's
+    `pipeline_prepare`), so an engine that is pipelined when the sampler names ANOTHER regime releases its pair first, has the
+    forms chosen for the new regime, and only then switches the launches on again; within a regime nothing is released, and
+    "not now" (0) just switches off."""
+    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
+    log = []
+
+    class FakeEngine:
+        pipelined = False
+        def set_pipelined(self, on, fresh=False):
+            log.append(("on" if on else "off"))
+            self.pipelined = bool(on)
+            return self.pipelined
+
+    class Host:
+        _apply_pipeline = AR._apply_pipeline
+
+    h, eng = Host(), FakeEngine()
+    h.pipeline_prepare = lambda regime: log.append(("prepare", regime))
+    say = [0]
+    h.pipeline_launches = lambda: say[0]
+    h._apply_pipeline(eng)
+    assert log == [] and not eng.pipelined                       # "not now", and it was off
+    say[0] = 2
+    h._apply_pipeline(eng)
+    assert log == [("prepare", 2), "on"] and eng._pipe_regime == 2
+    eng._pipe_verdict = True
+    h._apply_pipeline(eng)
+    assert log == [("prepare", 2), "on"] and eng._pipe_verdict is True      # same regime: nothing happens, the verdict stands
+    say[0] = 1                                                   # the level beside it has finished
+    h._apply_pipeline(eng)
+    assert log == [("prepare", 2), "on", "off", ("prepare", 1), "on"] and eng.pipelined
+    assert eng._pipe_regime == 1 and eng._pipe_verdict is None   # measured afresh on the new pair
+    say[0] = 0
+    h._apply_pipeline(eng)
+    assert log[-1] == "off" and not eng.pipelined
+    # a verdict against pipelined launches in this regime: the sampler's regime is answered with the plain chain, no pair is made
+    eng._pipe_verdict, n = False, len(log)
+    say[0] = 1
+    h._apply_pipeline(eng)
+    assert len(log) == n and not eng.pipelined
+    # without a hook (the sequential level loop, tests) the switch is what it was
+    h2, eng2 = Host(), FakeEngine()
+    h2.pipeline_launches = True
+    h2._apply_pipeline(eng2)
+    assert eng2.pipelined
+
+
 def test_f16_split_arithmetic_keeps_fp32_accuracy():
     """The arithmetic of gemm_split_kernel (jb_gemm_args.w_split), restated in numpy: x = hi + 2^-11 lo with hi = half(x),
     lo = half((x - hi) 2^11) for BOTH operands and w a = w_hi a_hi + 2^-11 (w_hi a_lo + w_lo a_hi), every half product exact.
