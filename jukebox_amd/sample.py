@@ -7,6 +7,7 @@ random streams, and the generated codes are all-gathered once per level (SURVEY.
 the whole job redundantly on every rank with identical seeds (sample.py:110-113)."""
 import contextlib
 import os
+import threading
 import time
 
 import torch as t
@@ -113,6 +114,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     ready_event = {}
     errors = []
     finished = set()                                       # levels whose codes are complete (their streams drained)
+    in_window = set()                                      # levels inside sample_single_window right now (not waiting for codes)
     levels = sorted(sample_levels, reverse=True)
     on_gpu = str(device).startswith("cuda")            # on CPU (host-logic tests) the schedule runs without streams
     current = torch_cuda_current_stream(device) if on_gpu else None
@@ -192,8 +194,12 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                     prior.window_tap = (chunk, publish) if tapped else None
                     t_w = time.perf_counter()
                     try:
+                        with cond:
+                            in_window.add(level)
                         out = sample_single_window(view, lab, k, level, prior, start, local_hps)
                     finally:
+                        with cond:
+                            in_window.discard(level)
                         prior.window_tap = None
                         timeline.append((level, start, round(t_w - t_job, 3), round(time.perf_counter() - t_job, 3)))
                     new_len = int(out[level].shape[1])
@@ -208,6 +214,12 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 callback = getattr(_sample, "level_done", None)
                 if on_gpu:
                     cur().synchronize()
+                # this level's phase is over: its engines' pairs of streams go BEFORE the level counts as finished -- an idle pair
+                # slows the other levels' plain chains, and the level below may only take the GPU for itself (regime 1: the fat
+                # attention kernel, which shares with no other owner) once this one owns nothing
+                level_ar = getattr(prior, "prior", None)
+                if level_ar is not None and callable(getattr(level_ar, "release_pipeline", None)):
+                    level_ar.release_pipeline()
                 with cond:
                     finished.add(level)
                     cond.notify_all()
@@ -253,10 +265,37 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     if _want_pipelined_launches(hps):
         cands = [l for l in sorted(sample_levels) if getattr(getattr(priors[l], "prior", None), "pipeline_candidate", False)][:n_pipe]
         others = [l for l in sample_levels if l not in cands]
+        shared_off = []                                        # non-empty: a level gave the shared regime up; it is over for all
+
+        def regime_of(l):
+            if not all(m in finished for m in others):
+                return 0
+            beside = sum(1 for m in cands if m != l and m not in finished)
+            return 1 if not beside else (0 if shared_off else 1 + beside)
+
+        # Levels enter the shared regime TOGETHER: the first to ask waits (its chain idle, the other's the faster for it) until
+        # the other asks too -- the lowest level looks every 512 steps, a tapped level every published chunk, about a second
+        # apart -- and gives up after `patience` seconds (the other level finished, or sits in a conditioner / prefill): plain
+        # chain until its next look.
+        meeting = _Rendezvous(len(cands))
+        patience = float(hps.get("pipeline_rendezvous_s", 2.5))
+        def meet(l, regime):
+            if regime == 1:
+                return True
+            # (nobody to meet while the other level waits for codes, sits between two windows or has not started: no waiting)
+            if not all(m in in_window for m in cands if m != l and m not in finished):
+                return False
+            return meeting.wait(patience) and not shared_off
+
         for l in cands:
-            priors[l].prior.pipeline_prepare = prepare
-            priors[l].prior.pipeline_launches = (
-                lambda l=l: (1 + sum(1 for m in cands if m != l and m not in finished)) if all(m in finished for m in others) else 0)
+            ar = priors[l].prior
+            ar.pipeline_prepare = prepare
+            ar.pipeline_rendezvous = (lambda regime, l=l: meet(l, regime)) if len(cands) > 1 else None
+            # ms per step a level of the shared regime must stay under (two pipelined upsampler engines side by side: 2.02;
+            # the broken states of DESIGN.md section 4.2 / 4.5: 3.0 - 6.8)
+            ar.pipeline_shared_regimes = {2: float(hps.get("pipeline_shared_bound_ms", 2.6))} if len(cands) > 1 else None
+            ar.pipeline_gave_up = lambda regime: shared_off.append(regime) if regime == 2 else None
+            ar.pipeline_launches = lambda l=l: regime_of(l)
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
     # (level, window start, seconds into the job at which the window's sampling began / ended) per window: diagnostics
@@ -279,6 +318,29 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     return zs_local
 
 
+class _Rendezvous:
+    """`parties` threads meet: wait(timeout) returns True in all of them once the last has arrived, False in one that waited
+    `timeout` seconds in vain (it leaves again: the next full meeting needs it back)."""
+
+    def __init__(self, parties):
+        self.parties, self.waiting, self.generation = parties, 0, 0
+        self.cond = threading.Condition()
+
+    def wait(self, timeout):
+        with self.cond:
+            gen = self.generation
+            self.waiting += 1
+            if self.waiting >= self.parties:
+                self.generation += 1
+                self.waiting = 0
+                self.cond.notify_all()
+                return True
+            if self.cond.wait_for(lambda: self.generation != gen, timeout):
+                return True
+            self.waiting -= 1
+            return False
+
+
 def torch_cuda_current_stream(device):
     return t.cuda.current_stream(device)
 
@@ -293,7 +355,7 @@ def _release_pipelines(priors, levels):
         ar = getattr(priors[level], "prior", None)
         if ar is not None:
             ar.pipeline_launches = None
-            ar.pipeline_prepare = None
+            ar.pipeline_prepare = ar.pipeline_rendezvous = ar.pipeline_shared_regimes = ar.pipeline_gave_up = None
             if callable(getattr(ar, "release_pipeline", None)):
                 ar.release_pipeline()
 

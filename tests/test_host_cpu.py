@@ -577,6 +577,123 @@ def test_a_change_of_regime_makes_a_new_pair_with_that_regimes_kernel_forms():
     assert eng2.pipelined
 
 
+def test_a_regime_shared_with_another_pipelined_level():
+    """Round 5, the two upsampler levels pipelined side by side (sample._sample_levels_pipelined, hps.pipeline_max_engines = 2):
+    a level enters the shared regime only TOGETHER with the other (`pipeline_rendezvous` says no: plain chain, asked again at the
+    next look); inside it there is no plain side to compare with, so the launches are held to the sampler's bound in ms per step
+    (`pipeline_shared_regimes`) on 16 + 240 steps, an engine that misses it switches off and tells the sampler
+    (`pipeline_gave_up`); the window is decoded in chunks of PIPE_RECHECK_STEPS with the sampler asked between them, so that the
+    end of the regime (the other level finished: regime 1, a new pair, the in-situ comparison as ever; or gave up: plain chain)
+    takes effect within a chunk.  Every position is decoded exactly once, in order, in every course of events."""
+    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
+
+    class FakeEngine:
+        def __init__(self, rate):
+            self.rate, self.pipelined, self.calls, self.switches = rate, False, [], []
+        def pipe_error(self):
+            return 0
+        def set_pipelined(self, on, fresh=False):
+            self.switches.append(bool(on))
+            self.pipelined = bool(on)
+            return self.pipelined
+        def decode(self, t0, n, plain=False):
+            self.calls.append((t0, n, self.pipelined and not plain))
+        def timed_decode(self, t0, n, plain=False):
+            self.decode(t0, n, plain=plain)
+            return (self.rate if self.pipelined and not plain else 2.3) * 1e-3
+
+    class Host:
+        _decode, _decode_window, _apply_pipeline = AR._decode, AR._decode_window, AR._apply_pipeline
+        PIPE_RECHECK_STEPS = AR.PIPE_RECHECK_STEPS
+
+    def covered(eng, t0, n):
+        pos = t0
+        for c0, cn, _ in eng.calls:
+            assert c0 == pos, eng.calls
+            pos += cn
+        assert pos == t0 + n
+
+    def host(say, partner_there):
+        h = Host()
+        h.gave_up, h.prepared = [], []
+        h.pipeline_launches = lambda: say[0]
+        h.pipeline_shared_regimes = {2: 2.6}
+        h.pipeline_rendezvous = lambda regime: regime == 1 or partner_there[0]
+        h.pipeline_prepare = h.prepared.append
+        h.pipeline_gave_up = h.gave_up.append
+        return h
+
+    # 1. the partner is not there: plain chunks; it arrives; the regime's launches meet the bound and are kept; asked every chunk
+    say, there = [2], [False]
+    h, eng = host(say, there), FakeEngine(2.02)
+    asked = []
+    h.pipeline_launches = lambda: (asked.append(len(eng.calls)), say[0])[1]
+    orig_timed = eng.timed_decode
+    def timed(t0, n, plain=False):                        # the partner arrives while this engine decodes its second plain chunk
+        if len(eng.calls) == 1:
+            there[0] = True
+        return orig_timed(t0, n, plain=plain)
+    eng.timed_decode = timed
+    h._decode_window(eng, 4096, 4096)
+    covered(eng, 4096, 4096)
+    assert eng.calls[:2] == [(4096, 512, False), (4608, 512, False)]
+    assert eng.calls[2:5] == [(5120, 16, True), (5136, 240, True), (5376, 256, True)]       # the bounded measurement, then the chunk's rest
+    assert eng._pipe_verdict is True and h.prepared == [2] and h.gave_up == [] and h.pipeline_report["bound_ms"] == 2.6
+    assert all(c[2] for c in eng.calls[2:]) and all(c[1] <= 1024 for c in eng.calls)           # chunked to the window's end
+    assert len(asked) >= 7                                                                     # the sampler was asked between the chunks
+    # 2. the other level finishes inside the window: regime 1 -- the pair released, the forms chosen again, the in-situ comparison
+    say, there = [2], [True]
+    h, eng = host(say, there), FakeEngine(2.02)
+    def launches():
+        if len(eng.calls) >= 5:
+            say[0] = 1
+            eng.rate = 1.6
+        return say[0]
+    h.pipeline_launches = launches
+    h._decode_window(eng, 0, 4096)
+    covered(eng, 0, 4096)
+    assert h.prepared == [2, 1] and eng.switches == [True, False, True, True] and eng._pipe_regime == 1   # (the last: the verdict confirmed)
+    assert eng._pipe_verdict is True and h.pipeline_report["regime"] == 1 and h.pipeline_report["plain_ms"] == 2.3
+    assert eng.calls[-1][2] and eng.calls[-1][1] > 1024                                        # alone: the rest of the window in one call
+    # 3. the regime's launches miss the bound (a broken state: 5.9 ms per step): off, the sampler is told, the window goes on plain
+    say, there = [2], [True]
+    h, eng = host(say, there), FakeEngine(5.9)
+    h.pipeline_gave_up = lambda regime: (h.gave_up.append(regime), say.__setitem__(0, 0))
+    h._decode_window(eng, 0, 4096)
+    covered(eng, 0, 4096)
+    assert h.gave_up == [2] and not eng.pipelined and eng._pipe_verdict is False
+    assert eng.calls[:2] == [(0, 16, True), (16, 240, True)] and not any(c[2] for c in eng.calls[2:])
+    # 4. the OTHER level gave up (the sampler says "not now" from then on): this one leaves the regime at its next chunk
+    say, there = [2], [True]
+    h, eng = host(say, there), FakeEngine(2.02)
+    def launches4():
+        if len(eng.calls) >= 6:
+            say[0] = 0
+        return say[0]
+    h.pipeline_launches = launches4
+    h._decode_window(eng, 0, 4096)
+    covered(eng, 0, 4096)
+    assert eng.switches == [True, False] and not eng.pipelined and not eng.calls[-1][2]
+
+
+def test_rendezvous_of_the_levels():
+    """sample._Rendezvous: all parties return True once the last has arrived; a party that waited in vain returns False and is
+    gone (the next meeting needs it again)."""
+    import threading
+    from jukebox_amd.sample import _Rendezvous
+    r = _Rendezvous(2)
+    assert r.wait(0.05) is False and r.waiting == 0
+    out = []
+    th = threading.Thread(target=lambda: out.append(r.wait(5.0)))
+    th.start()
+    import time
+    time.sleep(0.05)
+    assert r.wait(5.0) is True
+    th.join()
+    assert out == [True] and r.waiting == 0
+    assert r.wait(0.01) is False                           # a new meeting: alone again
+
+
 def test_f16_split_arithmetic_keeps_fp32_accuracy():
     """The arithmetic of gemm_split_kernel (jb_gemm_args.w_split), restated in numpy: x = hi + 2^-11 lo with hi = half(x),
     lo = half((x - hi) 2^11) for BOTH operands and w a = w_hi a_hi + 2^-11 (w_hi a_lo + w_lo a_hi), every half product exact.
