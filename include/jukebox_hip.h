@@ -124,7 +124,7 @@ void jb_tune_gemm_lds(int min_rows);
 /* fp16 problems of one tap at unit strides (rows = (sequence, position), any pitch between sequences) with at least
  * `min_rows` output rows use the LDS-DMA 128x128-tile kernel (default 256; < 0: never).  Bit-identical to the other kernels. */
 void jb_tune_gemm_glds(int min_rows);
-/* Of those, the problems with K a multiple of 128 and at least `min_tiles` 256x256 output tiles use the 8-phase kernel (one
+/* Of those, the problems with K >= 128 and at least `min_tiles` 256x256 output tiles use the 8-phase kernel (one
  * 8-wave workgroup per compute unit, two LDS stages of four half-tiles, the two wave rows half a phase apart; default 512;
  * < 0: never).  Bit-identical to the other kernels.  Replaces the same Conv1D.forward at q > 1
  * (jukebox/transformer/ops.py:97-101). */

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256, 3) void gemm_glds_kernel(GemmParams p, int MB,
     }
 }
 
-// The prefill's big projections since round 5 (K a multiple of 128, enough 256 x 256 tiles to fill the chip): the 8-phase K-loop of
+// The prefill's big projections since round 5 (K >= 128, enough 256 x 256 tiles to fill the chip): the 8-phase K-loop of
 // gemm_8phase.h -- one 8-wave workgroup per CU, 128 KiB of LDS in two stages of four half-tiles, the two wave rows half a phase
 // apart so that one group's operand reads and LDS-DMA requests run under the other's MFMA cluster.  Tile order, row addressing
 // (rows are (sequence, position) pairs with a pitch per sequence) and epilogue are gemm_glds_kernel's; same MFMA and k order per
@@ -855,8 +855,35 @@ __global__ __launch_bounds__(512, 1) void gemm_8phase_kernel(GemmParams p, int M
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) acc[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    g8::mainloop(src, p.nkt >> 1, s_glds, acc);
+    const int n_pairs = p.nkt >> 2;                     // loop iterations: two K-tiles = four 32-channel k-tiles each
+    g8::mainloop(src, n_pairs * 2, s_glds, acc);
     const int g = lane >> 4, c = lane & 15;
+    if (n_pairs * 4 < p.nkt) {
+        // K is not a multiple of 128 (the upsamplers' K = 480 projections: 3 iterations + 3 k-tiles; 5b_lyrics' K = 4800: 37 + 2):
+        // the last one to three k-tiles straight from L1 into the operand registers, as gemm_kernel does -- k ascending as ever
+        const T* a_row[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            int64_t q = m0 + wave_m * 128 + mt * 16 + c;
+            q = q < p.m_total ? q : p.m_total - 1;
+            const int64_t n = q / p.t_out, t = q - n * p.t_out;
+            a_row[mt] = (const T*)p.A + (n * p.in_seq_stride + t) * p.lda + g * 8;
+        }
+        const T* w_tile[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w_tile[j] = (const T*)p.W + ((int64_t)min(jt0 + wave_n * 4 + j, p.njt - 1) * p.nkt) * 512 + lane * 8;
+        for (int kt = n_pairs * 4; kt < p.nkt; ++kt) {
+            f16x8 wf[4], af[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = ld_frag<T>(w_tile[j] + (int64_t)kt * 512);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) af[mt] = ld_frag<T>(a_row[mt] + kt * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) acc[j][mt] = jb_mfma(wf[j], af[mt], acc[j][mt]);
+        }
+    }
     if (!fast_epi) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
@@ -1061,7 +1088,7 @@ extern "C" int jb_gemm(const jb_gemm_args* a, void* stream) {
             configured[dev] = true;
         }
         const int MB8 = (int)((p.m_total + g8::BM - 1) / g8::BM), NB8 = (p.njt + g8::BJT - 1) / g8::BJT;
-        if (a->K % 128 == 0 && g_gemm_8phase_min_tiles >= 0 && (int64_t)MB8 * NB8 >= g_gemm_8phase_min_tiles) {
+        if (a->K >= 128 && g_gemm_8phase_min_tiles >= 0 && (int64_t)MB8 * NB8 >= g_gemm_8phase_min_tiles) {
             static bool configured8[64] = {};
             if (dev >= 0 && dev < 64 && !configured8[dev]) {     // 144 KiB of dynamic LDS: above the 64-KiB default
                 JB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_8phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -176,10 +176,11 @@ def test_gemm_glds(H, M, K, J):
 
 
 @pytest.mark.parametrize("M,K,J", [(1300, 256, 264), (4096, 1920, 1440), (2048, 1920, 480), (777, 128, 1000), (8192, 1920, 1920),
-                                   (3000, 384, 200)])
+                                   (3000, 384, 200), (4096, 480, 1920), (1000, 160, 200), (2500, 224, 264), (700, 4800, 520)])
 def test_gemm_8phase(H, M, K, J):
     """The prefill's big projections since round 5 (gemm_8phase_kernel: 256 x 256 tile on 8 waves, two LDS stages of four
-    half-tiles filled by LDS-DMA, the two wave rows half a phase apart; K a multiple of 128): bit-identical to gemm_glds_kernel
+    half-tiles filled by LDS-DMA, the two wave rows half a phase apart; K >= 128, the k-tiles beyond a multiple of 128 straight
+    from L1 behind the loop: K = 480, 160, 224, 4800): bit-identical to gemm_glds_kernel
     and to the register-staged kernel on ragged rows / columns (partial tiles in both directions, fewer tiles than compute
     units), one to fifteen loop iterations, every epilogue, sequences a pitch apart -- and the same answer on every one of
     several launches (a missed ordering between an LDS-DMA request and an operand read shows as a rare wrong tile)."""
