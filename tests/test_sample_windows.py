@@ -234,6 +234,45 @@ def test_level_pipeline_names_the_regime_of_pipelined_launches():
     check_levels(zs, 2, top)
     assert all(x is False for x in seen[2] + seen[1]), (seen[2][:4], seen[1][:4])
     assert set(seen[0]) <= {0, 1} and seen[0][-1] == 1 and seen[0] == sorted(seen[0])
+    # two levels again, and one of them GIVES THE SHARED REGIME UP (its launches missed the bound, or a wait timed out:
+    # `pipeline_gave_up`, set by the sampler): from then on both are told "not now" while they run side by side -- neither may
+    # stay pipelined beside the other's plain chain -- and the survivor still gets regime 1 once it is alone.  The hooks the
+    # sampler hands out (rendezvous, bound, prepare) are taken back at the end of the job.
+    priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=top)
+    hps.keep_priors_resident, hps.pipeline_levels, hps.pipeline_chunk = True, True, 256
+    hps.pipeline_max_engines = 2
+    sk[2]["max_batch_size"] = 3
+    seen = {0: [], 1: [], 2: []}
+    started = {1: threading.Event(), 0: threading.Event()}
+    gave = []
+    for p in priors:
+        p.prior = FakeAR(p.level != 2)
+        p.after_publish = after_publish
+        orig = p.sample
+
+        def wrapped2(*a, _orig=orig, _p=p, **k):
+            w = _p.prior.pipeline_launches
+            r = w() if callable(w) else w
+            if _p.level == 0 and r == 2 and not gave:
+                assert _p.prior.pipeline_shared_regimes == {2: 2.6} and callable(_p.prior.pipeline_rendezvous)
+                _p.prior.pipeline_gave_up(2)
+                gave.append(len(seen[0]))
+                r = w()
+            seen[_p.level].append(r)
+            if _p.level in started:
+                started[_p.level].set()
+            out = _orig(*a, **k)
+            seen[_p.level].append(w() if callable(w) else w)
+            return out
+        p.sample = wrapped2
+    zs = S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
+    check_levels(zs, 2, top)
+    if gave:                                                         # (level 0 met regime 2 in this schedule)
+        after = seen[0][gave[0]:]
+        assert 2 not in after and after[-1] == 1 and after == sorted(after), after
+        assert 2 not in seen[1][-2:]
+    for p in priors:
+        assert p.prior.pipeline_launches is None and p.prior.pipeline_rendezvous is None and p.prior.pipeline_gave_up is None
 
 
 def test_pipelined_levels_refuse_a_total_length_below_a_lower_context():
