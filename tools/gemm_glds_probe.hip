@@ -18,7 +18,10 @@
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I tools tools/gemm_glds_probe.hip \
 //             -L jukebox_amd/csrc -ljukebox_hip -Wl,-rpath,$PWD/jukebox_amd/csrc -o tools/gemm_glds_probe
 // Run:    tools/gemm_glds_probe            (prints one line per shape and variant)
-// STATUS: written at the end of round 3 with the GPU budget spent -- compiles, index arithmetic verified, NOT yet run.
+// History: written at the end of round 3, first run in round 4 (gemm_glds_kernel went into the library: profiles/r04_gemm_glds_probe.log);
+// round 5 added the 8-phase 256 x 256 kernel (jukebox_amd/csrc/gemm_8phase.h: the K-loop the library's gemm_8phase_kernel shares) with
+// the wave groups in lock step or half a phase apart, the library's own gemm_8phase_kernel (line-wise epilogue) timed through jb_gemm,
+// and ablations of the loop (no LDS-DMA / no operand reads / neither / no MFMAs / barriers only): profiles/r05_gemm_8phase_probe*.log.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
