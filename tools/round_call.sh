@@ -9,6 +9,9 @@
 #        the driver's own (~17 minutes)      -> gpurun_out/<tag>_bench_<seconds>s_1gpu.json
 #     4. rocprofv3 kernel statistics of `bench.py --roofline-only` (the dominant kernel's average duration must agree with the
 #        line's roofline.avg_launch_us)       -> gpurun_out/<tag>_roofline_only_kernel_stats.csv
+#     5. a level-0 window stage by stage through the sampler's own entry point (conditioner, prefill, decode, everything else)
+#                                             -> gpurun_out/<tag>_window_glue.log
+# (Round 5's last full call was this with `r05f 20 1`: profiles/r05f_*.)
 # Copy what is to be judged into profiles/.  Always `python -u` and a `timeout` of your own: a call that runs into gpurun's
 # limit is lost.
 TAG=${1:-r05}; SECS=${2:-6}; STEPS=${3:-2}
@@ -32,3 +35,4 @@ cd /tmp && rm -rf /tmp/prof_roof && timeout 600 rocprofv3 --kernel-trace --stats
 cd $GRAFT_REPO_ROOT
 cp $(find /tmp/prof_roof -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_roofline_only_kernel_stats.csv 2>/dev/null
 head -4 gpurun_out/${TAG}_roofline_only_kernel_stats.csv | cut -c1-200; cat gpurun_out/${TAG}_roofline_only_stdout.json | cut -c1-500
+timeout 200 python -u tools/window_glue.py --steps 512 --windows 2 > gpurun_out/${TAG}_window_glue.log 2>&1; tail -16 gpurun_out/${TAG}_window_glue.log
