@@ -261,6 +261,13 @@ class ConditionalAutoregressive2D(nn.Module):
             # step: well above what two pipelined engines side by side take, well below the broken states DESIGN.md section 4.2
             # lists); an engine that misses it tells the sampler (`pipeline_gave_up`), which ends the regime for both levels.
             bound = float(self.pipeline_shared_regimes[eng._pipe_regime])
+            if getattr(eng, "_pipe_settled", None) != eng._pipe_regime:
+                # the first call after the levels met is not a measurement: both are making their pairs (stream handshakes, two
+                # graph captures each) inside it -- the 6-second job's level 0 measured 2.75 ms per step there and left a regime
+                # that runs at 2.02 (profiles/r05_bench_6s_two_engines_dynamic2.json)
+                eng._pipe_settled = eng._pipe_regime
+                eng.decode(t0, n_steps)
+                return
             warm, n_pipe = (16, 240) if n_steps >= 512 else (8, 112)
             eng.decode(t0, warm)
             ms = None

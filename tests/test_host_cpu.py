@@ -581,7 +581,7 @@ def test_a_regime_shared_with_another_pipelined_level():
     """Round 5, the two upsampler levels pipelined side by side (sample._sample_levels_pipelined, hps.pipeline_max_engines = 2):
     a level enters the shared regime only TOGETHER with the other (`pipeline_rendezvous` says no: plain chain, asked again at the
     next look); inside it there is no plain side to compare with, so the launches are held to the sampler's bound in ms per step
-    (`pipeline_shared_regimes`) on 16 + 240 steps, an engine that misses it switches off and tells the sampler
+    (`pipeline_shared_regimes`) on 16 + 240 steps of the SECOND chunk (the first is where both make their pairs), an engine that misses it switches off and tells the sampler
     (`pipeline_gave_up`); the window is decoded in chunks of PIPE_RECHECK_STEPS with the sampler asked between them, so that the
     end of the regime (the other level finished: regime 1, a new pair, the in-situ comparison as ever; or gave up: plain chain)
     takes effect within a chunk.  Every position is decoded exactly once, in order, in every course of events."""
@@ -637,7 +637,8 @@ def test_a_regime_shared_with_another_pipelined_level():
     h._decode_window(eng, 4096, 4096)
     covered(eng, 4096, 4096)
     assert eng.calls[:2] == [(4096, 512, False), (4608, 512, False)]
-    assert eng.calls[2:5] == [(5120, 16, True), (5136, 240, True), (5376, 256, True)]       # the bounded measurement, then the chunk's rest
+    assert eng.calls[2] == (5120, 512, True)                                                    # the chunk in which the pairs are made: no measurement
+    assert eng.calls[3:6] == [(5632, 16, True), (5648, 240, True), (5888, 256, True)]       # the bounded measurement, then the chunk's rest
     assert eng._pipe_verdict is True and h.prepared == [2] and h.gave_up == [] and h.pipeline_report["bound_ms"] == 2.6
     assert all(c[2] for c in eng.calls[2:]) and all(c[1] <= 1024 for c in eng.calls)           # chunked to the window's end
     assert len(asked) >= 7                                                                     # the sampler was asked between the chunks
@@ -645,7 +646,7 @@ def test_a_regime_shared_with_another_pipelined_level():
     say, there = [2], [True]
     h, eng = host(say, there), FakeEngine(2.02)
     def launches():
-        if len(eng.calls) >= 5:
+        if len(eng.calls) >= 6:
             say[0] = 1
             eng.rate = 1.6
         return say[0]
@@ -662,7 +663,7 @@ def test_a_regime_shared_with_another_pipelined_level():
     h._decode_window(eng, 0, 4096)
     covered(eng, 0, 4096)
     assert h.gave_up == [2] and not eng.pipelined and eng._pipe_verdict is False
-    assert eng.calls[:2] == [(0, 16, True), (16, 240, True)] and not any(c[2] for c in eng.calls[2:])
+    assert eng.calls[:3] == [(0, 512, True), (512, 16, True), (528, 240, True)] and not any(c[2] for c in eng.calls[3:])
     # 4. the OTHER level gave up (the sampler says "not now" from then on): this one leaves the regime at its next chunk
     say, there = [2], [True]
     h, eng = host(say, there), FakeEngine(2.02)
