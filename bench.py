@@ -220,6 +220,56 @@ def projection_roofline(eng, t0, n_steps):
                        "layers (cold weights per launch, as in the real step)")
 
 
+def engine_step_report(eng, t0, n_steps=256, pipelined=True):
+    """ms per token step of one engine at position t0 (graph replay: plain chain, and software-pipelined launches where the
+    engine has them), the algorithmic bytes of that step (jb_engine_step_bytes) and the fraction of the HBM peak."""
+    eng.set_pipelined(False)
+    eng.decode(t0, 8)
+    plain = eng.timed_decode(t0, n_steps) * 1e3
+    rep = dict(n_batch=eng.N, position=t0, steps_timed=n_steps, launches_per_step=eng.launches_per_step, ms_per_step_plain_chain=round(plain, 4))
+    best = plain
+    if pipelined and eng.set_pipelined(True):
+        eng.decode(t0, 16)
+        pipe = eng.timed_decode(t0, n_steps) * 1e3
+        if not eng.pipe_error() and eng.pipelined:
+            rep["ms_per_step_pipelined_launches"] = round(pipe, 4)
+            best = min(best, pipe)
+        eng.set_pipelined(False)
+    gb = eng.step_bytes(t0 + n_steps // 2) / 1e9
+    rep.update(ms_per_step=round(best, 4), algorithmic_gb_per_step=round(gb, 4), weights_gb=round(eng.weight_bytes() / 1e9, 3),
+               frac_of_hbm_peak=round(gb / (best * 1e-3) / HBM_PEAK_GBS, 4))
+    return rep
+
+
+def other_configs(priors, n_batch, device):
+    """BASELINE.json's configs 2, 3 and 5 as decode-step lines next to the headline (config 4): 256 graph-replayed token steps
+    of each engine at the reference's batch sizes -- small_prior (hparams.py:210-220; N = 16, mid-window), the prior_1b_lyrics
+    top prior of THIS job right behind its 384-token lyric prefill (hparams.py:165-188; N = 16), and the prior_5b_lyrics decoder
+    (hparams.py:127-156: 4800 wide, 79 layers, 8 heads, attn_order 10, 512 encoder states; N = 3, random-init).  Outside the
+    timed region; what tools/bench_engine.py prints, in the line the driver runs."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_engine import CFGS, random_state
+    from jukebox_amd.engine import PriorEngine
+    out = {}
+    top = priors[2].prior.bound_engine()
+    if top is not None and top.N == n_batch:
+        top.prefill(0, priors[2].n_tokens)               # the lyric prefix of the job's last window is still in the token buffer
+        out["config3_1b_lyrics_top_prior"] = engine_step_report(top, priors[2].n_tokens)
+    for key, name, n, t0 in (("config2_small_prior", "small", 16, 4096), ("config5_5b_lyrics_top_prior", "5b", 3, 4096)):
+        cfg = CFGS[name]
+        eng = PriorEngine(random_state(cfg, device), "", n_batch=n, fp16=True, chunk_cap=64, **cfg)
+        y = torch.randn(n, 1, cfg["width"], device=device) * 0.01 if cfg["y_cond"] else None
+        eng.set_cond(torch.randn(n, cfg["seq_len"], cfg["width"], device=device) * 0.01, y)
+        eng.set_sampling(temp=0.99, seed=1)
+        if cfg.get("encoder_dims"):
+            eng.set_encoder_kv(torch.randn(n, cfg["encoder_dims"], cfg["width"], device=device) * 0.1)
+        out[key] = engine_step_report(eng, t0)
+        eng.close()
+        del eng
+        torch.cuda.empty_cache()
+    return out
+
+
 def roofline_only(a, device):
     """Level-0 upsampler only: 256 graph-replayed decode steps at t = 4096.. plus the in-situ probe.  This is the
     command whose rocprofv3 kernel-trace summary is committed under profiles/."""
@@ -358,8 +408,6 @@ def main():
     n_samples = a.samples_per_gpu * world
     hps = Hyperparams(n_samples=n_samples, sample_length=sample_length, hop_fraction=[0.5, 0.5, 0.125], sr=sr, name="bench",
                       keep_priors_resident=True, pipeline_levels=not a.no_pipeline, seed=0)
-    if os.environ.get("JB_PIPELINE_MAX_ENGINES"):         # experiments: how many levels may run pipelined launches side by side
-        hps.pipeline_max_engines = int(os.environ["JB_PIPELINE_MAX_ENGINES"])
     labels = synthetic_labels(priors, n_samples, 180 * sr if not tiny else 3 * 4608, device)
     sk = S.default_sampling_kwargs(a.model if not tiny else "1b_lyrics")
     audio_seconds_per_step = n_samples * sample_length / sr
@@ -376,9 +424,13 @@ def main():
 
     step_t0 = []
 
+    step_codes = []        # every timed step's codes (device tensors, a few MB each): digested AFTER the timed region
+
     def one_step():
         step_t0.append(time.perf_counter())
-        return S.ancestral_sample(labels, sk, priors, hps, save=False, device=device)
+        zs = S.ancestral_sample(labels, sk, priors, hps, save=False, device=device)
+        step_codes.append(zs)
+        return zs
 
     # Warm-up (untimed): at most ONE pass of the same three-level job on 6 s of audio per sample -- every kernel, graph
     # capture and allocation of the timed step without its length (a full-length pass costs minutes).
@@ -395,9 +447,24 @@ def main():
     level_t.clear()
     level_t0.clear()
     cpu_leg_s = 0.0 if (world > 1 or a.no_cpu_baseline) else 120.0
+    if world == 1 and not tiny:
+        cpu_leg_s += 60.0                  # (the decode-step lines of BASELINE's other configs: other_configs)
     steps_done, dt, per_step, zs = timed_steps(one_step, max(a.steps, 1), world, device, 45.0 + cpu_leg_s,
                                                lambda: torch.cuda.synchronize())
     assert all(int(z.shape[1]) == sample_length // p.raw_to_tokens for z, p in zip(zs, priors))
+    # The timed job's own tokens: every step samples the same job with the same seed, and the draw of (level, sample, position)
+    # is a pure function of the seed -- whatever the launch form a window ran in, the moment the levels' threads met, the
+    # in-situ comparison or a recovered time-out did to the schedule -- so every step must produce the SAME codes on every
+    # level.  (tests/test_hip_models.py::test_timed_job_tokens holds the pipelined schedule to the sequential plain chain.)
+    import hashlib
+    step_digests = []
+    for zs_i in step_codes:
+        h = hashlib.sha256()
+        for z in zs_i:
+            h.update(z.to("cpu", torch.int64).contiguous().numpy().tobytes())
+        step_digests.append(h.hexdigest())
+    assert len(set(step_digests)) == 1, f"the timed steps did not produce the same codes: {step_digests}"
+    del step_codes[:]
     di = dist_info(world, rank, device, per_step, a.samples_per_gpu)
 
     if rank != 0:
@@ -405,7 +472,8 @@ def main():
     value = audio_seconds_per_step * steps_done / dt
     # per-level wall time of the LAST timed step
     t_last = step_t0[-1]
-    breakdown = {"levels_pipelined": not a.no_pipeline, "step_seconds": [round(x, 2) for x in per_step]}
+    breakdown = {"levels_pipelined": not a.no_pipeline, "step_seconds": [round(x, 2) for x in per_step],
+                 "step_digests": step_digests, "step_digests_note": "SHA-256 over the codes of all levels of each timed step; asserted equal"}
     for l in (2, 1, 0):          # seconds from the start of the step until level l had produced all its codes
         if l in level_t:
             breakdown[f"level{l}_codes_done_at_s"] = round(level_t[l][-1] - t_last, 3)
@@ -433,7 +501,7 @@ def main():
     breakdown["level0_launch_form"] = "pipelined" if kept else "plain chain"
     if report:
         breakdown["level0_in_situ_comparison_ms_per_step"] = report
-    # every in-situ comparison of the last jobs, per level (regime 2: the two upsampler levels pipelined side by side; 1: alone)
+    # every in-situ comparison of the last jobs, per level
     for l in (1, 0):
         reps = getattr(getattr(priors[l], "prior", None), "pipeline_reports", None)
         if reps:
@@ -451,6 +519,12 @@ def main():
     step_bytes = eng.step_bytes(4096 if not tiny else 64)
     breakdown["level0_decode_step_algorithmic_gb"] = round(step_bytes / 1e9, 4)
     breakdown["level0_decode_step_frac_of_hbm_peak"] = round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+
+    if world == 1 and not tiny and a.model == "1b_lyrics" and budget_left() > 200:
+        try:
+            breakdown["other_configs"] = other_configs(priors, a.samples_per_gpu, device)
+        except Exception as e:   # noqa: BLE001 -- an auxiliary report must never cost the bench line
+            breakdown["other_configs"] = dict(error=f"{type(e).__name__}: {e}")
 
     out = dict(metric=BASELINE_METRIC, value=round(value, 4), unit="audio_s/s",
                n_gpus=world, steps=steps_done, warmup=n_warm, steps_requested=a.steps, warmup_requested=a.warmup,

@@ -356,6 +356,10 @@ typedef struct jb_engine_cfg {
      * eight shard flags (32 words apart each); the last 32-word group starts with an error word (slot + 1 of a launch whose wait for its producer timed out; 0 = none; never reset by
      * the library). */
     unsigned* pipe_words;
+    /* rows the decode-step buffers x_a, x_b and mlp hold (0 = n_batch).  With 16 rows, the pipelined launches of a single-head
+     * engine hand their activation blocks over in the order the consumer's MFMA operands want them -- [k-tile][lane][8 channels],
+     * always 16 rows -- instead of [row][channel] (jb_tune_pipeline). */
+    int act_rows;
 } jb_engine_cfg;
 
 /* Transformer.forward(sample=True) + the token loop of ConditionalAutoregressive2D.sample/primed_sample
@@ -395,6 +399,13 @@ int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* str
  * enable makes a new one (milliseconds).  enable = 2 is enable = 1 with a fresh pair at the next decode.  The engine must
  * be idle in every case.  Replaces the same reference code as jb_engine_decode. */
 int jb_engine_pipeline(void* handle, int enable);
+/* The hand-off form of the pipelined launches, read when an engine's pair of graphs is captured: operand_order = 1 (default) --
+ * the activation blocks between the launches in MFMA operand order ([k-tile][lane][8 channels] of 16 rows: a consumer wave's
+ * fetch of a k-tile is one contiguous KiB, a producer's 16 x 16 tile two runs of 256 bytes) where the engine can (single head,
+ * cfg.act_rows >= 16); 0 -- [row][channel] (16 half lines per wave request).  Measured on the upsampler step at 16 samples:
+ * 1.438 against 1.572 ms.  Same arithmetic either way: tokens and logits stay bit-identical to the plain chain.  The reference
+ * has no counterpart (its hand-off between two layers is a tensor in HBM: jukebox/transformer/transformer.py:62-66,82-86). */
+void jb_tune_pipeline(int operand_order);
 /* 1 while the engine's decode steps run as pipelined launches, else 0 (also after a fallback to the plain chain). */
 int jb_engine_pipelined(void* handle);
 /* 1 while the engine holds a pair of streams for pipelined launches (from its first pipelined decode until

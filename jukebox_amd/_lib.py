@@ -12,6 +12,10 @@ ACT_NONE, ACT_RELU, ACT_QUICK_GELU = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libjukebox_hip.so")
+# measurement build of the same sources (-DJB_PIPE_SEGMENTS: per-segment clock stamps of the pipelined launches, common.h), loaded
+# instead of the product library ONLY when a measurement tool asks for it (tools/phase_segments.py sets JB_LIB_SEGMENTS=1)
+if os.environ.get("JB_LIB_SEGMENTS") == "1":
+    LIB_PATH = os.path.join(_HERE, "csrc", "libjukebox_hip_segments.so")
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -63,7 +67,7 @@ class EngineCfg(C.Structure):
                 ("c_mlp", vp), ("c_xf", vp), ("tokens", vp), ("tok_stride", i64), ("t_dev", vp),
                 ("preds", vp), ("preds_n_stride", i64), ("sample_params", vp),
                 ("rec_layer", i32), ("rec_head", i32), ("rec_keys", i32), ("rec_out", vp), ("rec_n_stride", i64),
-                ("att_ld", i32), ("pipe_words", vp)]
+                ("att_ld", i32), ("pipe_words", vp), ("act_rows", i32)]
 
 
 _SIGS = {
@@ -90,6 +94,7 @@ _SIGS = {
     "jb_attn_decode_wide": (i32, [i32, vp, i64, vp, vp, i32, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "jb_attn_decode_wide_supported": (i32, [i32, i32, i32, i32, i32]),
     "jb_tune_attn_decode_wide_lean": (None, [i32]),
+    "jb_tune_pipeline": (None, [i32]),
     "jb_tune_attn_decode_split": (None, [i32, i32]),
     "jb_tune_attn_decode_split_min_keys": (None, [i32]),
     "jb_tune_gemm_lds": (None, [i32]),
@@ -141,6 +146,9 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)          # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
+        # experiments: the hand-off form of the pipelined launches (jb_tune_pipeline) from the environment
+        if os.environ.get("JB_PIPE_FRAG"):
+            l.jb_tune_pipeline(int(os.environ["JB_PIPE_FRAG"]))
         _lib = l
     return _lib
 

@@ -363,7 +363,9 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     // epilogue operands of this thread's output channel (blockDim.x >= d): requested with the query, used at the end
     const int och = sl * d + min((int)threadIdx.x, d - 1);
     const float bias_e = bias[och];
-    const f16 res_e = res[(int64_t)n * ldr + och];
+    // (PIPE with operand-order hand-offs, common.h: the residual stream in and out is [k-tile][lane][8], 16 rows per block)
+    const bool frag_res = PIPE && (pipe.frag & JB_FRAG_RES), frag_out = PIPE && (pipe.frag & JB_FRAG_OUT);
+    const f16 res_e = res[frag_res ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldr + och];
     jb_issue_fence();
     // PIPE: the position was written by the previous step's last launch, which this stream has already seen complete
     // (an attention launch is never the first of a step): the key set is known before the wait.
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
             }
         }
         jb_issue_fence();
-        jb_pipe_wait(pipe, pipe_own);
+        jb_pipe_wait(pipe, pipe_own, (int)(blockDim.x >> 6) - 1);      // (the last wave: usually nothing of its own in flight)
         if constexpr (QL) {
             if (lane * 8 < d) *reinterpret_cast<f16x8*>(s_q + lane * 8) = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + lane * 8);
         } else {
@@ -453,7 +455,8 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
             for (int dt = 0; dt < ND32; ++dt) qf[dt] = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + dt * 32 + g * 8);
         }
         if (ks.count == 0) {      // zero rows -> attention output 0 -> c_proj gives its bias
-            if (threadIdx.x < d) jb_st_sc1(out, (int64_t)n * ldo + och, (f16)jb_round<f16>((float)res_e + jb_round<f16>(jb_round<f16>(bias_e))));
+            if (threadIdx.x < d) jb_st_sc1(out, frag_out ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldo + och,
+                                           (f16)jb_round<f16>((float)res_e + jb_round<f16>(jb_round<f16>(bias_e))));
             jb_pipe_publish(pipe, pipe_own);
             return;
         }
@@ -471,6 +474,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
             }
             if constexpr (QL) jb_issue_fence_before_use(kf[0]);
             else jb_issue_fence_before_use(qf[0]);
+            JB_SEG_VM(pipe, 5);
             tile_math(kf, vv, kbase_i);
         }
     } else {
@@ -514,11 +518,12 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
         for (int w = 0; w < nw; ++w) a += s_o[w * d + ch] * expf(s_ml[2 * w] - m);
         const float cp = jb_round<f16>(a * inv + jb_round<f16>(bias_e));
         const float v1 = jb_round<f16>((float)res_e + cp);
-        const float a1 = __shfl_down(v1, 1, 64), a2 = __shfl_down(v1, 2, 64), a3 = __shfl_down(v1, 3, 64);
+        const float a1 = jb_dpp<0x55>(v1), a2 = jb_dpp<0xAA>(v1), a3 = jb_dpp<0xFF>(v1);     // lanes 1, 2, 3 of the thread's quad
         if ((int)threadIdx.x < d && (threadIdx.x & 3) == 0) {
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
             const f16x4 o4 = {(f16)v1, (f16)a1, (f16)a2, (f16)a3};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), jb_rsrc(out), (int)(((int64_t)n * ldo + och) * 2), 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), jb_rsrc(out),
+                                                  (int)((frag_out ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldo + och) * 2), 0, 16);
         }
         jb_pipe_publish(pipe, pipe_own);
         return;
@@ -730,12 +735,13 @@ extern "C" int jb_attn_decode_wide(int attn_func, const void* q, int64_t ldq, co
 }
 
 // 480-channel heads (the 1b upsamplers): 1 = the lean form of the kernel (query through LDS, <= 168 registers per lane: shares a
-// compute unit with a waiting projection workgroup of a pipelined chain: what two pipelined engines side by side need), 0
-// (default) = the fat form, 0.4 us per launch faster for an engine that has the GPU to itself (1.557 against 1.587 ms per
-// upsampler step, profiles/r05_bench_engine_lean_vs_fat_attention.log).  jb_tune_attn_decode_wide_lean.
+// compute unit with a waiting projection workgroup of a pipelined chain; round 5 ran two pipelined engines side by side on it:
+// 2.02 against 2.09 ms per step, no gain for the job, the two-engine admission is gone since round 6), 0 (default) = the fat
+// form, 0.4 us per launch faster for an engine that has the GPU to itself (1.557 against 1.587 ms per upsampler step,
+// profiles/r05_bench_engine_lean_vs_fat_attention.log).  jb_tune_attn_decode_wide_lean: kept as a measured variant, bit-equal
+// to the fat form (tests/test_hip_kernels.py).
 static int g_wide_lean = 0;
 extern "C" void jb_tune_attn_decode_wide_lean(int on) { g_wide_lean = on ? 1 : 0; }
-int jb_attn_decode_wide_lean() { return g_wide_lean; }
 
 int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache_w, int cache_cap,
                              const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
@@ -753,7 +759,7 @@ int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const vo
     if (pipe) {
         JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30),
                    "a pipelined launch of the wide-value attention takes d_head = 480 and caches below 2 GiB");
-        JB_REQUIRE(pipe->proto != 1 || (int64_t)grid.x * grid.y >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
+        JB_REQUIRE(pipe->proto < 1 || (int64_t)grid.x * grid.y >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
         if (lean)
             attn_decode_wide_kernel<15, true, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
                                                                              (const f16*)vcache_w, cache_cap, (const f16*)res, ldr,
@@ -821,7 +827,7 @@ int jb_attn_decode_impl(int dtype, int attn_func, const void* q, int64_t ldq, co
     dim3 grid(n_batch, n_head);
     hipStream_t s = (hipStream_t)stream;
     const JbPipe nopipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr};
-    JB_REQUIRE(!pipe || pipe->proto != 1 || (int64_t)n_batch * n_head >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
+    JB_REQUIRE(!pipe || pipe->proto < 1 || (int64_t)n_batch * n_head >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
     JB_REQUIRE(!pipe || (jb_attn_decode_pipe_supported(dtype, d_head, (int)ldq, (int)ldo, n_head * d_head) &&
                          (int64_t)n_batch * cache_cap * n_head * d_head < (1ll << 30)),
                "a pipelined launch of the decode attention takes fp16 heads of 150 (ragged), 256 or 512 channels and caches below 2 GiB");

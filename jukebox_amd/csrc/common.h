@@ -175,7 +175,34 @@ struct JbPipe {
     long long* dbg;                                  // optional [slot][4] stamps of the 100 MHz clock (JB_PIPE_DEBUG): poll
                                                      // entered, producer seen, own completion published
     int proto;                                       // completion protocol: 0 = two-level ticket + one flag, 1 = a flag word per shard
+    int frag;                                        // JB_FRAG_*: which activation blocks of this launch are in OPERAND ORDER (below)
 };
+// Activation blocks of <= 16 rows handed from one pipelined launch to the next may be laid out in the order the consumer's MFMA
+// B operands want them -- [k-tile][lane = (channel / 8 mod 4) * 16 + row][8 channels], 1 KiB per k-tile -- instead of [row][channel]:
+// a consumer wave's 16-byte-per-lane fetch of a k-tile is then ONE contiguous KiB (8 full 128-byte lines) instead of 16 half
+// lines 2 * width bytes apart, and a producer workgroup's 16 x 16 tile leaves as 2 runs of 256 bytes instead of 16 runs of 32.
+// The block always holds 16 rows (engines of fewer samples leave the others untouched).
+constexpr int JB_FRAG_X = 1, JB_FRAG_OUT = 2, JB_FRAG_RES = 4;
+__host__ __device__ __forceinline__ int jb_frag_el(int row, int col) {      // element index of (row, channel) in operand order
+    return (col >> 5) * 512 + ((((col >> 3) & 3) << 4) + row) * 8 + (col & 7);
+}
+constexpr int JB_PIPE_STAMPS = 16;                   // clock stamps per launch slot (JB_PIPE_DEBUG; 4 in the product build, 10 with JB_PIPE_SEGMENTS)
+// Build with -DJB_PIPE_SEGMENTS (python -m jukebox_amd.csrc.build --segments -> libjukebox_hip_segments.so, tools/phase_segments.py)
+// for the per-segment account of a pipelined phase: workgroup 0 of every launch stamps, and WAITS where the product build does
+// not have to (operands landed, partial tiles in LDS), so its own timeline is the account's; the other workgroups run as ever.
+//   0 poll entered   1 producer's flags seen   4 barrier behind the poll passed   5 operand fragments landed (vmcnt 0)
+//   6 last MFMA / tile arithmetic retired, partials written to LDS   7 LDS exchange barrier passed   3 stores issued
+//   8 stores drained (vmcnt 0)   9 own ticket returned   2 the launch's last workgroup has published
+#ifdef JB_PIPE_SEGMENTS
+#define JB_SEG_ON(P) ((P).dbg && blockIdx.x == 0 && blockIdx.y == 0)
+#define JB_SEG(P, k) do { if (JB_SEG_ON(P) && threadIdx.x == 0) (P).dbg[(P).slot * JB_PIPE_STAMPS + (k)] = wall_clock64(); } while (0)
+#define JB_SEG_VM(P, k) do { if (JB_SEG_ON(P)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); JB_SEG(P, k); } } while (0)
+#define JB_SEG_LGKM(P, k) do { if (JB_SEG_ON(P)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); JB_SEG(P, k); } } while (0)
+#else
+#define JB_SEG(P, k) do { } while (0)
+#define JB_SEG_VM(P, k) do { } while (0)
+#define JB_SEG_LGKM(P, k) do { } while (0)
+#endif
 constexpr int JB_PIPE_PAD = 32;                      // words between two slots' completion words (128 bytes)
 constexpr int JB_PIPE_TICKET_WORDS = 17 * JB_PIPE_PAD;  // per slot: 8 shard tickets + the shard count + (protocol 1) 8 shard flags
 // words the caller provides: completion counts, tickets, one error word
@@ -208,35 +235,44 @@ __device__ __forceinline__ void jb_st_sc1(f16* base, int64_t el, f16 v) {
 // Own completion count: every thread asks for it next to its first requests (a broadcast load).
 __device__ __forceinline__ unsigned jb_pipe_own(const JbPipe& P) { return jb_ld_word(P.runs + P.slot * JB_PIPE_PAD); }
 // Wait for the producer launch; ends in a workgroup barrier.
-__device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own) {
-    if (P.proto == 1) {
+// poll_wave: the wave that polls (the others wait at the barrier).  A poll is a vector load and returns IN ORDER behind
+// everything its wave has requested before: a wave with a long prefetch outstanding (the attention's K / v' rows: 245 KB per
+// workgroup, longer than its head start) learns of the flags only when that has landed, so the attention polls from its last
+// wave, which owns a 16-key tile only at the latest positions.
+__device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own, int poll_wave = 0) {
+    const int pt = (int)threadIdx.x - poll_wave * 64;              // lane of the polling wave (other waves: outside 0..63)
+    if (P.proto >= 1) {
         // Protocol 1: the last arriver of each of the 8 ticket shards stores the run's number into the shard's own flag word
         // (its own 128-byte line, written once per run); lanes 0..7 of the first wave poll one flag each.  No second-level
         // ticket: one atomic round trip less per launch.  Every launch of the step has >= 8 workgroups (engines of >= 8 samples).
-        if (threadIdx.x < 64) {
+        // (Round 6 measured FOUR staggered polls in flight instead of the serial loop -- a flag would be seen a round trip and a
+        // quarter after it was written instead of one to two: probe 4.04 against 4.08 us per phase, engine 1.607 against 1.572 ms
+        // per step, 1.484 against 1.438 with operand-order hand-offs: no gain, removed; profiles/r06c1_*.)
+        if (pt >= 0 && pt < 64) {
             const unsigned need = P.slot == 0 ? own : own + 1;
-            const unsigned* w = P.tickets + (size_t)P.prev * JB_PIPE_TICKET_WORDS + (9 + (threadIdx.x & 7)) * JB_PIPE_PAD;
-            const bool stamp = P.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0;
-            if (stamp) P.dbg[P.slot * 4] = wall_clock64();
+            const unsigned* w = P.tickets + (size_t)P.prev * JB_PIPE_TICKET_WORDS + (9 + (pt & 7)) * JB_PIPE_PAD;
+            const bool stamp = P.dbg && pt == 0 && blockIdx.x == 0 && blockIdx.y == 0;
+            if (stamp) P.dbg[P.slot * JB_PIPE_STAMPS] = wall_clock64();
             const long long t0 = wall_clock64();
             unsigned spins = 0;
-            while (!__all(threadIdx.x >= 8 || jb_ld_word(w) >= need)) {
+            while (!__all(pt >= 8 || jb_ld_word(w) >= need)) {
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 255u) == 0) {
                     if (jb_ld_word(P.err) != 0u) break;
-                    if (wall_clock64() - t0 > P.timeout) { if (threadIdx.x == 0) jb_st_word(P.err, (unsigned)P.slot + 1u); break; }
+                    if (wall_clock64() - t0 > P.timeout) { if (pt == 0) jb_st_word(P.err, (unsigned)P.slot + 1u); break; }
                 }
             }
-            if (stamp) P.dbg[P.slot * 4 + 1] = wall_clock64();
+            if (stamp) P.dbg[P.slot * JB_PIPE_STAMPS + 1] = wall_clock64();
         }
         __syncthreads();
+        JB_SEG(P, 4);
         return;
     }
-    if (threadIdx.x == 0) {
+    if (pt == 0) {
         const unsigned need = P.slot == 0 ? own : own + 1;
         const unsigned* w = P.runs + P.prev * JB_PIPE_PAD;
         const bool stamp = P.dbg && blockIdx.x == 0 && blockIdx.y == 0;
-        if (stamp) P.dbg[P.slot * 4] = wall_clock64();
+        if (stamp) P.dbg[P.slot * JB_PIPE_STAMPS] = wall_clock64();
         if (jb_ld_word(w) < need) {
             const long long t0 = wall_clock64();
             unsigned spins = 0;
@@ -250,21 +286,31 @@ __device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own) {
                 }
             }
         }
-        if (stamp) P.dbg[P.slot * 4 + 1] = wall_clock64();
+        if (stamp) P.dbg[P.slot * JB_PIPE_STAMPS + 1] = wall_clock64();
     }
     __syncthreads();
+    JB_SEG(P, 4);
 }
 // After the last store of every thread: drain the write-through stores, count the workgroup in, the last one publishes.
 __device__ __forceinline__ void jb_pipe_publish(const JbPipe& P, unsigned own) {
-    if (P.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) P.dbg[P.slot * 4 + 3] = wall_clock64();
+    if (P.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) P.dbg[P.slot * JB_PIPE_STAMPS + 3] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    JB_SEG(P, 8);
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned* tk = P.tickets + (size_t)P.slot * JB_PIPE_TICKET_WORDS;
         const unsigned n_wg = gridDim.x * gridDim.y * gridDim.z;
         const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), shard = b & 7u;
         const unsigned members = (n_wg - shard + 7u) >> 3, n_shards = n_wg < 8u ? n_wg : 8u;
-        if (__hip_atomic_fetch_add(tk + shard * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+        const unsigned arrived = __hip_atomic_fetch_add(tk + shard * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef JB_PIPE_SEGMENTS
+        if (JB_SEG_ON(P)) {
+            P.dbg[P.slot * JB_PIPE_STAMPS + 9] = wall_clock64() + (long long)(arrived & 0u);      // (waits for the returned value)
+            P.dbg[P.slot * JB_PIPE_STAMPS + 10] = wall_clock64();      // 10, 11: two stamps back to back -- what a stamp itself costs
+            P.dbg[P.slot * JB_PIPE_STAMPS + 11] = wall_clock64();
+        }
+#endif
+        if (arrived == members - 1) {
             jb_st_word(tk + shard * JB_PIPE_PAD, 0u);
             // protocol 1: the shard's flag is what the consumer waits for -- published first; the count of finished shards comes
             // after it, off the consumer's path, and only guards the slot's OWN count: that word is read by every workgroup of
@@ -272,11 +318,11 @@ __device__ __forceinline__ void jb_pipe_publish(const JbPipe& P, unsigned own) {
             // compute unit), so it may move only once every workgroup of this run has arrived.  (Round 4's first form let
             // shard 0's last arriver write it: a workgroup that started after that read the next run's number, waited for a
             // completion that belongs to the next step, and timed out -- once in a 20-second job.)
-            if (P.proto == 1) jb_st_word(tk + (9 + shard) * JB_PIPE_PAD, own + 1);
+            if (P.proto >= 1) jb_st_word(tk + (9 + shard) * JB_PIPE_PAD, own + 1);
             if (__hip_atomic_fetch_add(tk + 8 * JB_PIPE_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_shards - 1) {
                 jb_st_word(tk + 8 * JB_PIPE_PAD, 0u);
                 jb_st_word(P.runs + P.slot * JB_PIPE_PAD, own + 1);
-                if (P.dbg) P.dbg[P.slot * 4 + 2] = wall_clock64();
+                if (P.dbg) P.dbg[P.slot * JB_PIPE_STAMPS + 2] = wall_clock64();
             }
         }
     }
@@ -291,7 +337,6 @@ int jb_attn_decode_pipe_supported(int dtype, int d_head, int ldq, int ldo, int S
 int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const void* kcache, const void* vcache_w, int cache_cap,
                              const void* res, int64_t ldr, const float* bias, void* x_out, int64_t ldo, int n_batch, int d_head,
                              int width, int block_ctx, const int* t_dev, int max_len, const JbPipe* pipe, void* stream);
-int jb_attn_decode_wide_lean();        // jb_tune_attn_decode_wide_lean's state (engine.hip: how many engines may be pipelined)
 int jb_sample_step_impl(const float* logits, int n_batch, int bins, const jb_sample_params* params, int64_t* tokens,
                         int64_t tok_stride, int* t_dev, float* preds, int64_t preds_n_stride, int x_dtype, void* x_next,
                         const float* x_emb, const float* pos_emb, const float* x_cond, int64_t xc_n_stride, int64_t xc_t_stride,

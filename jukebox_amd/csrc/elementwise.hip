@@ -403,7 +403,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                 const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                 if constexpr (PIPE) {
                     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), jb_rsrc(tail.x_next), (int)(((int64_t)n * W + i) * 2), 0, 16);
+                    // (operand-order hand-offs, common.h: the next step's first projection fetches [k-tile][lane][8])
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), jb_rsrc(tail.x_next),
+                                                          (int)(((pipe.frag & JB_FRAG_OUT) ? (int64_t)jb_frag_el(n, i) : (int64_t)n * W + i) * 2), 0, 16);
                 } else {
                     *reinterpret_cast<f16x4*>((f16*)tail.x_next + (int64_t)n * W + i) = o;
                 }
@@ -431,7 +433,7 @@ static int launch_sample(const float* logits, int n_batch, int bins, const jb_sa
     const size_t lds = (size_t)n2 * sizeof(float);
     if (pipe) {
         if (tail.x_dtype != JB_F16 || !tail.x_next) JB_UNSUPPORTED("a pipelined sampler launch takes the fp16 decode step's tail");
-        if (pipe->proto == 1 && n_batch < 8) JB_UNSUPPORTED("completion protocol 1 needs launches of >= 8 workgroups (>= 8 samples)");
+        if (pipe->proto >= 1 && n_batch < 8) JB_UNSUPPORTED("completion protocol 1 needs launches of >= 8 workgroups (>= 8 samples)");
         sample_kernel<true><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds, preds_n_stride,
                                                             tail, *pipe);
     } else {

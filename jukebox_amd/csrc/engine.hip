@@ -14,21 +14,16 @@
 
 #include "common.h"
 
-// the engines of the process that may run pipelined launches (jb_engine_pipeline): at most JB_MAX_PIPE_OWNERS at a time
+// the engine of the process that runs pipelined launches (jb_engine_pipeline): one at a time
 static std::mutex g_pipe_mutex;
-constexpr int JB_MAX_PIPE_OWNERS = 2;
-static void* g_pipe_owners[JB_MAX_PIPE_OWNERS] = {nullptr, nullptr};
-static bool pipe_owner(const void* e) {               // caller holds g_pipe_mutex
-    for (void* o : g_pipe_owners) if (o == e) return true;
-    return false;
-}
+static void* g_pipe_owner = nullptr;
 static bool pipe_own(void* e) {                       // caller holds g_pipe_mutex
-    if (pipe_owner(e)) return true;
-    for (void*& o : g_pipe_owners) if (!o) { o = e; return true; }
-    return false;
+    if (g_pipe_owner && g_pipe_owner != e) return false;
+    g_pipe_owner = e;
+    return true;
 }
 static void pipe_disown(const void* e) {              // caller holds g_pipe_mutex
-    for (void*& o : g_pipe_owners) if (o == e) o = nullptr;
+    if (g_pipe_owner == e) g_pipe_owner = nullptr;
 }
 
 struct JbEngine {
@@ -48,7 +43,20 @@ struct JbEngine {
     hipGraphExec_t pexec[2] = {nullptr, nullptr};
 };
 
+// Hand-off form of the pipelined launches, read when an engine's pair of graphs is captured (jb_tune_pipeline): activation blocks
+// between the launches in MFMA operand order (common.h: JB_FRAG_*; single-head engines whose decode buffers hold 16 rows,
+// jb_engine_cfg.act_rows) or as [row][channel].
+static int g_pipe_frag = 1;
+extern "C" void jb_tune_pipeline(int operand_order) { g_pipe_frag = operand_order ? 1 : 0; }
+
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
+// [row][channel] -> operand order (common.h: jb_frag_el), n rows of `width` halves; rows n..15 of dst are left alone
+__global__ void to_operand_order_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int n, int width) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 8;        // 8 consecutive channels of one row: one 16-byte piece
+    if (i >= n * width) return;
+    const int row = i / width, col = i - row * width;
+    *reinterpret_cast<f16x8*>(dst + jb_frag_el(row, col)) = *reinterpret_cast<const f16x8*>(src + (int64_t)row * width + col);
+}
 __global__ void inc_int_kernel(int* p) { *p += 1; }
 
 extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers, void** handle) {
@@ -92,6 +100,7 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
     JB_REQUIRE(cfg->bins <= 0 || !cfg->x_out_packed || cfg->ticket, "ticket counter missing");
     JB_REQUIRE(cfg->width % 4 == 0, "width must be a multiple of 4");
     JB_REQUIRE(cfg->att_ld == 0 || cfg->att_ld >= cfg->n_state, "att_ld must be 0 or >= n_state");
+    JB_REQUIRE(cfg->act_rows == 0 || cfg->act_rows >= cfg->n_batch, "act_rows must be 0 or >= n_batch");
     JB_REQUIRE(!cfg->rec_out || (cfg->rec_layer >= 0 && cfg->rec_layer < cfg->n_layers && cfg->rec_keys > 0 &&
                                  cfg->rec_head >= 0 && cfg->rec_head < cfg->n_head), "bad attention recording request");
     JbEngine* e = new JbEngine();
@@ -214,6 +223,14 @@ static int enqueue_embed(JbEngine* e, int t0, hipStream_t s) {
                     c.xc_n_stride, c.xc_t_stride, c.n_batch, c.width, t0, nullptr, 1, s);
 }
 
+static bool pipeline_eligible_multi_head(const JbEngine* e);
+// Whether this engine's pipelined launches hand their activation blocks over in operand order (common.h): the single-head
+// wide-value form (every launch of its step is one of the four kernels that know the layout), decode buffers of 16 rows, whole
+// 32-channel k-tiles in width and MLP (pipeline_eligible), and the switch (jb_tune_pipeline).
+static bool pipe_operand_order(const JbEngine* e) {
+    return g_pipe_frag && e->cfg.act_rows >= 16 && e->cfg.n_batch <= 16 && e->cfg.dtype == JB_F16 && !pipeline_eligible_multi_head(e);
+}
+
 // One decode step at position *t_dev (x_a already holds that position's embedding); everything position-dependent is
 // read on the device.  Leaves the next position's embedding in x_a and *t_dev advanced.
 // parity < 0: every launch on `s` (the plain chain).  parity 0 / 1: software-pipelined step -- only the even / odd launches
@@ -230,12 +247,15 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
               c.pipe_words ? c.pipe_words + jb_pipe_words(n_slots) - JB_PIPE_PAD : nullptr, 0, 0,
               (getenv("JB_PIPE_TIMEOUT_MS") ? atoll(getenv("JB_PIPE_TIMEOUT_MS")) : 2000ll) * 100000ll,
               (c.pipe_words && getenv("JB_PIPE_DEBUG")) ? reinterpret_cast<long long*>(c.pipe_words + jb_pipe_words(n_slots)) : nullptr,
-              c.n_batch >= 8 ? 1 : 0};
-    // the pipeline slot of the next launch, or NULL for the plain chain; `mine`: this call enqueues it
+              c.n_batch >= 8 ? 1 : 0, 0};
+    const bool frag = parity >= 0 && pipe_operand_order(e);
+    // the pipeline slot of the next launch, or NULL for the plain chain; `mine`: this call enqueues it; `layout`: which of the
+    // launch's activation blocks (JB_FRAG_X operand, JB_FRAG_OUT output, JB_FRAG_RES residual) are in operand order
     bool mine = true;
-    auto next = [&]() -> const JbPipe* {
+    auto next = [&](int layout = 0) -> const JbPipe* {
         mine = parity < 0 || (slot & 1) == parity;
         pp.slot = slot; pp.prev = slot == 0 ? n_slots - 1 : slot - 1;
+        pp.frag = frag ? layout : 0;
         ++slot;
         return parity < 0 ? nullptr : &pp;
     };
@@ -244,7 +264,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
         jb_gemv_args g;
         // a7/a8/a9: ln_0 + c_attn, k/v appended at *t_dev
         fill_c_attn(g, c, L);
-        { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
+        { const JbPipe* pipe = next(JB_FRAG_X); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }      // (q and the cache rows stay [row][channel])
         // attention, then attn.c_proj + residual: x_b = x_a + a
         const int parts = layer_split_parts(c, L);
         g = {};
@@ -252,7 +272,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
         g.dtype = c.dtype; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
         g.out = c.x_b; g.ldo = W; g.res = c.x_a; g.ldr = W;
         if (layer_wide(c, L)) {
-            const JbPipe* pipe = next();
+            const JbPipe* pipe = next(JB_FRAG_RES | JB_FRAG_OUT);
             if (mine) JB_TRY(jb_attn_decode_wide_impl(L.attn_func, c.q, S, L.kcache, L.vcache_w, L.cache_cap, c.x_a, W, L.b_proj, c.x_b,
                                                       W, N, S, W, c.block_ctx, c.t_dev, c.seq_len, pipe, s));
         } else if (parts > 0) {
@@ -278,7 +298,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
         g = {};
         fill_ln_proj(g, c, L, 1);
         g.x = c.x_b; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
-        { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
+        { const JbPipe* pipe = next(JB_FRAG_X | JB_FRAG_OUT); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
         // mlp.c_proj + residual: x_a = x_b + m   (h = x + a + m, transformer.py:82-83); the last layer also hands the
         // logits head xf = float(x_a) (+ cond[t], autoregressive.py:226-227)
         g = {};
@@ -288,14 +308,14 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
             g.out2 = c.xf; g.ldo2 = W; g.t_dev = c.t_dev;
             if (c.add_cond_after && c.x_cond) { g.add2 = c.x_cond; g.add2_n_stride = c.xc_n_stride; g.add2_t_stride = c.xc_t_stride; }
         }
-        { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
+        { const JbPipe* pipe = next(JB_FRAG_X | JB_FRAG_RES | JB_FRAG_OUT); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }   // (xf stays fp32 [row][channel])
     }
     jb_gemv_args g = {};
     g.dtype = JB_F32; g.x = c.xf; g.ldx = W; g.n_rows = N; g.W = c.x_out_packed; g.K = W; g.J = c.bins;
     g.out = c.logits; g.ldo = c.bins;
     { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
     {
-        const JbPipe* pipe = next();
+        const JbPipe* pipe = next(JB_FRAG_OUT);
         if (mine) JB_TRY(jb_sample_step_impl(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds,
                                              c.preds_n_stride, c.dtype, c.x_a, c.x_emb, c.pos_emb, c.x_cond, c.xc_n_stride,
                                              c.xc_t_stride, W, c.seq_len, c.ticket, pipe, s));
@@ -345,26 +365,16 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     if (enable && !pipeline_eligible(e)) JB_UNSUPPORTED("this engine's decode step has launches without a pipelined form (needs pipe_words, "
                                                         "fp16, <= 16 samples, and either wide-value layers of one 480-channel head on "
                                                         "33..64 k-tiles or folded-LayerNorm multi-head layers without key splits)");
-    // At most TWO pipelined engines per process.  A waiting launch holds up to 180 workgroup slots (8 waves at 88 registers per
-    // lane: two such workgroups fill a compute unit) while it spins, and the producer it waits for must still find room.  The
-    // waiters of two engines take <= 360 of the chip's 512 such slots, so >= 152 compute units keep half of their registers
-    // free -- enough for a projection workgroup or for a LEAN wide-value attention workgroup (<= 168 registers per lane,
-    // attention.hip), which every eligible engine's attention launches are: the producers of both engines always make progress.
-    // (Round 4's one-owner rule came from the fat attention kernel, 198 registers per lane: one workgroup per otherwise EMPTY
-    // compute unit, and the waiters of two engines can leave none -- every slot timed out.)  A third engine's waiters could
-    // cover all 512 slots.
+    // ONE pipelined engine per process.  A waiting launch holds up to 180 workgroup slots (8 waves at <= 96 registers per lane:
+    // two such workgroups fill a compute unit) while it spins, and the producer it waits for must still find room -- the
+    // wide-value attention workgroup needs an otherwise EMPTY compute unit, and the waiters of two engines can leave none (round
+    // 4: every slot timed out).  Round 5 admitted two engines on a lean form of that kernel; side by side they ran at 2.02 ms
+    // per step against 2.09 for two plain chains and the job did not get faster: removed in round 6.
     JB_REQUIRE(enable >= 0 && enable <= 2, "enable must be 0, 1 or 2");
     std::lock_guard<std::mutex> lock(g_pipe_mutex);
     if (enable) {
-        // (multi-head engines -- 16-wave attention and projection workgroups that fill a compute unit -- share with nobody)
-        const bool other = (g_pipe_owners[0] && g_pipe_owners[0] != e) || (g_pipe_owners[1] && g_pipe_owners[1] != e);
-        bool other_multi_head = false;
-        for (void* o : g_pipe_owners) other_multi_head = other_multi_head || (o && o != e && pipeline_eligible_multi_head((JbEngine*)o));
-        if (other && (!jb_attn_decode_wide_lean() || pipeline_eligible_multi_head(e) || other_multi_head))
-            JB_UNSUPPORTED("another engine of this process runs pipelined launches, and only two single-head engines on the lean "
-                           "attention kernel (jb_tune_attn_decode_wide_lean(1)) can share the GPU that way");
-        if (!pipe_own(e)) JB_UNSUPPORTED("two other engines of this process run pipelined launches (two at a time: switch one off "
-                                         "or destroy it first)");
+        if (!pipe_own(e)) JB_UNSUPPORTED("another engine of this process runs pipelined launches (one at a time: switch it off or "
+                                         "destroy it first)");
         if (enable == 2) release_pipeline(e);   // a fresh pair of streams and fresh graphs at the next decode
     } else {
         // switched off = gone: streams, hardware queues and graphs are released now and made again (milliseconds) the next
@@ -485,6 +495,15 @@ static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s, bool use_gr
     JB_TRY(prepare_pipeline(e));
     // completion counts and tickets start from zero in every call
     JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));
+    if (pipe_operand_order(e)) {
+        // the first position's embedding (jb_engine_decode has just written it as rows) in the order the first projection fetches
+        // it; x_b is free until the first attention launch writes it
+        const jb_engine_cfg& c = e->cfg;
+        const int pieces = c.n_batch * c.width / 8;
+        to_operand_order_kernel<<<(pieces + 255) / 256, 256, 0, s>>>((const f16*)c.x_a, (f16*)c.x_b, c.n_batch, c.width);
+        JB_CHECK_LAUNCH();
+        JB_HIP(hipMemcpyAsync(c.x_a, c.x_b, (size_t)16 * c.width * sizeof(f16), hipMemcpyDeviceToDevice, s));
+    }
     JB_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < n_steps; ++i)
         for (int k = 0; k < 2; ++k) {

@@ -188,19 +188,21 @@ __device__ __forceinline__ float epilogue_value(const EpiParams& p, float x, flo
 // hand them to the first, which stores them write-through in one piece (f16: 8 bytes, fp32: 16); likewise the fp32 second
 // output.  Called by whole waves; jt16 = first column of the workgroup's tile (its destination region is uniform).
 template <typename T>
-__device__ __forceinline__ void pipe_store4(const EpiParams& p, float x, float x2, int64_t orow, int jb, int jt16, int64_t cache_row, bool valid) {
+__device__ __forceinline__ void pipe_store4(const EpiParams& p, float x, float x2, int64_t orow, int jb, int jt16, int64_t cache_row, bool valid,
+                                            bool frag_out = false) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const float a1 = __shfl_down(x, 1, 64), a2 = __shfl_down(x, 2, 64), a3 = __shfl_down(x, 3, 64);
+    // (quad broadcasts in the vector ALU: lanes 1, 2, 3 of every aligned group of four; a __shfl_down is an LDS-crossbar round trip)
+    const float a1 = jb_dpp<0x55>(x), a2 = jb_dpp<0xAA>(x), a3 = jb_dpp<0xFF>(x);
     float b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    if (p.out2) { b1 = __shfl_down(x2, 1, 64); b2 = __shfl_down(x2, 2, 64); b3 = __shfl_down(x2, 3, 64); }
+    if (p.out2) { b1 = jb_dpp<0x55>(x2); b2 = jb_dpp<0xAA>(x2); b3 = jb_dpp<0xFF>(x2); }
     if (!valid || (threadIdx.x & 3)) return;
     if (p.out2) {
         const f32x4 o2 = {x2, b1, b2, b3};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o2), jb_rsrc(p.out2), (int)((orow * p.ldo2 + jb) * 4), 0, 16);
     }
     T* base = (T*)p.out;
-    int64_t el = orow * p.ldo + jb;
+    int64_t el = (frag_out && !p.qkv_split) ? (int64_t)jb_frag_el((int)orow, jb) : orow * p.ldo + jb;     // (the query rows stay [row][channel])
     if (p.qkv_split && jt16 >= p.S) {
         if (cache_row < 0) return;
         if (jt16 < 2 * p.S) { base = (T*)p.kcache; el = cache_row * p.S + (jb - p.S); }
@@ -1200,7 +1202,7 @@ struct EpiOperands {
             const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
             bias[u] = bias_p[jc];
             c1[u] = c1_p[jc];
-            res[u] = (float)res_p[(int64_t)rc * ldr + jc];
+            res[u] = (float)res_p[(ALT && (p.pipe.frag & JB_FRAG_RES) && p.epi.res) ? (int64_t)jb_frag_el(rc, jc) : (int64_t)rc * ldr + jc];
         }
         (void)jt; (void)MT;
     }
@@ -1450,12 +1452,21 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
                     if constexpr (LNS) {
                         xf[i][mt] = *reinterpret_cast<const V*>(s_x + (int64_t)row * pitch + k0);
                     } else if constexpr (PIPE) {
-                        xf[i][mt] = jb_ld_frag_sc1<T>(x, (int64_t)row * p.ldx + k0);       // the producer launch's rows
+                        // the producer launch's rows (operand order: k-tile by k-tile, a contiguous KiB per wave request)
+                        xf[i][mt] = jb_ld_frag_sc1<T>(x, (p.pipe.frag & JB_FRAG_X) ? (int64_t)min(kb + i, p.nkt - 1) * (64 * E) + lane * E
+                                                                                   : (int64_t)row * p.ldx + k0);
                     } else {
                         if (kb == kt0) xf[i][mt] = xf0[i][mt];
                         else xf[i][mt] = ld_frag<T>(x + (int64_t)row * p.ldx + k0);
                     }
                 }
+            }
+            if constexpr (PIPE) {
+                // every fragment of the batch is requested before the first is waited for: the MFMA chain hangs on acc[0], so
+                // none of it (and none of its waits) can be scheduled above the requests -- the compiler used to wait for the
+                // first fragment with the last two or three requests still unissued: a second dependent round trip
+                asm volatile("" : "+v"(acc[0]) :: "memory");
+                JB_SEG_VM(p.pipe, 5);
             }
 #pragma unroll
             for (int i = 0; i < WB; ++i) {
@@ -1486,7 +1497,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     JB_STAMP(5);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
+    if constexpr (PIPE) JB_SEG_LGKM(p.pipe, 6);
     __syncthreads();
+    if constexpr (PIPE) JB_SEG(p.pipe, 7);
     JB_STAMP(6);
     eo.finish(p);
     if constexpr (PIPE) {
@@ -1501,7 +1514,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
             for (int w = 0; w < NW; ++w) v += sa[(w * 64 + l) * 4 + r];
             const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
             const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
-            pipe_store4<T>(p.epi, xo, xo + e_add2[0], row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J);
+            pipe_store4<T>(p.epi, xo, xo + e_add2[0], row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J, (p.pipe.frag & JB_FRAG_OUT) != 0);
         }
         jb_pipe_publish(p.pipe, pipe_own);
         return;
@@ -1576,8 +1589,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
             const int k0 = min(kt0 + i, p.nkt - 1) * KT + g * E;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                xf[i][mt] = jb_ld_frag_sc1<T>(x, (int64_t)min(mt * 16 + c, p.n_rows - 1) * p.ldx + k0);
+                xf[i][mt] = jb_ld_frag_sc1<T>(x, (p.pipe.frag & JB_FRAG_X) ? (int64_t)min(kt0 + i, p.nkt - 1) * (64 * E) + lane * E
+                                                                           : (int64_t)min(mt * 16 + c, p.n_rows - 1) * p.ldx + k0);
         }
+        jb_issue_fence();                      // (all of them in flight before the first MFMA's wait)
+        JB_SEG_VM(p.pipe, 5);
     }
     int t = 0;
     if (p.epi.qkv_split) t = PIPE ? (int)jb_ld_word(reinterpret_cast<const unsigned*>(p.t_dev)) : *p.t_dev;
@@ -1608,7 +1624,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
             s_sq[wave * (MT * 16) + mt * 16 + c] = r == 0 ? a2[mt][0] : (r == 1 ? a2[mt][1] : (r == 2 ? a2[mt][2] : a2[mt][3]));
         }
     }
+    if constexpr (PIPE) JB_SEG_LGKM(p.pipe, 6);
     __syncthreads();
+    if constexpr (PIPE) JB_SEG(p.pipe, 7);
     eo.finish(p);
     const float* sa = reinterpret_cast<const float*>(s_acc);
     if constexpr (PIPE) {
@@ -1629,7 +1647,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
             v = (v - mean * eo.c1[0]) / sqrtf(var + p.ln_eps);
             const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
             const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
-            pipe_store4<T>(p.epi, xo, xo, row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J);
+            pipe_store4<T>(p.epi, xo, xo, row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J, (p.pipe.frag & JB_FRAG_OUT) != 0);
         }
         jb_pipe_publish(p.pipe, pipe_own);
         return;
@@ -2107,7 +2125,7 @@ int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream) {
                "a pipelined launch takes the plain or the folded-LayerNorm projection, <= 16 rows, whole 16-column tiles");
     // completion protocol 1 has a flag word per ticket shard (workgroup index mod 8): a launch of fewer than 8 workgroups would
     // leave flags that nobody writes, and every consumer would sit out its time-out on them
-    JB_REQUIRE(!pipe || pipe->proto != 1 || njt >= 8, "completion protocol 1 needs launches of >= 8 workgroups (J >= 128)");
+    JB_REQUIRE(!pipe || pipe->proto < 1 || njt >= 8, "completion protocol 1 needs launches of >= 8 workgroups (J >= 128)");
     p.dbg = nullptr;
 #ifdef JB_TIMING
     p.dbg = jb_dbg_ptr;

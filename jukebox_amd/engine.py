@@ -141,6 +141,8 @@ class PriorEngine:
     The conditioning inputs are COPIED into persistent buffers, so the handle and its captured hipGraph survive across
     windows (set_cond per window is a device copy, not a re-capture)."""
 
+    PIPE_STAMPS = 16           # int64 clock stamps per launch slot behind the completion words (common.h: JB_PIPE_STAMPS)
+
     def __init__(self, sd=None, prefix="", *, n_batch, chunk_cap=256, want_preds=False, record=None, packed=None,
                  attn_split=None, **model):
         if packed is None:
@@ -200,7 +202,11 @@ class PriorEngine:
         # attention output rows padded to whole k-tiles (zeros): attn.c_proj's branch-free path for n_state = 1200 (5b_lyrics)
         kt = 32 if self.dtype == torch.float16 else 16
         self.att_ld = (S + kt - 1) // kt * kt
-        self.buf = dict(x_a=e(N, W), x_b=e(N, W), q=e(N, S), att=e(N, self.att_ld), mlp=e(N, M),
+        # x_a / x_b / mlp hold 16 rows: pipelined launches hand them over in MFMA operand order, [k-tile][lane][8 channels] of
+        # always 16 rows (jb_engine_cfg.act_rows)
+        self.act_rows = max(N, 16)
+        R = self.act_rows
+        self.buf = dict(x_a=e(R, W), x_b=e(R, W), q=e(N, S), att=e(N, self.att_ld), mlp=e(R, M),
                         xf=e(N, W, dtype=torch.float32), logits=e(N, max(self.bins, 1), dtype=torch.float32),
                         c_xa=e(N * Cc, W), c_xb=e(N * Cc, W), c_h=e(N * Cc, W), c_q=e(N * Cc, S), c_att=e(N * Cc, S),
                         c_mlp=e(N * Cc, M))
@@ -212,7 +218,8 @@ class PriorEngine:
         # completion words of software-pipelined launches (jb_engine_pipeline): counts + tickets per launch slot, error word last
         # (+ room for the JB_PIPE_DEBUG stamps: 4 x int64 per slot behind the error group)
         # (an odd number of launches per step gets one pad slot: 5 * depth + 3 covers every engine)
-        self.pipe_words = torch.zeros((18 * (5 * self.depth + 3) + 1) * 32 + (5 * self.depth + 3) * 8, dtype=torch.int32, device=dev)
+        self.pipe_words = torch.zeros((18 * (5 * self.depth + 3) + 1) * 32 + (5 * self.depth + 3) * 2 * self.PIPE_STAMPS,
+                                      dtype=torch.int32, device=dev)
         self.pipelined = False
         self.tokens = torch.zeros((N, T), dtype=torch.int64, device=dev)
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -282,6 +289,7 @@ class PriorEngine:
         c.ticket = self.ticket.data_ptr()
         c.att_ld = self.att_ld
         c.pipe_words = self.pipe_words.data_ptr()
+        c.act_rows = self.act_rows
         c.chunk_cap = self.chunk_cap
         c.c_xf = b["c_xf"].data_ptr() if "c_xf" in b else None
         c.tokens, c.tok_stride, c.t_dev = self.tokens.data_ptr(), self.tokens.stride(0), self.t_dev.data_ptr()
@@ -327,11 +335,13 @@ class PriorEngine:
         return bool(self.handle) and L.lib().jb_engine_pipeline_resident(self.handle) == 1
 
     def pipe_stamps(self):
-        """JB_PIPE_DEBUG=1: (n_slots, 4) int64 ticks of the 100 MHz clock of the last pipelined step: poll entered, producer
-        seen, completion published."""
+        """JB_PIPE_DEBUG=1: (n_slots, PIPE_STAMPS) int64 ticks of the 100 MHz clock of the last pipelined step, workgroup 0 of
+        every launch: 0 poll entered, 1 producer seen, 2 completion published (the launch's last workgroup), 3 stores issued;
+        the measurement build (JB_LIB_SEGMENTS=1) adds 4 barrier behind the poll, 5 operands landed, 6 arithmetic retired and
+        partials in LDS, 7 LDS exchange barrier, 8 stores drained, 9 own ticket returned (common.h)."""
         n = self.pipe_slots
         base = (18 * n + 1) * 32
-        return self.pipe_words[base:base + n * 8].view(torch.int64).reshape(n, 4).cpu().numpy()
+        return self.pipe_words[base:base + n * 2 * self.PIPE_STAMPS].view(torch.int64).reshape(n, self.PIPE_STAMPS).cpu().numpy()
 
     def pipe_error(self):
         """0, or slot + 1 of a pipelined launch whose wait for its producer timed out (sticky)."""

@@ -39,13 +39,6 @@ class PositionEmbedding(nn.Module):
         return self.pos_emb
 
 
-def _regime_is_shared(model, eng):
-    """Whether the engine's pipelined launches run in a regime that the sampler declared shared with another pipelined level
-    (`pipeline_shared_regimes`: regime -> bound in ms per step)."""
-    shared = getattr(model, "pipeline_shared_regimes", None) or ()
-    return getattr(eng, "_pipe_regime", None) in shared
-
-
 class ConditionalAutoregressive2D(nn.Module):
     def __init__(self, input_shape, bins, width=128, depth=2, heads=1, attn_dropout=0.0, resid_dropout=0.0,
                  emb_dropout=0.0, mask=True, zero_out=False, init_scale=1.0, res_scale=False, pos_init=False,
@@ -156,7 +149,7 @@ class ConditionalAutoregressive2D(nn.Module):
     @property
     def pipeline_candidate(self):
         """Whether this model's engines can run software-pipelined launches, from the geometry alone (the library decides for
-        an engine: jb_engine_pipeline's eligibility rule -- fp16, <= 16 samples, one 480-channel head on lean wide-value
+        an engine: jb_engine_pipeline's eligibility rule -- fp16, <= 16 samples, one 480-channel head on wide-value
         attention, width and MLP of 33..64 k-tiles, key sets of <= 128 keys: the 1b upsamplers)."""
         S, M = int(self.m_attn * self.width), int(self.m_mlp * self.width)
         bc = self.input_dims // self.blocks if self.blocks else 0
@@ -166,37 +159,17 @@ class ConditionalAutoregressive2D(nn.Module):
 
     def _apply_pipeline(self, eng):
         """Software-pipelined launches as the sampler asks for them: `pipeline_launches` is None (leave the engine alone), a
-        bool, or a callable that is asked again before every decode call and answers with a falsy value (not now) or with a
-        REGIME -- any truthy, comparable token that names the conditions the launches would run under (the level pipeline:
-        how many pipelined engines share the GPU).  The verdict of the in-situ comparison (`_decode`) against them stands
-        within the regime it was measured in; a new regime is measured afresh ON A NEW PAIR, made after `pipeline_prepare(regime)`
-        (if the sampler set one) has chosen the kernel forms for that regime."""
+        bool, or a callable that is asked again before every decode call (the level pipeline: "does this level have the GPU to
+        itself now?").  A verdict of the in-situ comparison (`_decode`) against them stands for as long as the engine's pair of
+        streams would (`release_pipeline` forgets it)."""
         want = getattr(self, "pipeline_launches", None)
         if callable(want):
             want = want()
-        if want and getattr(eng, "_pipe_regime", None) != want:
-            eng._pipe_regime = want
-            if not getattr(eng, "_pipe_timed_out", False):
-                eng._pipe_verdict = None
-            if eng.pipelined:
-                # the pair's graphs were captured for the OTHER regime's kernel forms (`pipeline_prepare`: the lean attention
-                # kernel beside another pipelined level, the fat one alone): release it, the switch below makes a new one
-                eng.set_pipelined(False)
-        if want and getattr(eng, "_pipe_verdict", None) is False:
-            want = False
-        if want is not None and eng.pipelined != bool(want):
-            if want:
-                # a regime shared with another pipelined level is entered TOGETHER (`pipeline_rendezvous`: the sampler lets the
-                # levels of that regime meet here): a pipelined engine beside a plain chain runs at 5.9 / 6.8 ms per step
-                # (DESIGN.md section 4.5), so neither switches while the other is still on its plain chain; whoever finds
-                # nobody within the sampler's patience keeps the plain chain and is asked again at its next look
-                meet = getattr(self, "pipeline_rendezvous", None)
-                if callable(meet) and not meet(want):
-                    return
-                prepare = getattr(self, "pipeline_prepare", None)
-                if callable(prepare):
-                    prepare(want)                  # (kernel forms are chosen when the pair's graphs are captured: next decode)
-            eng.set_pipelined(bool(want))
+        if want is None:
+            return
+        want = bool(want) and getattr(eng, "_pipe_verdict", None) is not False
+        if eng.pipelined != want:
+            eng.set_pipelined(want)
 
     def release_pipeline(self):
         """End of the phase in which this prior's engines may run pipelined launches (its level has finished, a job starts or
@@ -223,24 +196,14 @@ class ConditionalAutoregressive2D(nn.Module):
         pos, end = t0, t0 + n_steps
         if callable(want):
             while True:
-                self._apply_pipeline(eng)          # (a new regime -- a level finished -- re-opens a verdict against them)
-                if end - pos < 2 * self.PIPE_RECHECK_STEPS:
+                self._apply_pipeline(eng)
+                # the rest in one call: once the launches are on, once the in-situ comparison has decided against them (nothing
+                # can re-open that verdict before the pair is released), or when too little of the window is left
+                if eng.pipelined or getattr(eng, "_pipe_verdict", None) is False or end - pos < 2 * self.PIPE_RECHECK_STEPS:
                     break
-                if eng.pipelined:
-                    # alone (regime 1) the rest of the window is one call; in a regime SHARED with another pipelined level the
-                    # sampler is still asked every PIPE_RECHECK_STEPS steps (a pipelined call is host-synchronous: chunks cost
-                    # nothing): when the other level finishes or gives its launches up, this engine must not run beside a plain
-                    # chain, or on the shared regime's kernel forms, for up to a whole window
-                    if not _regime_is_shared(self, eng):
-                        break
-                    self._decode(eng, pos, self.PIPE_RECHECK_STEPS)
-                    if eng.pipe_error():
-                        return                     # (the caller decodes the window again on the plain chain)
-                else:
-                    eng.timed_decode(pos, self.PIPE_RECHECK_STEPS)
+                eng.timed_decode(pos, self.PIPE_RECHECK_STEPS)
                 pos += self.PIPE_RECHECK_STEPS
         self._decode(eng, pos, end - pos)
-
 
     def _decode(self, eng, t0, n_steps):
         """eng.decode, with the two launch forms compared IN SITU the first time an engine runs pipelined launches: the same
@@ -254,44 +217,10 @@ class ConditionalAutoregressive2D(nn.Module):
         if not eng.pipelined or getattr(eng, "_pipe_verdict", None) is not None or n_steps < 256:
             eng.decode(t0, n_steps)
             return
-        if _regime_is_shared(self, eng):
-            # Beside another pipelined level there is no fair plain side to compare with -- this engine's plain chain next to the
-            # other's pipelined launches runs at 6.8 - 11 ms per step, and measuring it costs both levels seconds -- so the
-            # regime's pipelined launches are only held to the sampler's bound for it (`pipeline_shared_regimes[regime]`, ms per
-            # step: well above what two pipelined engines side by side take, well below the broken states DESIGN.md section 4.2
-            # lists); an engine that misses it tells the sampler (`pipeline_gave_up`), which ends the regime for both levels.
-            bound = float(self.pipeline_shared_regimes[eng._pipe_regime])
-            if getattr(eng, "_pipe_settled", None) != eng._pipe_regime:
-                # the first call after the levels met is not a measurement: both are making their pairs (stream handshakes, two
-                # graph captures each) inside it -- the 6-second job's level 0 measured 2.75 ms per step there and left a regime
-                # that runs at 2.02 (profiles/r05_bench_6s_two_engines_dynamic2.json)
-                eng._pipe_settled = eng._pipe_regime
-                eng.decode(t0, n_steps)
-                return
-            warm, n_pipe = (16, 240) if n_steps >= 512 else (8, 112)
-            eng.decode(t0, warm)
-            ms = None
-            if not eng.pipe_error() and eng.pipelined:
-                ms = round(eng.timed_decode(t0 + warm, n_pipe) * 1e3, 4)
-            if ms is None or eng.pipe_error():
-                return
-            kept = ms < bound
-            report = dict(pipelined_ms=[ms], plain_ms=None, kept=kept, regime=eng._pipe_regime, bound_ms=bound)
-            eng._pipe_verdict = kept
-            self.pipeline_report = report
-            self.pipeline_reports = (getattr(self, "pipeline_reports", None) or [])[-15:] + [report]
-            if not kept:
-                eng.set_pipelined(False)
-                gave_up = getattr(self, "pipeline_gave_up", None)
-                if callable(gave_up):
-                    gave_up(eng._pipe_regime)
-            if n_steps > warm + n_pipe:
-                eng.decode(t0 + warm + n_pipe, n_steps - warm - n_pipe)
-            return
         # steps: untimed warm-up, timed pipelined, untimed plain warm-up, timed plain -- the short form fits one published
         # chunk of a tapped window (256 steps: the level pipeline's upper levels)
         warm, n_pipe, n_plain = (16, 384, 128) if n_steps >= 1024 else (8, 112, 64)
-        report = dict(pipelined_ms=[], plain_ms=None, kept=False, regime=getattr(eng, "_pipe_regime", None))
+        report = dict(pipelined_ms=[], plain_ms=None, kept=False)
         pos, end = t0, t0 + n_steps
         for attempt in range(2):
             if end - pos < warm + n_pipe + (0 if report["plain_ms"] is not None else warm + n_plain):
@@ -333,9 +262,6 @@ class ConditionalAutoregressive2D(nn.Module):
         eng.set_pipelined(False)
         eng._pipe_verdict = False
         eng._pipe_timed_out = True
-        gave_up = getattr(self, "pipeline_gave_up", None)
-        if callable(gave_up):
-            gave_up(getattr(eng, "_pipe_regime", None))       # (a shared regime ends for the other level too)
         self.pipeline_report = dict(getattr(self, "pipeline_report", None) or {}, kept=False, timed_out=True)
 
     def packed(self, fp16):

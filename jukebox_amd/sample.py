@@ -7,7 +7,6 @@ random streams, and the generated codes are all-gathered once per level (SURVEY.
 the whole job redundantly on every rank with identical seeds (sample.py:110-113)."""
 import contextlib
 import os
-import threading
 import time
 
 import torch as t
@@ -114,7 +113,6 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     ready_event = {}
     errors = []
     finished = set()                                       # levels whose codes are complete (their streams drained)
-    in_window = set()                                      # levels inside sample_single_window right now (not waiting for codes)
     levels = sorted(sample_levels, reverse=True)
     on_gpu = str(device).startswith("cuda")            # on CPU (host-logic tests) the schedule runs without streams
     current = torch_cuda_current_stream(device) if on_gpu else None
@@ -194,12 +192,8 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                     prior.window_tap = (chunk, publish) if tapped else None
                     t_w = time.perf_counter()
                     try:
-                        with cond:
-                            in_window.add(level)
                         out = sample_single_window(view, lab, k, level, prior, start, local_hps)
                     finally:
-                        with cond:
-                            in_window.discard(level)
                         prior.window_tap = None
                         timeline.append((level, start, round(t_w - t_job, 3), round(time.perf_counter() - t_job, 3)))
                     new_len = int(out[level].shape[1])
@@ -215,8 +209,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 if on_gpu:
                     cur().synchronize()
                 # this level's phase is over: its engines' pairs of streams go BEFORE the level counts as finished -- an idle pair
-                # slows the other levels' plain chains, and the level below may only take the GPU for itself (regime 1: the fat
-                # attention kernel, which shares with no other owner) once this one owns nothing
+                # slows the other levels' plain chains, and the library admits one pipelined engine per process
                 level_ar = getattr(prior, "prior", None)
                 if level_ar is not None and callable(getattr(level_ar, "release_pipeline", None)):
                     level_ar.release_pipeline()
@@ -239,63 +232,19 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
                 cond.notify_all()
 
     # Software-pipelined launches for the lowest level (the long pole of the job) ONLY WHILE IT RUNS ALONE.  A pipelined engine's
-    # waiting launches keep compute units half occupied for good, and whatever runs next to them crawls -- measured again in round 5
-    # with everything that could be in the way removed (profiles/r05_pipe_concurrent_two_engines.log, upsampler geometry, ms per
-    # step): alone 1.53 pipelined / 1.77 plain; two plain chains side by side 2.09 each; a pipelined engine next to a plain
-    # chain 5.9 / 6.8 (!); TWO pipelined engines side by side -- possible since the lean attention kernel, <= 168 registers per
-    # lane, attention.hip -- 2.02 each: 3 % better than two plain chains, which the lean kernel gives back when the level is
-    # alone (1.587 against 1.557 ms).  So the default stays one pipelined level, from the moment every other level has
-    # finished; hps.pipeline_max_engines = 2 pipelines the two lowest candidate levels side by side once the levels that are
-    # no candidates (the top prior: its 16-wave kernels do not fit beside a waiter) have finished.  The sampler's answer is
-    # the REGIME the launches would run in -- 2: another pipelined level runs beside this one, 1: alone --; a verdict of the
-    # in-situ comparison (ConditionalAutoregressive2D._decode) stands within its regime.  The engine is asked before every
-    # window (and every 512 steps of a window on the plain chain); its pair of streams is made when the launches are switched
-    # on and released when they go off or the job ends: two more hardware queues in the process -- even idle ones -- slowed the
-    # concurrent levels' plain chains 2.5x (profiles/r04_pipe_in_job.log).
-    n_pipe = int(hps.get("pipeline_max_engines", 1))
-    prepare = None
-    if _want_pipelined_launches(hps) and t.device(device).type == "cuda":
-        from . import _lib
-        # The kernel form goes with the REGIME, and is read when a pair's graphs are captured: the lean attention kernel (a
-        # workgroup fits beside a waiting projection workgroup: what lets two pipelined engines share the GPU) costs the level
-        # that runs alone 2 % (1.587 against 1.557 ms per step), so regime 2 captures the lean form, regime 1 the fat one, and a
-        # change of regime makes a new pair (ConditionalAutoregressive2D._apply_pipeline).
-        _lib.lib().jb_tune_attn_decode_wide_lean(0)
-        prepare = lambda regime: _lib.lib().jb_tune_attn_decode_wide_lean(1 if regime == 2 else 0)
+    # waiting launches keep compute units half occupied, and whatever runs next to them crawls -- measured with everything that
+    # could be in the way removed (profiles/r05_pipe_concurrent_two_engines.log, upsampler geometry, ms per step): alone 1.53
+    # pipelined / 1.77 plain; two plain chains side by side 2.09 each; a pipelined engine next to a plain chain 5.9 / 6.8.
+    # (Round 5 also built TWO pipelined levels side by side -- a lean attention kernel, two owners in the library, regimes and
+    # a rendezvous here: 2.02 ms per step each against 2.09, 67.53 s against 67.21 s for the default on the 6-second job; it
+    # did not pay and was removed in round 6: DESIGN.md / HISTORY.md.)  The engine is asked before every window and every 512
+    # steps of a window on the plain chain; its pair of streams is made when the launches are switched on and released when
+    # they go off or the job ends: two more hardware queues in the process -- even idle ones -- slowed the concurrent levels'
+    # plain chains 2.5x (profiles/r04_pipe_in_job.log).
     if _want_pipelined_launches(hps):
-        cands = [l for l in sorted(sample_levels) if getattr(getattr(priors[l], "prior", None), "pipeline_candidate", False)][:n_pipe]
-        others = [l for l in sample_levels if l not in cands]
-        shared_off = []                                        # non-empty: a level gave the shared regime up; it is over for all
-
-        def regime_of(l):
-            if not all(m in finished for m in others):
-                return 0
-            beside = sum(1 for m in cands if m != l and m not in finished)
-            return 1 if not beside else (0 if shared_off else 1 + beside)
-
-        # Levels enter the shared regime TOGETHER: the first to ask waits (its chain idle, the other's the faster for it) until
-        # the other asks too -- the lowest level looks every 512 steps, a tapped level every published chunk, about a second
-        # apart -- and gives up after `patience` seconds (the other level finished, or sits in a conditioner / prefill): plain
-        # chain until its next look.
-        meeting = _Rendezvous(len(cands))
-        patience = float(hps.get("pipeline_rendezvous_s", 2.5))
-        def meet(l, regime):
-            if regime == 1:
-                return True
-            # (nobody to meet while the other level waits for codes, sits between two windows or has not started: no waiting)
-            if not all(m in in_window for m in cands if m != l and m not in finished):
-                return False
-            return meeting.wait(patience) and not shared_off
-
+        cands = [l for l in sorted(sample_levels) if getattr(getattr(priors[l], "prior", None), "pipeline_candidate", False)][:1]
         for l in cands:
-            ar = priors[l].prior
-            ar.pipeline_prepare = prepare
-            ar.pipeline_rendezvous = (lambda regime, l=l: meet(l, regime)) if len(cands) > 1 else None
-            # ms per step a level of the shared regime must stay under (two pipelined upsampler engines side by side: 2.02;
-            # the broken states of DESIGN.md section 4.2 / 4.5: 3.0 - 6.8)
-            ar.pipeline_shared_regimes = {2: float(hps.get("pipeline_shared_bound_ms", 2.6))} if len(cands) > 1 else None
-            ar.pipeline_gave_up = lambda regime: shared_off.append(regime) if regime == 2 else None
-            ar.pipeline_launches = lambda l=l: regime_of(l)
+            priors[l].prior.pipeline_launches = lambda l=l: all(m in finished for m in sample_levels if m != l)
     early_audio = {}
     _sample_levels_pipelined.early_audio = early_audio
     # (level, window start, seconds into the job at which the window's sampling began / ended) per window: diagnostics
@@ -318,29 +267,6 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     return zs_local
 
 
-class _Rendezvous:
-    """`parties` threads meet: wait(timeout) returns True in all of them once the last has arrived, False in one that waited
-    `timeout` seconds in vain (it leaves again: the next full meeting needs it back)."""
-
-    def __init__(self, parties):
-        self.parties, self.waiting, self.generation = parties, 0, 0
-        self.cond = threading.Condition()
-
-    def wait(self, timeout):
-        with self.cond:
-            gen = self.generation
-            self.waiting += 1
-            if self.waiting >= self.parties:
-                self.generation += 1
-                self.waiting = 0
-                self.cond.notify_all()
-                return True
-            if self.cond.wait_for(lambda: self.generation != gen, timeout):
-                return True
-            self.waiting -= 1
-            return False
-
-
 def torch_cuda_current_stream(device):
     return t.cuda.current_stream(device)
 
@@ -355,7 +281,6 @@ def _release_pipelines(priors, levels):
         ar = getattr(priors[level], "prior", None)
         if ar is not None:
             ar.pipeline_launches = None
-            ar.pipeline_prepare = ar.pipeline_rendezvous = ar.pipeline_shared_regimes = ar.pipeline_gave_up = None
             if callable(getattr(ar, "release_pipeline", None)):
                 ar.release_pipeline()
 

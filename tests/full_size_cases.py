@@ -42,6 +42,15 @@ WHOLE = {
                                 t0=384, N=2, seed=21),
 }
 
+# The arithmetic the bench times, pinned to the reference's OWN fp16 path (sample.py:239-241 samples with fp16=True at every level;
+# transformer.py:169-192 x.half(), ops.py:14-24,97-101, factored_attention.py:82-108): tests/golden/gen_fp16_window.py runs the
+# UNMODIFIED reference's primed_sample(fp16=True) at the upsampler geometry -- 4096 primed tokens in chunks of 32, then 4096 greedy
+# steps with get_preds (a whole level-0 window of the 20-second job) -- and the fp32 reference teacher-forced on that stream (N = 2; CPU here, zero GPU minutes)
+FP16 = {
+    "upsampler_fp16": dict(W=1920, depth=72, heads=1, attn_order=2, blocks=128, seq=8192, bins=2048, prime_len=None, y_cond=True,
+                           t0=4096, n_steps=4096, N=2, seed=29),
+}
+
 _ORDERS = {
     2: lambda d: [1, 2, 3][d % 3],
     10: lambda d: [*[1, 2, 3, 1, 2, 3, 1, 2, 3], *[1, 2, 3, 1, 2, 3, 1, 2, 3, 6] * 7][d % 79],
@@ -106,6 +115,15 @@ def digest_positions(case):
         keep = sorted(set(np.linspace(0, len(pos) - 1, 12).round().astype(int).tolist()))
         pos = [pos[i] for i in keep]
     return np.asarray(pos, dtype=np.int64)
+
+
+def fp16_full_positions(case, n_steps=None):
+    """Positions of an FP16 case whose logit rows the golden keeps in full: the last 64 primed ones, the first and the last 128
+    sampled ones (fewer when the generator was asked for a short stream)."""
+    t0 = case["t0"]
+    n_steps = case["n_steps"] if n_steps is None else n_steps
+    k = min(128, n_steps)
+    return np.unique(np.concatenate([np.arange(max(t0 - 64, 0), t0 + k), np.arange(t0 + n_steps - k, t0 + n_steps)])).astype(np.int64)
 
 
 def golden_path(tag):

@@ -9,7 +9,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 from conftest import load_golden, sub_state  # noqa: E402
-from jukebox_amd.hparams import Hyperparams  # noqa: E402
+from jukebox_amd.hparams import Hyperparams, setup_hparams  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -290,3 +290,63 @@ def test_teacher_forced_losses(models, tiny_hps):
         for k in ("bpd", "prime_loss", "gen_loss"):
             assert abs(float(m[k]) - float(f[f"{tag}.{k}"])) < 1e-4, (tag, k)
         assert abs(float(loss) - float(f[f"{tag}.loss"])) < 1e-4, tag
+
+
+def test_timed_job_tokens():
+    """The job bench.py times, as a job: 1b_lyrics at its real widths, contexts, heads and conditioners (upsamplers 1920 wide /
+    one 480-channel head / 8192 tokens, top prior 2048 wide / 2 heads / 6144 + 384 tokens, the 5b VQ-VAE), 16 samples, 6 s of
+    audio (the shortest the upsamplers take, sample.py:183) at temp 0.99 in fp16 -- at reduced DEPTH (12 / 12 / 16 layers; the
+    schedule does not know the depth) -- sampled twice:
+      * as the bench does: the level pipeline (a host thread and a stream per level, partial windows published to the level
+        below), level 0 switching to software-pipelined launches with operand-order hand-offs in the middle of the window in
+        which the upper levels finish, the in-situ comparison of the two launch forms, the pair released at the end;
+      * the reference's schedule (sample.py:90-121): one level after the other, whole windows, plain launch chain.
+    Same seed, so the codes of EVERY level must be identical (the draw of a position is a pure function of seed, level, sample
+    and position); and a second pipelined job in the same process reproduces the first (what bench.py asserts over its timed
+    steps through `breakdown.step_digests`)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from jukebox_amd import sample as S
+    from jukebox_amd.make_models import MODELS, make_prior, make_vqvae
+    sr, n = 44100, 16
+    sample_length = int(6.0 * sr) // 128 * 128
+    names = MODELS["1b_lyrics"]
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        vq = make_vqvae(setup_hparams(names[0], dict(sample_length=sample_length, restore_vqvae="")), "cuda")
+        for blk in vq.bottleneck.level_blocks:
+            blk.k.normal_()
+        priors = [make_prior(setup_hparams(nm, dict(restore_prior="", prior_depth=d)), vq, "cuda") for nm, d in zip(names[1:], (12, 12, 16))]
+    assert priors[0].prior.pipeline_candidate and priors[0].prior.width == 1920 and priors[2].prior.width == 2048
+    rng = np.random.RandomState(0)
+    labels = []
+    for p in priors:
+        yb = p.y_emb.bow_genre_emb.bins, p.y_emb.artist_emb.bins
+        items = [dict(artist_id=int(rng.randint(1, yb[1])), genre_ids=[int(rng.randint(1, yb[0]))],
+                      full_tokens=rng.randint(1, 79, size=1500).tolist() if p.n_tokens > 0 else [], total_length=180 * sr, offset=0)
+                 for _ in range(n)]
+        labels.append(p.labeller.get_batch_labels_from_ids(items, "cuda"))
+    sk = S.default_sampling_kwargs("1b_lyrics")
+
+    def job(pipelined):
+        hps = Hyperparams(n_samples=n, sample_length=sample_length, hop_fraction=[0.5, 0.5, 0.125], sr=sr, name="unused",
+                          keep_priors_resident=True, pipeline_levels=pipelined, pipeline_launches=pipelined, seed=0)
+        priors[0].prior.pipeline_report = None
+        zs = S.ancestral_sample(labels, sk, priors, hps, save=False, device="cuda")
+        torch.cuda.synchronize()
+        return [z.cpu().numpy() for z in zs], priors[0].prior.pipeline_report
+
+    z_pipe, report = job(True)
+    assert report is not None and report["pipelined_ms"], "level 0 never tried its pipelined launches: the test did not test the bench's schedule"
+    assert not any(e.pipelined or e.pipeline_resident for p in priors for e in p.prior._engines.values()), "a pair of streams outlived the job"
+    z_seq, rep_seq = job(False)
+    assert rep_seq is None                                   # the sequential plain-chain schedule ran no pipelined launch
+    z_again, _ = job(True)
+    print("timed-job tokens: level 0 in situ", report, "; tokens per level", [z.shape for z in z_pipe])
+    for l in range(3):
+        assert z_pipe[l].shape == (n, sample_length // priors[l].raw_to_tokens)
+        assert np.array_equal(z_pipe[l], z_seq[l]), f"level {l}: the pipelined schedule and the sequential plain chain drew different codes"
+        assert np.array_equal(z_pipe[l], z_again[l]), f"level {l}: two pipelined jobs with one seed drew different codes"
+    assert len(np.unique(z_pipe[0])) > 100                   # (a sampled stream, not a constant)
+    for p in priors:
+        p.cpu()

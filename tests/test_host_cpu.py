@@ -497,15 +497,12 @@ def test_in_situ_choice_between_the_launch_forms():
         assert eng.pipelined is kept
         h._decode(eng, 4096, 4096)
         assert len(eng.calls) == n_calls + 1                  # one call, nothing measured again
-        # ... within the REGIME it was measured in: when the sampler names another one (a level finished: this engine now
-        # runs alone), the verdict -- also one against pipelined launches -- is open again and the next long call measures
-        eng.rates = [1.5]
-        h.pipeline_launches = lambda: 2
+        # ... until the pair is released (the level's phase ends, a job starts or ends): the next long call measures afresh
+        eng._pipe_verdict, eng.rates = None, [1.5]
         h._apply_pipeline(eng)
-        assert eng._pipe_verdict is None and eng.pipelined and eng._pipe_regime == 2
+        assert eng.pipelined
         h._decode(eng, 0, 4096)
-        assert eng._pipe_verdict is True and h.pipeline_report["regime"] == 2 and h.pipeline_report["pipelined_ms"] == [1.5]
-        assert [r["regime"] for r in h.pipeline_reports] == [True, 2]
+        assert eng._pipe_verdict is True and h.pipeline_report["pipelined_ms"] == [1.5] and len(h.pipeline_reports) == 2
     bad = FakeEngine([1.6])
     bad.pipe_error = lambda: 19 if len(bad.calls) >= 2 else 0  # a wait times out inside the timed steps
     Host()._decode(bad, 0, 4096)
@@ -525,174 +522,6 @@ def test_in_situ_choice_between_the_launch_forms():
     tiny = FakeEngine([])
     Host()._decode(tiny, 0, 200)                              # too short to measure on: decoded as asked
     assert tiny.calls == [(0, 200, True)] and not hasattr(tiny, "_pipe_verdict")
-
-
-def test_a_change_of_regime_makes_a_new_pair_with_that_regimes_kernel_forms():
-    """ConditionalAutoregressive2D._apply_pipeline, round 5: the kernel forms of a pipelined pair are chosen when its graphs are
-    captured (the lean attention kernel beside another pipelined level, the fat one alone: sample._sample_levels_pipelined's
-    `pipeline_prepare`), so an engine that is pipelined when the sampler names ANOTHER regime releases its pair first, has the
-    forms chosen for the new regime, and only then switches the launches on again; within a regime nothing is released, and
-    "not now" (0) just switches off."""
-    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
-    log = []
-
-    class FakeEngine:
-        pipelined = False
-        def set_pipelined(self, on, fresh=False):
-            log.append(("on" if on else "off"))
-            self.pipelined = bool(on)
-            return self.pipelined
-
-    class Host:
-        _apply_pipeline = AR._apply_pipeline
-
-    h, eng = Host(), FakeEngine()
-    h.pipeline_prepare = lambda regime: log.append(("prepare", regime))
-    say = [0]
-    h.pipeline_launches = lambda: say[0]
-    h._apply_pipeline(eng)
-    assert log == [] and not eng.pipelined                       # "not now", and it was off
-    say[0] = 2
-    h._apply_pipeline(eng)
-    assert log == [("prepare", 2), "on"] and eng._pipe_regime == 2
-    eng._pipe_verdict = True
-    h._apply_pipeline(eng)
-    assert log == [("prepare", 2), "on"] and eng._pipe_verdict is True      # same regime: nothing happens, the verdict stands
-    say[0] = 1                                                   # the level beside it has finished
-    h._apply_pipeline(eng)
-    assert log == [("prepare", 2), "on", "off", ("prepare", 1), "on"] and eng.pipelined
-    assert eng._pipe_regime == 1 and eng._pipe_verdict is None   # measured afresh on the new pair
-    say[0] = 0
-    h._apply_pipeline(eng)
-    assert log[-1] == "off" and not eng.pipelined
-    # a verdict against pipelined launches in this regime: the sampler's regime is answered with the plain chain, no pair is made
-    eng._pipe_verdict, n = False, len(log)
-    say[0] = 1
-    h._apply_pipeline(eng)
-    assert len(log) == n and not eng.pipelined
-    # without a hook (the sequential level loop, tests) the switch is what it was
-    h2, eng2 = Host(), FakeEngine()
-    h2.pipeline_launches = True
-    h2._apply_pipeline(eng2)
-    assert eng2.pipelined
-
-
-def test_a_regime_shared_with_another_pipelined_level():
-    """Round 5, the two upsampler levels pipelined side by side (sample._sample_levels_pipelined, hps.pipeline_max_engines = 2):
-    a level enters the shared regime only TOGETHER with the other (`pipeline_rendezvous` says no: plain chain, asked again at the
-    next look); inside it there is no plain side to compare with, so the launches are held to the sampler's bound in ms per step
-    (`pipeline_shared_regimes`) on 16 + 240 steps of the SECOND chunk (the first is where both make their pairs), an engine that misses it switches off and tells the sampler
-    (`pipeline_gave_up`); the window is decoded in chunks of PIPE_RECHECK_STEPS with the sampler asked between them, so that the
-    end of the regime (the other level finished: regime 1, a new pair, the in-situ comparison as ever; or gave up: plain chain)
-    takes effect within a chunk.  Every position is decoded exactly once, in order, in every course of events."""
-    from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
-
-    class FakeEngine:
-        def __init__(self, rate):
-            self.rate, self.pipelined, self.calls, self.switches = rate, False, [], []
-        def pipe_error(self):
-            return 0
-        def set_pipelined(self, on, fresh=False):
-            self.switches.append(bool(on))
-            self.pipelined = bool(on)
-            return self.pipelined
-        def decode(self, t0, n, plain=False):
-            self.calls.append((t0, n, self.pipelined and not plain))
-        def timed_decode(self, t0, n, plain=False):
-            self.decode(t0, n, plain=plain)
-            return (self.rate if self.pipelined and not plain else 2.3) * 1e-3
-
-    class Host:
-        _decode, _decode_window, _apply_pipeline = AR._decode, AR._decode_window, AR._apply_pipeline
-        PIPE_RECHECK_STEPS = AR.PIPE_RECHECK_STEPS
-
-    def covered(eng, t0, n):
-        pos = t0
-        for c0, cn, _ in eng.calls:
-            assert c0 == pos, eng.calls
-            pos += cn
-        assert pos == t0 + n
-
-    def host(say, partner_there):
-        h = Host()
-        h.gave_up, h.prepared = [], []
-        h.pipeline_launches = lambda: say[0]
-        h.pipeline_shared_regimes = {2: 2.6}
-        h.pipeline_rendezvous = lambda regime: regime == 1 or partner_there[0]
-        h.pipeline_prepare = h.prepared.append
-        h.pipeline_gave_up = h.gave_up.append
-        return h
-
-    # 1. the partner is not there: plain chunks; it arrives; the regime's launches meet the bound and are kept; asked every chunk
-    say, there = [2], [False]
-    h, eng = host(say, there), FakeEngine(2.02)
-    asked = []
-    h.pipeline_launches = lambda: (asked.append(len(eng.calls)), say[0])[1]
-    orig_timed = eng.timed_decode
-    def timed(t0, n, plain=False):                        # the partner arrives while this engine decodes its second plain chunk
-        if len(eng.calls) == 1:
-            there[0] = True
-        return orig_timed(t0, n, plain=plain)
-    eng.timed_decode = timed
-    h._decode_window(eng, 4096, 4096)
-    covered(eng, 4096, 4096)
-    assert eng.calls[:2] == [(4096, 512, False), (4608, 512, False)]
-    assert eng.calls[2] == (5120, 512, True)                                                    # the chunk in which the pairs are made: no measurement
-    assert eng.calls[3:6] == [(5632, 16, True), (5648, 240, True), (5888, 256, True)]       # the bounded measurement, then the chunk's rest
-    assert eng._pipe_verdict is True and h.prepared == [2] and h.gave_up == [] and h.pipeline_report["bound_ms"] == 2.6
-    assert all(c[2] for c in eng.calls[2:]) and all(c[1] <= 1024 for c in eng.calls)           # chunked to the window's end
-    assert len(asked) >= 7                                                                     # the sampler was asked between the chunks
-    # 2. the other level finishes inside the window: regime 1 -- the pair released, the forms chosen again, the in-situ comparison
-    say, there = [2], [True]
-    h, eng = host(say, there), FakeEngine(2.02)
-    def launches():
-        if len(eng.calls) >= 6:
-            say[0] = 1
-            eng.rate = 1.6
-        return say[0]
-    h.pipeline_launches = launches
-    h._decode_window(eng, 0, 4096)
-    covered(eng, 0, 4096)
-    assert h.prepared == [2, 1] and eng.switches == [True, False, True, True] and eng._pipe_regime == 1   # (the last: the verdict confirmed)
-    assert eng._pipe_verdict is True and h.pipeline_report["regime"] == 1 and h.pipeline_report["plain_ms"] == 2.3
-    assert eng.calls[-1][2] and eng.calls[-1][1] > 1024                                        # alone: the rest of the window in one call
-    # 3. the regime's launches miss the bound (a broken state: 5.9 ms per step): off, the sampler is told, the window goes on plain
-    say, there = [2], [True]
-    h, eng = host(say, there), FakeEngine(5.9)
-    h.pipeline_gave_up = lambda regime: (h.gave_up.append(regime), say.__setitem__(0, 0))
-    h._decode_window(eng, 0, 4096)
-    covered(eng, 0, 4096)
-    assert h.gave_up == [2] and not eng.pipelined and eng._pipe_verdict is False
-    assert eng.calls[:3] == [(0, 512, True), (512, 16, True), (528, 240, True)] and not any(c[2] for c in eng.calls[3:])
-    # 4. the OTHER level gave up (the sampler says "not now" from then on): this one leaves the regime at its next chunk
-    say, there = [2], [True]
-    h, eng = host(say, there), FakeEngine(2.02)
-    def launches4():
-        if len(eng.calls) >= 6:
-            say[0] = 0
-        return say[0]
-    h.pipeline_launches = launches4
-    h._decode_window(eng, 0, 4096)
-    covered(eng, 0, 4096)
-    assert eng.switches == [True, False] and not eng.pipelined and not eng.calls[-1][2]
-
-
-def test_rendezvous_of_the_levels():
-    """sample._Rendezvous: all parties return True once the last has arrived; a party that waited in vain returns False and is
-    gone (the next meeting needs it again)."""
-    import threading
-    from jukebox_amd.sample import _Rendezvous
-    r = _Rendezvous(2)
-    assert r.wait(0.05) is False and r.waiting == 0
-    out = []
-    th = threading.Thread(target=lambda: out.append(r.wait(5.0)))
-    th.start()
-    import time
-    time.sleep(0.05)
-    assert r.wait(5.0) is True
-    th.join()
-    assert out == [True] and r.waiting == 0
-    assert r.wait(0.01) is False                           # a new meeting: alone again
 
 
 def test_f16_split_arithmetic_keeps_fp32_accuracy():
@@ -793,18 +622,17 @@ def test_window_switches_to_pipelined_launches_when_the_upper_levels_finish():
     for setup in ("none", "on"):
         h, eng = Host(), FakeEngine()
         if setup == "on":
-            h.pipeline_launches, eng.pipelined, eng._pipe_verdict, eng._pipe_regime = (lambda: True), True, True, True
+            h.pipeline_launches, eng.pipelined, eng._pipe_verdict = (lambda: True), True, True
         h._decode_window(eng, 0, 4096)
         assert eng.calls == [(0, 4096, setup == "on")]
-    # a verdict against them stands within its regime -- plain chunks, the sampler is asked again between them -- and falls
-    # with it: when the other pipelined level finishes (regime 2 -> 1) the rest of the window is measured afresh
-    h, eng = Host(), FakeEngine()
-    eng._pipe_verdict, eng._pipe_regime = False, 2
-    h.pipeline_launches = lambda: 2 if len(eng.calls) < 3 else 1
-    h._decode_window(eng, 0, 4096)
-    covered(eng, 0, 4096)
-    assert eng.calls[:3] == [(0, C, False), (C, C, False), (2 * C, C, False)] and eng.calls[3] == (3 * C, 16, True)
-    assert eng._pipe_verdict is True and eng._pipe_regime == 1 and h.pipeline_report["regime"] == 1
+    # a verdict against them stands until the pair is released: the window is ONE plain call, whatever the sampler says -- no
+    # 512-step chunks with a host wait each for the rest of the job
+    for say in (False, True):
+        h, eng = Host(), FakeEngine()
+        eng._pipe_verdict = False
+        h.pipeline_launches = lambda say=say: say
+        h._decode_window(eng, 0, 4096)
+        assert eng.calls == [(0, 4096, False)] and not eng.pipelined and eng._pipe_verdict is False
 
 
 def test_pipeline_candidates_by_geometry():
@@ -887,8 +715,8 @@ def test_a_finished_level_releases_its_pipelined_pair():
 
 def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
     """jb_engine_pipeline's host logic (no launch happens before the first decode): which engines are eligible (fp16, <= 16
-    samples, wide-value layers of one 480-channel head, key sets <= 128), TWO owners per process (one with the fat attention
-    kernel), release by switching off or by destroying the engine, JB_PIPELINE_LAUNCHES=0 forbids, enable = 2 is accepted on an engine without streams,
+    samples, wide-value layers of one 480-channel head, key sets <= 128), ONE owner per process, release by switching off or by
+    destroying the engine, JB_PIPELINE_LAUNCHES=0 forbids, enable = 2 is accepted on an engine without streams,
     jb_engine_pipelined reports the effective state."""
     from jukebox_amd import _lib as L
     from jukebox_amd import engine as E
@@ -921,29 +749,22 @@ def test_pipelined_launch_ownership_without_a_gpu(monkeypatch):
         e.set_cond(None, None)
         return e
 
-    a, b, c3 = engine(), engine(), engine()
+    a, b = engine(), engine()
     assert not a.pipelined and not b.pipelined                     # opt-in: nothing asks by default
-    L.lib().jb_tune_attn_decode_wide_lean(1)                       # the lean attention kernel: two owners per process
     assert a.set_pipelined(True) is True and a.pipelined and L.lib().jb_engine_pipelined(a.handle) == 1
     assert L.lib().jb_engine_pipelined(b.handle) == 0 and L.lib().jb_engine_pipeline(a.handle, 3) != 0     # modes 0 / 1 / 2 only
     assert not a.pipeline_resident                                 # the pair of streams is made by the first pipelined decode
-    assert b.set_pipelined(True) is True and b.pipelined           # TWO owners per process (lean attention kernel) ...
-    assert c3.set_pipelined(True) is False and not c3.pipelined    # ... and no third
+    assert b.set_pipelined(True) is False and not b.pipelined      # ONE owner per process (whatever the attention kernel's form)
+    L.lib().jb_tune_attn_decode_wide_lean(1)
+    assert b.set_pipelined(True) is False
+    L.lib().jb_tune_attn_decode_wide_lean(0)
     assert a.set_pipelined(True) is True                           # asking again changes nothing
     assert a.set_pipelined(False) is False
-    assert c3.set_pipelined(True) is True
+    assert b.set_pipelined(True) is True
     assert a.set_pipelined(True) is False
-    b.close()                                                      # destroying an owner releases its right
+    b.close()                                                      # destroying the owner releases its right
     assert a.set_pipelined(True, fresh=True) is True               # enable = 2 on an engine that never made its streams
     a.set_pipelined(False)
-    c3.set_pipelined(False)
-    L.lib().jb_tune_attn_decode_wide_lean(0)                       # the fat attention kernel (the default) needs empty compute
-    b = engine()                                                   # units: one owner
-    assert a.set_pipelined(True) is True and b.set_pipelined(True) is False
-    a.set_pipelined(False)
-    assert b.set_pipelined(True) is True
-    b.close()
-    c3.close()
     for kw in (dict(heads=2, W=256), dict(fp16=False), dict(n_batch=32), dict(T=16384, blocks=64)):   # last: 256-key block sets
         e = engine(**kw)
         assert e.set_pipelined(True) is False and not e.pipelined, kw

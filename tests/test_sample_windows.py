@@ -162,16 +162,15 @@ def test_pipelined_levels_on_cpu(chunk):
         assert sorted(a.calls) == sorted(b.calls)
 
 
-def test_level_pipeline_names_the_regime_of_pipelined_launches():
-    """The level pipeline's say on software-pipelined launches (sample._sample_levels_pipelined): the two lowest levels whose
-    models can have them (`prior.prior.pipeline_candidate`: the upsamplers) are told "not now" (0) while any OTHER level -- the
-    top prior, whose kernels do not fit beside a pipelined engine's waiting launches -- still runs, then the regime: 2 while the
-    other candidate is still sampling beside them, 1 once they are alone.  The top level is never asked.  Nothing of it
-    outlives the job (release_pipeline, pipeline_launches back to None)."""
+def test_level_pipeline_gives_pipelined_launches_to_the_lowest_level_once_it_is_alone():
+    """The level pipeline's say on software-pipelined launches (sample._sample_levels_pipelined): ONE level -- the lowest whose
+    model can have them (`prior.prior.pipeline_candidate`: an upsampler) -- is asked, and is told "not now" while any other level
+    still samples, "yes" once it has the GPU to itself; every other level keeps the plain chain (False).  Nothing of it outlives
+    the job (release_pipeline, pipeline_launches back to None).  (Round 5's two pipelined levels side by side -- regimes, a
+    rendezvous, a bound -- measured 67.53 s against 67.21 s and were removed in round 6.)"""
     top = 8192 + 1024
     priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=top)
     hps.keep_priors_resident, hps.pipeline_levels, hps.pipeline_chunk = True, True, 256
-    hps.pipeline_max_engines = 2             # (the default, 1, is the second half of this test)
     sk[2]["max_batch_size"] = 3
 
     class FakeAR:
@@ -180,99 +179,39 @@ def test_level_pipeline_names_the_regime_of_pipelined_launches():
         def release_pipeline(self):
             self.released += 1
 
-    import threading
     seen = {0: [], 1: [], 2: []}
-    started = {1: threading.Event(), 0: threading.Event()}
-
-    def after_publish(prior, n_done):        # an upper level's first window does not end before the level below has started
-        if prior.level in (1, 2) and 2048 <= n_done < 8192:
-            started[prior.level - 1].wait(timeout=20)
-
     for p in priors:
         p.prior = FakeAR(p.level != 2)
-        p.after_publish = after_publish
         orig = p.sample
 
         def wrapped(*a, _orig=orig, _p=p, **k):
             w = _p.prior.pipeline_launches
             seen[_p.level].append(w() if callable(w) else w)
-            if _p.level in started:
-                started[_p.level].set()
             out = _orig(*a, **k)
             seen[_p.level].append(w() if callable(w) else w)
             return out
         p.sample = wrapped
     zs = S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
     check_levels(zs, 2, top)
-    assert all(x is False for x in seen[2]), seen[2]                 # the top prior: plain chain, never a candidate
-    for l in (0, 1):
-        assert set(seen[l]) <= {0, 1, 2}, (l, seen[l])
-        assert seen[l] == sorted(seen[l], key=lambda r: {0: 0, 2: 1, 1: 2}[r]), (l, seen[l])     # 0 -> 2 -> 1, never back
-    assert seen[1][0] == 0                                           # "not now" while the top level runs
-    assert 1 in seen[0] and 2 in seen[0] + seen[1]                   # level 0 ends alone; the two ran side by side before
-    assert 1 not in seen[1]                                          # level 1 always has level 0 beside it
+    assert all(x is False for x in seen[2] + seen[1]), (seen[2][:4], seen[1][:4])      # never candidates for the launches
+    assert set(seen[0]) <= {False, True} and seen[0][0] is False and seen[0][-1] is True and seen[0] == sorted(seen[0])
     for p in priors:
         assert p.prior.pipeline_launches is None and p.prior.released >= 2      # job start + job end
-    # the default: ONE pipelined level -- the lowest candidate, only once every other level has finished (regime 1); the level
-    # above it is told nothing but "plain chain"
+    # hps.pipeline_launches = False: nobody is asked
     priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=top)
-    hps.keep_priors_resident, hps.pipeline_levels, hps.pipeline_chunk = True, True, 256
+    hps.keep_priors_resident, hps.pipeline_levels, hps.pipeline_chunk, hps.pipeline_launches = True, True, 256, False
     sk[2]["max_batch_size"] = 3
-    seen = {0: [], 1: [], 2: []}
+    said = []
     for p in priors:
         p.prior = FakeAR(p.level != 2)
         orig = p.sample
 
-        def wrapped1(*a, _orig=orig, _p=p, **k):
-            w = _p.prior.pipeline_launches
-            seen[_p.level].append(w() if callable(w) else w)
-            out = _orig(*a, **k)
-            seen[_p.level].append(w() if callable(w) else w)
-            return out
-        p.sample = wrapped1
-    zs = S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
-    check_levels(zs, 2, top)
-    assert all(x is False for x in seen[2] + seen[1]), (seen[2][:4], seen[1][:4])
-    assert set(seen[0]) <= {0, 1} and seen[0][-1] == 1 and seen[0] == sorted(seen[0])
-    # two levels again, and one of them GIVES THE SHARED REGIME UP (its launches missed the bound, or a wait timed out:
-    # `pipeline_gave_up`, set by the sampler): from then on both are told "not now" while they run side by side -- neither may
-    # stay pipelined beside the other's plain chain -- and the survivor still gets regime 1 once it is alone.  The hooks the
-    # sampler hands out (rendezvous, bound, prepare) are taken back at the end of the job.
-    priors, hps, labels, sk = make_setup(n_samples=2, top_tokens=top)
-    hps.keep_priors_resident, hps.pipeline_levels, hps.pipeline_chunk = True, True, 256
-    hps.pipeline_max_engines = 2
-    sk[2]["max_batch_size"] = 3
-    seen = {0: [], 1: [], 2: []}
-    started = {1: threading.Event(), 0: threading.Event()}
-    gave = []
-    for p in priors:
-        p.prior = FakeAR(p.level != 2)
-        p.after_publish = after_publish
-        orig = p.sample
-
-        def wrapped2(*a, _orig=orig, _p=p, **k):
-            w = _p.prior.pipeline_launches
-            r = w() if callable(w) else w
-            if _p.level == 0 and r == 2 and not gave:
-                assert _p.prior.pipeline_shared_regimes == {2: 2.6} and callable(_p.prior.pipeline_rendezvous)
-                _p.prior.pipeline_gave_up(2)
-                gave.append(len(seen[0]))
-                r = w()
-            seen[_p.level].append(r)
-            if _p.level in started:
-                started[_p.level].set()
-            out = _orig(*a, **k)
-            seen[_p.level].append(w() if callable(w) else w)
-            return out
-        p.sample = wrapped2
-    zs = S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
-    check_levels(zs, 2, top)
-    if gave:                                                         # (level 0 met regime 2 in this schedule)
-        after = seen[0][gave[0]:]
-        assert 2 not in after and after[-1] == 1 and after == sorted(after), after
-        assert 2 not in seen[1][-2:]
-    for p in priors:
-        assert p.prior.pipeline_launches is None and p.prior.pipeline_rendezvous is None and p.prior.pipeline_gave_up is None
+        def wrapped0(*a, _orig=orig, _p=p, **k):
+            said.append(_p.prior.pipeline_launches)
+            return _orig(*a, **k)
+        p.sample = wrapped0
+    S.ancestral_sample(labels, sk, priors, hps, save=False, device="cpu")
+    assert said and all(x is False for x in said)
 
 
 def test_pipelined_levels_refuse_a_total_length_below_a_lower_context():

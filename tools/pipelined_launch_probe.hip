@@ -29,6 +29,12 @@
 //       the words still in flight.
 //   V12: protocol 1 (V5) with contiguous shards -- the producers of one eighth of the block -- and consumer waves that wait for
 //       their own eighth only.
+//   V13 / V14 (round 6): protocol 1 (V5) with the ENGINE's access pattern on the activation block instead of the probe's coalesced
+//       8-byte words -- 16-byte sc1 loads of MFMA operand fragments, 8 per lane, and 64 8-byte stores per workgroup -- V13 with the
+//       block as [row][channel] (a wave request = 16 half lines 3840 bytes apart, a workgroup's tile = 16 runs of 32 bytes), V14
+//       with the block in operand order [k-tile][lane][8] (a wave request = one contiguous KiB, a tile = 2 runs of 256 bytes).
+//       G = 120 only.
+//   V15 / V16: V5 / V14 with FOUR polls of the consumer in flight, a quarter of a round trip apart (straight-line code).
 //   "2 graphs": the even and the odd kernels of the chain as two single-stream graphs replayed on two streams (a 2-stream
 //       capture in ONE graph replays at 22 us per kernel: round 3, profiles/r03_pipelined_launch_probe.log)
 // Spin loops are bounded: after 2^22 polls a workgroup raises the abort flag, every later poll returns at once and the
@@ -320,7 +326,7 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
             for (int u = 0; u < N_W8 / THREADS; ++u) r12[u] = ld8<1>(s8 + ln + u * 64);
             if (tid == 0) s_i = i;
         }
-    } else if constexpr (V == 5 || V == 7) {
+    } else if constexpr (V == 5 || V == 7 || V >= 13) {
         // V5: 8 shard tickets; the last arriver of a shard stores the run's number into the shard's own FLAG WORD (write-through,
         // once per run); lanes 0..7 of wave 0 poll one flag word each.  V5: the 8 words in 8 different 128-byte lines; V7: in
         // one line.  Against the engine's protocol (V6) this drops the second-level ticket: one atomic round trip per launch.
@@ -329,8 +335,29 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
             if constexpr (WAIT) {
                 const int prev = j == 0 ? K - 1 : j - 1;
                 const unsigned n_shards = a.G < 8 ? (unsigned)a.G : 8u, need = j == 0 ? i : i + 1;
-                const unsigned* w = a.rows + (size_t)prev * 1024 + (V == 5 ? 256 + (tid & 7) * 32 : 512 + (tid & 7));
-                for (unsigned spins = 0;; ++spins) {
+                const unsigned* w = a.rows + (size_t)prev * 1024 + (V != 7 ? 256 + (tid & 7) * 32 : 512 + (tid & 7));
+                bool seen = false;
+                if constexpr (V == 15 || V == 16) {
+                    unsigned q0 = ld_flag(w);
+                    __builtin_amdgcn_s_sleep(6);
+                    unsigned q1 = ld_flag(w);
+                    __builtin_amdgcn_s_sleep(6);
+                    unsigned q2 = ld_flag(w);
+                    __builtin_amdgcn_s_sleep(6);
+                    unsigned q3 = ld_flag(w);
+#pragma unroll
+                    for (int it = 0; it < 12; ++it) {
+                        if (__all((unsigned)tid >= n_shards || q0 >= need)) { seen = true; break; }
+                        q0 = ld_flag(w);
+                        if (__all((unsigned)tid >= n_shards || q1 >= need)) { seen = true; break; }
+                        q1 = ld_flag(w);
+                        if (__all((unsigned)tid >= n_shards || q2 >= need)) { seen = true; break; }
+                        q2 = ld_flag(w);
+                        if (__all((unsigned)tid >= n_shards || q3 >= need)) { seen = true; break; }
+                        q3 = ld_flag(w);
+                    }
+                }
+                for (unsigned spins = 0; !seen; ++spins) {
                     const bool ok = (unsigned)tid >= n_shards || ld_flag(w) >= need;
                     if (__all(ok)) break;
                     __builtin_amdgcn_s_sleep(1);
@@ -365,14 +392,33 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
     __half* dst = a.act + (size_t)((j + 1) & 1) * N_EL;
     // 3. the whole activation block, checksummed
     float s = 0.f;
+    if constexpr (V == 13 || V == 14 || V == 16) {
+        // the engine's fetch: wave w takes k-tiles 8 w .. 8 w + 7 (60 in all), lane l = (g, row) 16 bytes of each
+        const int wv_id = tid >> 6, ln = tid & 63, row = ln & 15, g = ln >> 4;
+        u32x4 f[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kt = min(wv_id * 8 + u, 59);
+            const int off = V == 13 ? row * 3840 + kt * 64 + g * 16 : kt * 1024 + ln * 16;
+            f[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc(src), off, 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            union { u32x4 q; __half h[8]; } cv; cv.q = f[u];
+            float t8 = 0.f;
+            for (int k = 0; k < 8; ++k) t8 += __half2float(cv.h[k]);
+            s += (wv_id * 8 + u < 60) ? t8 : 0.f;
+        }
+    } else {
     const u64* s8 = reinterpret_cast<const u64*>(src);
     u64 r[N_W8 / THREADS];
 #pragma unroll
-    for (int u = 0; u < N_W8 / THREADS; ++u) r[u] = V == 12 ? r12[u] : ld8<(V == 12 ? 1 : V)>(s8 + tid + u * THREADS);
+    for (int u = 0; u < N_W8 / THREADS; ++u) r[u] = V == 12 ? r12[u] : ld8<(V >= 12 ? 1 : V)>(s8 + tid + u * THREADS);
 #pragma unroll
     for (int u = 0; u < N_W8 / THREADS; ++u) {
         union { u64 q; __half h[4]; } cv; cv.q = r[u];
         s += __half2float(cv.h[0]) + __half2float(cv.h[1]) + __half2float(cv.h[2]) + __half2float(cv.h[3]);
+    }
     }
     for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
     if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -382,11 +428,22 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
     if (tid == 0 && tot != expected_sum(p)) atomicAdd(a.err, 1u);
     // 4. my slice of the next block
     const int per = N_EL / a.G, w8 = per / 4;
-    if (tid < w8) {
+    if constexpr (V == 13 || V == 14 || V == 16) {
+        // the engine's store: workgroup wg owns columns 16 wg .. 16 wg + 15 of all 16 rows; 64 threads, 4 columns (8 bytes) each
+        if (tid < 64) {
+            const int row = tid & 15, col = wg * 16 + (tid >> 4) * 4;
+            union { u64 q; __half h[4]; } cv;
+            for (int k = 0; k < 4; ++k) cv.h[k] = value_at(row * 1920 + col + k, p + 1);
+            const int el = V == 13 ? row * 1920 + col : (col >> 5) * 512 + ((((col >> 3) & 3) << 4) + row) * 8 + (col & 7);
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            union { u64 q; u32x2 v; } o; o.q = cv.q;
+            __builtin_amdgcn_raw_buffer_store_b64(o.v, rsrc(dst), el * 2, 0, 16);
+        }
+    } else if (tid < w8) {
         union { u64 q; __half h[4]; } cv;
         const int i0 = wg * per + tid * 4;
         for (int k = 0; k < 4; ++k) cv.h[k] = value_at(i0 + k, p + 1);
-        st8<V>(reinterpret_cast<u64*>(dst) + (i0 >> 2), cv.q);
+        st8<(V >= 12 ? 1 : V)>(reinterpret_cast<u64*>(dst) + (i0 >> 2), cv.q);
     }
     float wacc = 0.f;
 #pragma unroll
@@ -427,14 +484,14 @@ template <int V, bool WAIT> __global__ __launch_bounds__(THREADS) void phase_ker
                 __hip_atomic_store(a.rows + (size_t)j * 1024 + 256 + shard * 32, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-    } else if constexpr (V == 5 || V == 7) {
+    } else if constexpr (V == 5 || V == 7 || V >= 13) {
         if (tid == 0) {
             const unsigned shard = (unsigned)wg & 7u, members = ((unsigned)a.G - shard + 7u) >> 3;
             unsigned* tk = a.rows + (size_t)j * 1024 + shard * 32;
             if (__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
                 __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (shard == 0) __hip_atomic_store(a.flags + j * PAD + 1, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.rows + (size_t)j * 1024 + (V == 5 ? 256 + shard * 32 : 512 + shard), i + 1, __ATOMIC_RELAXED,
+                __hip_atomic_store(a.rows + (size_t)j * 1024 + (V != 7 ? 256 + shard * 32 : 512 + shard), i + 1, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -522,6 +579,7 @@ int main(int argc, char** argv) {
                           {2, true, 2, "2 graphs on 2 streams, wait"}, {3, true, 2, "3 graphs on 3 streams, wait"}};
     const int v_lo = argc > 2 ? atoi(argv[2]) : 1, v_hi = argc > 3 ? atoi(argv[3]) : 4;     // protocol variants to run
     for (const Shape& sh : shapes) for (int v = v_lo; v <= v_hi; ++v) for (const Mode& m : modes) {
+        if ((v == 13 || v == 14 || v == 16) && sh.G != 120) continue;        // the engine's tile ownership: 120 workgroups of 16 columns
         Args a{act, wts, sh.wbytes / 16, flags, tickets, err, abortf, sink, sh.G, rows, tagged};
         if (a.w_phase_u4 == 0) a.w_phase_u4 = (size_t)sh.G;      // one dummy vector per workgroup
         CK(hipMemcpy(act, h.data(), N_EL * 2, hipMemcpyHostToDevice));
@@ -557,7 +615,11 @@ int main(int argc, char** argv) {
             else if (v == 9) { if (m.wait) launch<9, true>(a, j, s); else launch<9, false>(a, j, s); }
             else if (v == 10) { if (m.wait) launch<10, true>(a, j, s); else launch<10, false>(a, j, s); }
             else if (v == 11) { if (m.wait) launch<11, true>(a, j, s); else launch<11, false>(a, j, s); }
-            else { if (m.wait) launch<12, true>(a, j, s); else launch<12, false>(a, j, s); }
+            else if (v == 12) { if (m.wait) launch<12, true>(a, j, s); else launch<12, false>(a, j, s); }
+            else if (v == 13) { if (m.wait) launch<13, true>(a, j, s); else launch<13, false>(a, j, s); }
+            else if (v == 14) { if (m.wait) launch<14, true>(a, j, s); else launch<14, false>(a, j, s); }
+            else if (v == 15) { if (m.wait) launch<15, true>(a, j, s); else launch<15, false>(a, j, s); }
+            else { if (m.wait) launch<16, true>(a, j, s); else launch<16, false>(a, j, s); }
         };
         float ms = 0.f;
         if (m.kind == 0) {
