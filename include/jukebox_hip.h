@@ -403,7 +403,7 @@ int jb_engine_pipeline(void* handle, int enable);
  * the activation blocks between the launches in MFMA operand order ([k-tile][lane][8 channels] of 16 rows: a consumer wave's
  * fetch of a k-tile is one contiguous KiB, a producer's 16 x 16 tile two runs of 256 bytes) where the engine can (single head,
  * cfg.act_rows >= 16); 0 -- [row][channel] (16 half lines per wave request).  Measured on the upsampler step at 16 samples:
- * 1.438 against 1.572 ms.  Same arithmetic either way: tokens and logits stay bit-identical to the plain chain.  The reference
+ * 1.407 against 1.522 ms.  Same arithmetic either way: tokens and logits stay bit-identical to the plain chain.  The reference
  * has no counterpart (its hand-off between two layers is a tensor in HBM: jukebox/transformer/transformer.py:62-66,82-86). */
 void jb_tune_pipeline(int operand_order);
 /* 1 while the engine's decode steps run as pipelined launches, else 0 (also after a fallback to the plain chain). */

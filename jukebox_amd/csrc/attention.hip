@@ -518,12 +518,15 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
         for (int w = 0; w < nw; ++w) a += s_o[w * d + ch] * expf(s_ml[2 * w] - m);
         const float cp = jb_round<f16>(a * inv + jb_round<f16>(bias_e));
         const float v1 = jb_round<f16>((float)res_e + cp);
-        const float a1 = jb_dpp<0x55>(v1), a2 = jb_dpp<0xAA>(v1), a3 = jb_dpp<0xFF>(v1);     // lanes 1, 2, 3 of the thread's quad
-        if ((int)threadIdx.x < d && (threadIdx.x & 3) == 0) {
-            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-            const f16x4 o4 = {(f16)v1, (f16)a1, (f16)a2, (f16)a3};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o4), jb_rsrc(out),
-                                                  (int)((frag_out ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldo + och) * 2), 0, 16);
+        // eight neighbours leave as ONE 16-byte write-through store: lanes 1, 2, 3 of the thread's quad, then the next quad's
+        // (row_shl:4), all in the vector ALU; eight consecutive channels are contiguous in either layout (d, ldo multiples of 8)
+        const float a1 = jb_dpp<0x55>(v1), a2 = jb_dpp<0xAA>(v1), a3 = jb_dpp<0xFF>(v1);
+        const float a4 = jb_dpp<0x104>(v1), a5 = jb_dpp<0x104>(a1), a6 = jb_dpp<0x104>(a2), a7 = jb_dpp<0x104>(a3);
+        if ((int)threadIdx.x < d && (threadIdx.x & 7) == 0) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const f16x8 o8 = {(f16)v1, (f16)a1, (f16)a2, (f16)a3, (f16)a4, (f16)a5, (f16)a6, (f16)a7};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), jb_rsrc(out),
+                                                   (int)((frag_out ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldo + och) * 2), 0, 16);
         }
         jb_pipe_publish(pipe, pipe_own);
         return;
@@ -757,8 +760,8 @@ int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const vo
     hipStream_t s = (hipStream_t)stream;
     const JbPipe nopipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr};
     if (pipe) {
-        JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30),
-                   "a pipelined launch of the wide-value attention takes d_head = 480 and caches below 2 GiB");
+        JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30) && ldo % 8 == 0 && ((uintptr_t)x_out % 16) == 0,
+                   "a pipelined launch of the wide-value attention takes d_head = 480, caches below 2 GiB and 16-byte aligned output rows");
         JB_REQUIRE(pipe->proto < 1 || (int64_t)grid.x * grid.y >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
         if (lean)
             attn_decode_wide_kernel<15, true, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,

@@ -205,6 +205,8 @@ constexpr int JB_PIPE_STAMPS = 16;                   // clock stamps per launch 
 #endif
 constexpr int JB_PIPE_PAD = 32;                      // words between two slots' completion words (128 bytes)
 constexpr int JB_PIPE_TICKET_WORDS = 17 * JB_PIPE_PAD;  // per slot: 8 shard tickets + the shard count + (protocol 1) 8 shard flags
+// (Round 6 measured 16 shards -- half the arrivals per ticket word, 16 flag words to poll -- on the upsampler step: 1.412 against
+// 1.407 ms, no gain; profiles/r06c3_bench_engine_16B_stores_and_shards.log.)
 // words the caller provides: completion counts, tickets, one error word
 __host__ __device__ constexpr size_t jb_pipe_words(int n_slots) { return (size_t)n_slots * (JB_PIPE_PAD + JB_PIPE_TICKET_WORDS) + JB_PIPE_PAD; }
 
@@ -243,7 +245,7 @@ __device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own, int 
     const int pt = (int)threadIdx.x - poll_wave * 64;              // lane of the polling wave (other waves: outside 0..63)
     if (P.proto >= 1) {
         // Protocol 1: the last arriver of each of the 8 ticket shards stores the run's number into the shard's own flag word
-        // (its own 128-byte line, written once per run); lanes 0..7 of the first wave poll one flag each.  No second-level
+        // (its own 128-byte line, written once per run); lanes 0..7 of the polling wave poll one flag each.  No second-level
         // ticket: one atomic round trip less per launch.  Every launch of the step has >= 8 workgroups (engines of >= 8 samples).
         // (Round 6 measured FOUR staggered polls in flight instead of the serial loop -- a flag would be seen a round trip and a
         // quarter after it was written instead of one to two: probe 4.04 against 4.08 us per phase, engine 1.607 against 1.572 ms

@@ -396,6 +396,19 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         const float* src = tail.x_emb + (int64_t)tok * W;
         const float* pe = tail.pos_emb + (int64_t)(t + 1) * W;
         const float* cd = tail.x_cond ? tail.x_cond + (int64_t)n * tail.xc_n + (int64_t)(t + 1) * tail.xc_t : nullptr;
+        if (PIPE && tail.x_dtype == JB_F16 && (W & 7) == 0) {
+            // pipelined launches: 8 channels per thread, one 16-byte write-through store each (eight consecutive channels are
+            // contiguous in operand order too: common.h)
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            for (int i = tid * 8; i < W; i += 256 * 8) {
+                f32x4 lo = *reinterpret_cast<const f32x4*>(src + i) + *reinterpret_cast<const f32x4*>(pe + i);
+                f32x4 hi = *reinterpret_cast<const f32x4*>(src + i + 4) + *reinterpret_cast<const f32x4*>(pe + i + 4);
+                if (cd) { lo += *reinterpret_cast<const f32x4*>(cd + i); hi += *reinterpret_cast<const f32x4*>(cd + i + 4); }
+                const f16x8 o = {(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), jb_rsrc(tail.x_next),
+                                                       (int)(((pipe.frag & JB_FRAG_OUT) ? (int64_t)jb_frag_el(n, i) : (int64_t)n * W + i) * 2), 0, 16);
+            }
+        } else
         for (int i = tid * 4; i < W; i += 256 * 4) {          // W % 4 == 0 is checked on the host
             f32x4 v = *reinterpret_cast<const f32x4*>(src + i) + *reinterpret_cast<const f32x4*>(pe + i);
             if (cd) v += *reinterpret_cast<const f32x4*>(cd + i);
@@ -403,7 +416,6 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
                 const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                 if constexpr (PIPE) {
                     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                    // (operand-order hand-offs, common.h: the next step's first projection fetches [k-tile][lane][8])
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), jb_rsrc(tail.x_next),
                                                           (int)(((pipe.frag & JB_FRAG_OUT) ? (int64_t)jb_frag_el(n, i) : (int64_t)n * W + i) * 2), 0, 16);
                 } else {

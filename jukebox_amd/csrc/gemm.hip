@@ -184,22 +184,32 @@ __device__ __forceinline__ float epilogue_value(const EpiParams& p, float x, flo
     if (p.res) x = (p.res_scale == 1.0f) ? jb_round<T>(res_v + x) : jb_round<T>(res_v + jb_round<T>(p.res_scale * x));
     return x;
 }
-// Pipelined launches: the four consecutive threads that hold columns jb .. jb+3 of output row `orow` (epi_coords<true>)
-// hand them to the first, which stores them write-through in one piece (f16: 8 bytes, fp32: 16); likewise the fp32 second
-// output.  Called by whole waves; jt16 = first column of the workgroup's tile (its destination region is uniform).
+// LDS slot (in f32x4 units) of fragment lane `lane`'s accumulator inside a wave's 64-slot partial tile, pipelined launches:
+// [row][column group] instead of [lane], see epi_coords<true>.
+__device__ __forceinline__ int jb_pipe_tile_slot(int lane) { return ((lane & 15) << 2) | (lane >> 4); }
+
+// Pipelined launches, thread = (row, column) of the tile (epi_coords<true>): the eight consecutive threads that hold columns
+// jb .. jb+7 of output row `orow` hand them to the first, which stores them write-through in one 16-byte piece (f16; fp32: two);
+// likewise the fp32 second output.  Quad broadcasts and a row shift by four lanes: seven DPP moves, no LDS.  Called by whole
+// waves; jt16 = first column of the workgroup's tile (its destination region is uniform); frag_out: the output block is in
+// operand order (common.h), where columns jb .. jb+7 of a row are contiguous as well.
 template <typename T>
-__device__ __forceinline__ void pipe_store4(const EpiParams& p, float x, float x2, int64_t orow, int jb, int jt16, int64_t cache_row, bool valid,
-                                            bool frag_out = false) {
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pipe_store8(const EpiParams& p, float x, float x2, int64_t orow, int jb, int jt16, int64_t cache_row, bool valid,
+                                            bool frag_out) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    // (quad broadcasts in the vector ALU: lanes 1, 2, 3 of every aligned group of four; a __shfl_down is an LDS-crossbar round trip)
-    const float a1 = jb_dpp<0x55>(x), a2 = jb_dpp<0xAA>(x), a3 = jb_dpp<0xFF>(x);
-    float b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    if (p.out2) { b1 = jb_dpp<0x55>(x2); b2 = jb_dpp<0xAA>(x2); b3 = jb_dpp<0xFF>(x2); }
-    if (!valid || (threadIdx.x & 3)) return;
+    const float a1 = jb_dpp<0x55>(x), a2 = jb_dpp<0xAA>(x), a3 = jb_dpp<0xFF>(x);                 // lanes 1, 2, 3 of the thread's quad
+    const float a4 = jb_dpp<0x104>(x), a5 = jb_dpp<0x104>(a1), a6 = jb_dpp<0x104>(a2), a7 = jb_dpp<0x104>(a3);   // the next quad's (row_shl:4)
+    float b[8] = {x2, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.out2) {
-        const f32x4 o2 = {x2, b1, b2, b3};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o2), jb_rsrc(p.out2), (int)((orow * p.ldo2 + jb) * 4), 0, 16);
+        b[1] = jb_dpp<0x55>(x2); b[2] = jb_dpp<0xAA>(x2); b[3] = jb_dpp<0xFF>(x2);
+        b[4] = jb_dpp<0x104>(x2); b[5] = jb_dpp<0x104>(b[1]); b[6] = jb_dpp<0x104>(b[2]); b[7] = jb_dpp<0x104>(b[3]);
+    }
+    if (!valid || (threadIdx.x & 7)) return;
+    if (p.out2) {
+        const f32x4 lo = {b[0], b[1], b[2], b[3]}, hi = {b[4], b[5], b[6], b[7]};
+        const int off = (int)((orow * p.ldo2 + jb) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), jb_rsrc(p.out2), off, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), jb_rsrc(p.out2), off + 16, 0, 16);
     }
     T* base = (T*)p.out;
     int64_t el = (frag_out && !p.qkv_split) ? (int64_t)jb_frag_el((int)orow, jb) : orow * p.ldo + jb;     // (the query rows stay [row][channel])
@@ -210,11 +220,12 @@ __device__ __forceinline__ void pipe_store4(const EpiParams& p, float x, float x
         else { base = (T*)p.vcache2; el = cache_row * p.v2w + (jb - 2 * p.S - p.v_cols); }
     }
     if constexpr (sizeof(T) == 2) {
-        const f16x4 o = {(f16)x, (f16)a1, (f16)a2, (f16)a3};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), jb_rsrc(base), (int)(el * 2), 0, 16);
+        const f16x8 o = {(f16)x, (f16)a1, (f16)a2, (f16)a3, (f16)a4, (f16)a5, (f16)a6, (f16)a7};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), jb_rsrc(base), (int)(el * 2), 0, 16);
     } else {
-        const f32x4 o = {x, a1, a2, a3};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), jb_rsrc(base), (int)(el * 4), 0, 16);
+        const f32x4 lo = {x, a1, a2, a3}, hi = {a4, a5, a6, a7};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), jb_rsrc(base), (int)(el * 4), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), jb_rsrc(base), (int)(el * 4) + 16, 0, 16);
     }
 }
 
@@ -1177,12 +1188,14 @@ __device__ __forceinline__ float frag_sum(typename Frag<T>::vec v) {
 __device__ __forceinline__ void jb_issue_fence() { asm volatile("" ::: "memory"); }
 
 // Which element of the MT 16x16 output tiles flat index i stands for: fragment lane l, register r of tile mt.  The plain
-// kernels put consecutive threads on consecutive lanes (r = wave); ALT (pipelined launches) puts the four registers of a
-// lane on four consecutive threads, so that a lane's 4 consecutive columns can be gathered by shuffles and leave as ONE
-// 8- or 16-byte write-through store instead of four 2-byte ones.
+// kernels put consecutive threads on consecutive lanes (r = wave); ALT (pipelined launches, MT = 1) makes thread i the
+// element (row i >> 4, column i & 15) of the tile -- 16 consecutive threads (one DPP row) hold one output row, so eight
+// neighbours' columns can be gathered in the vector ALU and leave as ONE 16-byte write-through store instead of eight 2-byte
+// ones (pipe_store8); the partial tiles are parked in LDS in that order (jb_pipe_tile_slot), so the sum over the waves reads
+// word w * 256 + i: conflict free.
 template <bool ALT> __device__ __forceinline__ void epi_coords(int i, int& mt, int& r, int& l) {
     mt = i >> 8;
-    if (ALT) { l = (i >> 2) & 63; r = i & 3; } else { r = (i >> 6) & 3; l = i & 63; }
+    if (ALT) { r = i & 3; l = (((i & 15) >> 2) << 4) | ((i >> 4) & 15); } else { r = (i >> 6) & 3; l = i & 63; }
 }
 
 template <typename T, int EPT, int NT, bool ALT = false>
@@ -1496,25 +1509,23 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     }
     JB_STAMP(5);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
+    for (int mt = 0; mt < MT; ++mt) s_acc[(wave * MT + mt) * 64 + (PIPE ? jb_pipe_tile_slot(lane) : lane)] = acc[mt];
     if constexpr (PIPE) JB_SEG_LGKM(p.pipe, 6);
     __syncthreads();
     if constexpr (PIPE) JB_SEG(p.pipe, 7);
     JB_STAMP(6);
     eo.finish(p);
     if constexpr (PIPE) {
-        // MT == 1: the 256 elements of the tile on the first four waves, four consecutive threads per fragment lane
+        // MT == 1: the 256 elements of the tile on the first four waves, thread i = (row i >> 4, column i & 15)
         if (wave < 4) {
             const float* sa = reinterpret_cast<const float*>(s_acc);
-            int mt, r, l;
-            epi_coords<true>(threadIdx.x, mt, r, l);
-            const int row = l & 15, j = jt * 16 + (l >> 4) * 4 + r;
+            const int row = threadIdx.x >> 4, j = jt * 16 + (threadIdx.x & 15);
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) v += sa[(w * 64 + l) * 4 + r];
+            for (int w = 0; w < NW; ++w) v += sa[w * 256 + threadIdx.x];
             const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
             const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
-            pipe_store4<T>(p.epi, xo, xo + e_add2[0], row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J, (p.pipe.frag & JB_FRAG_OUT) != 0);
+            pipe_store8<T>(p.epi, xo, xo + e_add2[0], row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J, (p.pipe.frag & JB_FRAG_OUT) != 0);
         }
         jb_pipe_publish(p.pipe, pipe_own);
         return;
@@ -1617,7 +1628,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        s_acc[(wave * MT + mt) * 64 + lane] = acc[mt];
+        s_acc[(wave * MT + mt) * 64 + (PIPE ? jb_pipe_tile_slot(lane) : lane)] = acc[mt];
         if (g == 0) s_sum[wave * (MT * 16) + mt * 16 + c] = a1[mt][0];
         if (g == (c >> 2)) {                            // this lane holds the Gram diagonal of row c in register c & 3
             const int r = c & 3;
@@ -1630,15 +1641,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     eo.finish(p);
     const float* sa = reinterpret_cast<const float*>(s_acc);
     if constexpr (PIPE) {
-        // MT == 1: the 256 elements of the tile on the first four waves, four consecutive threads per fragment lane
+        // MT == 1: the 256 elements of the tile on the first four waves, thread i = (row i >> 4, column i & 15)
         if (wave < 4) {
-            int mt, r, l;
-            epi_coords<true>(threadIdx.x, mt, r, l);
-            const int row = l & 15, j = jt * 16 + (l >> 4) * 4 + r;
+            const int row = threadIdx.x >> 4, j = jt * 16 + (threadIdx.x & 15);
             float v = 0.f, sm = 0.f, sq = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                v += sa[(w * 64 + l) * 4 + r];
+                v += sa[w * 256 + threadIdx.x];
                 sm += s_sum[w * 16 + row];
                 sq += s_sq[w * 16 + row];
             }
@@ -1647,7 +1656,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
             v = (v - mean * eo.c1[0]) / sqrtf(var + p.ln_eps);
             const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
             const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
-            pipe_store4<T>(p.epi, xo, xo, row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J, (p.pipe.frag & JB_FRAG_OUT) != 0);
+            pipe_store8<T>(p.epi, xo, xo, row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J, (p.pipe.frag & JB_FRAG_OUT) != 0);
         }
         jb_pipe_publish(p.pipe, pipe_own);
         return;
@@ -1768,7 +1777,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_long_kernel(GemvParams p) {
         if (b + 2 < NB) { issue_w(st, b + 2); issue_x(st, b + 2); }
         __builtin_amdgcn_sched_barrier(0);
     }
-    s_acc[wave * 64 + lane] = acc;
+    s_acc[wave * 64 + (PIPE ? jb_pipe_tile_slot(lane) : lane)] = acc;
     if constexpr (LNF) {
         if (g == 0) s_sum[wave * 16 + c] = a1[0];
         if (g == (c >> 2)) {                            // this lane holds the Gram diagonal of row c in register c & 3
@@ -1786,7 +1795,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_long_kernel(GemvParams p) {
         float v = 0.f, sm = 0.f, sq = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            v += sa[(w * 64 + l) * 4 + r];
+            v += PIPE ? sa[w * 256 + threadIdx.x] : sa[(w * 64 + l) * 4 + r];      // (PIPE: parked as [row][column], jb_pipe_tile_slot)
             if constexpr (LNF) { sm += s_sum[w * 16 + row]; sq += s_sq[w * 16 + row]; }
         }
         if constexpr (LNF) {
@@ -1797,7 +1806,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_long_kernel(GemvParams p) {
         const int64_t cache_row = (p.epi.qkv_split && t < p.epi.cache_cap) ? (int64_t)row * p.epi.cache_cap + t : -1;
         if constexpr (PIPE) {
             const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
-            pipe_store4<T>(p.epi, xo, xo + e_add2, row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J);
+            pipe_store8<T>(p.epi, xo, xo + e_add2, row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J, false);
         } else if (row < p.n_rows && j < p.epi.J) {
             epilogue_store1<T>(p.epi, v, row, j, cache_row, eo.bias[0], eo.res[0], e_add2);
         }
@@ -2120,9 +2129,12 @@ int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream) {
     p.t_dev = a->t_dev;
     p.x_parts = a->x_parts; p.x_ml = a->x_ml; p.n_parts = a->n_parts; p.n_head = a->n_head; p.d_head = a->d_head;
     p.pipe = pipe ? *pipe : JbPipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr};
-    JB_REQUIRE(!pipe || (!a->x_parts && !a->ln_gamma && a->J % 16 == 0 && a->n_rows <= 16 && a->ldo % 4 == 0 &&
-                         (!a->qkv_split || a->S % 16 == 0) && (!a->out2 || a->ldo2 % 4 == 0)),
-               "a pipelined launch takes the plain or the folded-LayerNorm projection, <= 16 rows, whole 16-column tiles");
+    JB_REQUIRE(!pipe || (!a->x_parts && !a->ln_gamma && a->J % 16 == 0 && a->n_rows <= 16 && a->ldo % 8 == 0 && aligned_to(a->out, 16) &&
+                         (!a->qkv_split || (a->S % 16 == 0 && a->wide % 8 == 0 && aligned_to(a->kcache, 16) &&
+                                            (!a->vcache || aligned_to(a->vcache, 16)) && (!a->vcache_wide || aligned_to(a->vcache_wide, 16)))) &&
+                         (!a->out2 || (a->ldo2 % 4 == 0 && aligned_to(a->out2, 16)))),
+               "a pipelined launch takes the plain or the folded-LayerNorm projection, <= 16 rows, whole 16-column tiles, 16-byte "
+               "aligned rows (its outputs leave as 16-byte pieces)");
     // completion protocol 1 has a flag word per ticket shard (workgroup index mod 8): a launch of fewer than 8 workgroups would
     // leave flags that nobody writes, and every consumer would sit out its time-out on them
     JB_REQUIRE(!pipe || pipe->proto < 1 || njt >= 8, "completion protocol 1 needs launches of >= 8 workgroups (J >= 128)");

@@ -29,6 +29,10 @@ CASES = {
     # ... and as it is built: attn_order 10 (cross-attention layers 18 and 28 inside depth 29), merged_decoder, 512 encoder states
     "5b_order10": dict(W=4800, depth=29, heads=8, attn_order=10, blocks=128, seq=8192, bins=2048, prime_len=None, y_cond=True,
                        t0=700, n_steps=48, N=3, seed=7, enc_len=512, merged_decoder=True),
+    # ... and at its REAL depth: all 79 layers of prior_5b_lyrics (hparams.py:127-156), cross-attention layers 18, 28, ..., 78
+    # (22 GB of fp32 weights: generated on a thread pool, see state_dict)
+    "5b_order10_full": dict(W=4800, depth=79, heads=8, attn_order=10, blocks=128, seq=8192, bins=2048, prime_len=None, y_cond=True,
+                            t0=700, n_steps=64, N=3, seed=9, enc_len=512, merged_decoder=True),
 }
 
 # Whole greedy windows from the UNMODIFIED reference (tests/golden/gen_whole_window.py: CPU hours here, zero GPU minutes): the
@@ -67,8 +71,10 @@ def _normal(seed, what, idx, shape, scale):
     return rng.standard_normal(shape, dtype=np.float32) * np.float32(scale)
 
 
-def state_dict(case):
-    """Reference-named state dict of the case's prior (float32 numpy)."""
+def state_dict(case, threads=None):
+    """Reference-named state dict of the case's prior (float32 numpy).  Every tensor has a stream of its own (case seed, layer,
+    index), so the layers are generated side by side on a thread pool (numpy releases the GIL while it draws): the 5.5 billion
+    weights of the full-depth 5b case take seconds on the GPU box's host cores, and the result does not depend on the pool."""
     W, depth, bins, seq, seed = case["W"], case["depth"], case["bins"], case["seq"], case["seed"]
     S = W // 4
     funcs = attn_funcs(case)
@@ -76,7 +82,9 @@ def state_dict(case):
     sd["x_out.weight"] = _normal(seed, 0, 2, (bins, W), 0.05) if case.get("merged_decoder") else sd["x_emb.weight"]
     if not case["y_cond"]:
         sd["start_token"] = _normal(seed, 0, 3, (1, W), 0.01)
-    for d in range(depth):
+
+    def layer(d):
+        out = {}
         p = f"transformer._attn_mods.{d}."
         cross = funcs[d] == 6
         j_attn = S if cross else 3 * S
@@ -84,13 +92,25 @@ def state_dict(case):
                                              ("mlp.c_fc.w", (W, W), 0.02), ("mlp.c_proj.w", (W, W), 0.02),
                                              ("attn.c_attn.b", (j_attn,), 0.01), ("attn.c_proj.b", (W,), 0.01),
                                              ("mlp.c_fc.b", (W,), 0.01), ("mlp.c_proj.b", (W,), 0.01))):
-            sd[p + nm] = _normal(seed, 1 + d, i, shape, sc)
+            out[p + nm] = _normal(seed, 1 + d, i, shape, sc)
         if cross:
-            sd[p + "attn.c_enc_kv.w"] = _normal(seed, 1 + d, 8, (W, 2 * S), 0.02)
-            sd[p + "attn.c_enc_kv.b"] = _normal(seed, 1 + d, 9, (2 * S,), 0.01)
+            out[p + "attn.c_enc_kv.w"] = _normal(seed, 1 + d, 8, (W, 2 * S), 0.02)
+            out[p + "attn.c_enc_kv.b"] = _normal(seed, 1 + d, 9, (2 * S,), 0.01)
         for i, ln in enumerate(("ln_0", "ln_1")):
-            sd[p + ln + ".weight"] = 1 + _normal(seed, 1 + d, 10 + i, (W,), 0.05)
-            sd[p + ln + ".bias"] = _normal(seed, 1 + d, 12 + i, (W,), 0.02)
+            out[p + ln + ".weight"] = 1 + _normal(seed, 1 + d, 10 + i, (W,), 0.05)
+            out[p + ln + ".bias"] = _normal(seed, 1 + d, 12 + i, (W,), 0.02)
+        return out
+
+    if threads is None:
+        threads = min(32, os.cpu_count() or 1) if depth * W * W > 2 ** 30 else 1
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as pool:
+            layers = list(pool.map(layer, range(depth)))
+    else:
+        layers = [layer(d) for d in range(depth)]
+    for out in layers:                       # (layer order: the dict reads as the sequential form built it)
+        sd.update(out)
     return sd
 
 

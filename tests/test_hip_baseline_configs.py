@@ -420,6 +420,26 @@ def test_config5_5b_lyrics_order10_cross_attention():
     assert err.max() < 0.12 * max(1.0, float(np.abs(p32).max())) and err.mean() < 0.02 * max(1.0, float(p32.std())) and agree >= 0.95
 
 
+def test_config5_5b_lyrics_full_depth():
+    """BASELINE config 5's decoder at its REAL depth: all 79 layers of prior_5b_lyrics (hparams.py:127-156: width 4800, 8 heads
+    of 150, attn_order 10 with the cross-attention layers 18, 28, ..., 78 over 512 lyric-encoder states, merged_decoder), N = 3
+    (the reference's batch, sample.py:231-238), fp32: c_enc_kv projections + prefill of 700 positions -- EVERY layer's k / v rows
+    against the numpy oracle's digest (tests/golden/gen_full_size.py, offline on the CPU) -- then 64 greedy decode steps of all
+    samples against the torch port of the oracle's decode step.  22 GB of seeded fp32 weights, generated on a thread pool."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import full_size_cases as FS
+    if not os.path.exists(FS.golden_path("5b_order10_full")):
+        pytest.skip("tests/golden/full_size_5b_order10_full.npz has not been generated (minutes of CPU oracle otherwise)")
+    h = setup_hparams("prior_5b_lyrics", {})
+    case = FS.CASES["5b_order10_full"]
+    assert (h.prior_width, h.heads, h.blocks, h.n_ctx, h.attn_order, h.prior_depth, h.n_tokens) == \
+        (case["W"], case["heads"], case["blocks"], case["seq"], case["attn_order"], case["depth"], case["enc_len"])
+    assert [d for d, f in enumerate(FS.attn_funcs(case)) if f == 6] == [18, 28, 38, 48, 58, 68, 78]
+    _full_size_case("5b_order10_full")
+    torch.cuda.empty_cache()
+
+
 def test_config5_5b_lyrics_lyric_encoder_geometry():
     """The lyric encoder of prior_5b_lyrics at its real size (prior.py:104-117,285-292 with hparams.py:139-146: width 1280,
     depth 18, 4 heads of 80 channels, attn_order 2, blocks 32 over 512 tokens, 80 bins, only_encode): one prefill pass over

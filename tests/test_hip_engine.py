@@ -363,7 +363,7 @@ def test_pipelined_timeout_is_recovered_on_the_plain_chain(monkeypatch):
     def decode(self, t0, n_steps, use_graph=True, plain=False):
         if self.pipelined and not injected:
             injected.append((t0, n_steps))
-            self.pipe_words[18 * self.launches_per_step * 32] = 7          # "slot 6 timed out"
+            self.pipe_words[18 * self.pipe_slots * 32] = 7          # "slot 6 timed out"
         return real_decode(self, t0, n_steps, use_graph, plain)
 
     monkeypatch.setattr(PriorEngine, "decode", decode)

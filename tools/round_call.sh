@@ -14,10 +14,10 @@
 # (Round 5's last full call was this with `r05f 20 1`: profiles/r05f_*.)
 # Copy what is to be judged into profiles/.  Always `python -u` and a `timeout` of your own: a call that runs into gpurun's
 # limit is lost.
-TAG=${1:-r05}; SECS=${2:-6}; STEPS=${3:-2}
+TAG=${1:-r06}; SECS=${2:-6}; STEPS=${3:-2}
 export PYTHONPATH=$PWD TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -u -m pytest tests -q -m gpu -p no:cacheprovider --durations=8 -s > gpurun_out/${TAG}_gpu_tests.log 2>&1
+timeout 1500 python -u -m pytest tests -q -m gpu -p no:cacheprovider --durations=8 -s > gpurun_out/${TAG}_gpu_tests.log 2>&1
 grep -E "passed|failed|error" gpurun_out/${TAG}_gpu_tests.log | tail -3
 timeout 300 python -u __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.log 2>&1; tail -2 gpurun_out/${TAG}_smoke.log
 JB_BENCH_TIMELINE=1 timeout 1500 python -u bench.py --gpus 1 --seconds $SECS --steps $STEPS --warmup 1 \
