@@ -33,6 +33,9 @@ def _parse_args(argv=None):
     ap.add_argument("--model", default="1b_lyrics")
     ap.add_argument("--seconds", type=float, default=20.0)
     ap.add_argument("--samples-per-gpu", type=int, default=16)
+    ap.add_argument("--max-batch-size", type=int, default=0,
+                    help="rows per engine call (the reference's max_batch_size, sample.py:231-238: 16 -- a V100 limit); 0 = the "
+                         "reference's value.  The headline stays at 16; larger values are the separate report SURVEY 8d asks for")
     ap.add_argument("--cpu-steps", type=int, default=32, help="decode steps of the fallback CPU port (kind 'port')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -410,6 +413,9 @@ def main():
                       keep_priors_resident=True, pipeline_levels=not a.no_pipeline, seed=0)
     labels = synthetic_labels(priors, n_samples, 180 * sr if not tiny else 3 * 4608, device)
     sk = S.default_sampling_kwargs(a.model if not tiny else "1b_lyrics")
+    if a.max_batch_size > 0:
+        for k in sk:
+            k["max_batch_size"] = a.max_batch_size
     audio_seconds_per_step = n_samples * sample_length / sr
 
     level_t, level_t0 = {}, {}
@@ -534,7 +540,8 @@ def main():
                                     f"{sample_length / sr:.2f} s audio at {sr} Hz, n_samples={n_samples} "
                                     f"({a.samples_per_gpu}/GPU), temp=0.99, fp16 activations and weights, "
                                     "hop_fraction=(0.5,0.5,0.125), random-init weights",
-                           samples_per_gpu=a.samples_per_gpu, parallelism=f"sample-sharded x{world}",
+                           samples_per_gpu=a.samples_per_gpu, max_batch_size=[k["max_batch_size"] for k in sk],
+                           parallelism=f"sample-sharded x{world}",
                            wall_budget_s=BUDGET_S,
                            note="a step is the whole 3-level job; the run times as many full steps as fit the wall budget "
                                 "(steps <= steps_requested), after at most one short warm-up pass"),

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
 // the 960-byte row into a region of its own (no workgroup barrier: a wave's LDS operations are ordered) and the QK^T chain
 // reads its B operands from there.  At <= 168 registers per lane a workgroup shares a compute unit with a WAITING projection
 // workgroup of a pipelined chain (8 waves at 88 registers): the fat form needs an EMPTY compute unit, which is why only one
-// engine of a process could run pipelined launches, and why a plain chain next to a pipelined engine starved.
+// engine of a process could run pipelined launches, and why a plain chain next to a pipelined engine starved (HISTORY.md section 4.2).
 template <int ND32, bool PIPE = false, bool QL = false>
 __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f16* __restrict__ q, int64_t ldq,
                                                                const f16* __restrict__ kc, const f16* __restrict__ vw, int cap,

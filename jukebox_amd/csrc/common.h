@@ -152,7 +152,7 @@ __device__ __forceinline__ float jb_load_any(const void* p, int dtype, int64_t i
     return dtype == JB_F16 ? (float)((const f16*)p)[i] : ((const float*)p)[i];
 }
 
-// ---- software-pipelined launches (engine.hip) ------------------------------------------------
+// ---- software-pipelined launches (engine.hip; measurements: HISTORY.md section 4.2) ------------------------------------------------
 // The kernels of a decode step alternate between two streams, so launch j+1 is dispatched -- and requests its weights --
 // while launch j still runs; the dependency itself is a completion word per launch slot:
 //   runs[slot]    how often the slot has completed since the words were last zeroed (written by its last workgroup),

@@ -330,7 +330,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
     return JB_OK;
 }
 
-// Software-pipelined launches of the decode step (DESIGN.md section 4.2).  Available where every launch of the step has a
+// Software-pipelined launches of the decode step (DESIGN.md section 5).  Available where every launch of the step has a
 // pipelined form: fp16, <= 16 samples, wide-value layers throughout (one head of 480 channels), widths of 33..64 k-tiles.
 // ... or (multi-head engines: 5b_lyrics' top prior) five launches per layer with the MFMA decode attention: fp16, <= 16 samples, folded
 // LayerNorm, no key-split layer, heads of 150 (ragged) / 256 / 512 channels, projections of 33..64 or 129..160 k-tiles.
@@ -369,7 +369,7 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     // two such workgroups fill a compute unit) while it spins, and the producer it waits for must still find room -- the
     // wide-value attention workgroup needs an otherwise EMPTY compute unit, and the waiters of two engines can leave none (round
     // 4: every slot timed out).  Round 5 admitted two engines on a lean form of that kernel; side by side they ran at 2.02 ms
-    // per step against 2.09 for two plain chains and the job did not get faster: removed in round 6.
+    // per step against 2.09 for two plain chains and the job did not get faster (HISTORY.md sections 4.5 / 4.6): removed in round 6.
     JB_REQUIRE(enable >= 0 && enable <= 2, "enable must be 0, 1 or 2");
     std::lock_guard<std::mutex> lock(g_pipe_mutex);
     if (enable) {

@@ -208,7 +208,7 @@ class ConditionalAutoregressive2D(nn.Module):
     def _decode(self, eng, t0, n_steps):
         """eng.decode, with the two launch forms compared IN SITU the first time an engine runs pipelined launches: the same
         process has measured them at 1.6 ms per step (the pair of streams made early) and at 3.0 ms + 0.18 s per call (made
-        late, a waiting packet in a neighbouring hardware queue: DESIGN.md section 4.2), against 1.87 ms for the plain chain.
+        late, a waiting packet in a neighbouring hardware queue: HISTORY.md section 4.2), against 1.87 ms for the plain chain.
         Both forms produce the same tokens bit for bit, so the window's first steps are the measurement: 384 pipelined steps,
         128 plain ones (after 16 untimed ones: the plain graph may not exist yet, and its capture is not the chain's speed;
         112 / 64 after 8 in a call of 256..1023 steps), and the engine keeps pipelined launches only if they were >= 3 %

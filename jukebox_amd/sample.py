@@ -120,7 +120,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # land on one hardware queue and serialise completely, whereas torch's pooled high-priority streams plus one
     # normal-priority stream ran three decode chains concurrently at 1.3x the single-chain step time.  The two
     # upsampler levels (the long poles) therefore get high priority, the top level normal priority.
-    # Tried and measured in round 2: confining the levels' token loops to disjoint CU sets
+    # Tried and measured in round 2 (HISTORY.md section 5a): confining the levels' token loops to disjoint CU sets
     # (hipExtStreamCreateWithCUMask, tools/cu_mask_probe.py) -- the long pole runs faster while the others decode, but they
     # decode longer, and the job time does not move; prefilling the next window in a second engine while the current one
     # decodes -- the prefill's bandwidth slows the latency-bound chain by what it saves.  Neither is in the tree.
@@ -237,7 +237,7 @@ def _sample_levels_pipelined(zs_local, labels, sampling_kwargs, priors, sample_l
     # pipelined / 1.77 plain; two plain chains side by side 2.09 each; a pipelined engine next to a plain chain 5.9 / 6.8.
     # (Round 5 also built TWO pipelined levels side by side -- a lean attention kernel, two owners in the library, regimes and
     # a rendezvous here: 2.02 ms per step each against 2.09, 67.53 s against 67.21 s for the default on the 6-second job; it
-    # did not pay and was removed in round 6: DESIGN.md / HISTORY.md.)  The engine is asked before every window and every 512
+    # did not pay and was removed in round 6: HISTORY.md sections 4.5 / 4.6.)  The engine is asked before every window and every 512
     # steps of a window on the plain chain; its pair of streams is made when the launches are switched on and released when
     # they go off or the job ends: two more hardware queues in the process -- even idle ones -- slowed the concurrent levels'
     # plain chains 2.5x (profiles/r04_pipe_in_job.log).
@@ -286,7 +286,7 @@ def _release_pipelines(priors, levels):
 
 
 def _want_pipelined_launches(hps):
-    """Software-pipelined launches of the decode step (-14 % per token step for an engine that has the
+    """Software-pipelined launches of the decode step (-24 % per token step for an engine that has the
     GPU to itself, bit-identical tokens) are the sampler's default for a level that runs alone; hps.pipeline_launches = False
     or JB_PIPELINE_LAUNCHES=0 keeps the plain launch chain."""
     if os.environ.get("JB_PIPELINE_LAUNCHES", "") == "0":

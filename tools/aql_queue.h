@@ -1,6 +1,6 @@
 // User-mode AQL dispatch: a hardware queue of one's own, fed with pre-built kernel-dispatch packets (probe tool).
 //
-// Why it was tried (round 4): the software-pipelined launches need launch j+1 dispatched while launch j
+// Why it was tried (round 4): the software-pipelined launches (HISTORY.md section 4.3) need launch j+1 dispatched while launch j
 // runs.  HIP offers that only across streams -- i.e. across hardware queues -- and refuses hipExtAnyOrderLaunch on gfx9.  An AQL
 // packet carries the ordering itself: with the BARRIER bit clear the packet processor starts the next packet of the SAME queue
 // as soon as the previous one's workgroups are placed, and its header says which cache actions surround the dispatch.  The

@@ -1,4 +1,4 @@
-// Micro-benchmark for a PERSISTENT decode step: the 4 x 72 dependent phases of one token step of the
+// Micro-benchmark for a PERSISTENT decode step (HISTORY.md section 4.2): the 4 x 72 dependent phases of one token step of the
 // level-0 upsampler (1920 wide, 72 wide-value layers, 16 rows) run inside ONE launch, every workgroup owning the same
 // output tile of the same projection in every layer, so that
 //   * the weight stream (or the old K / v' rows) of a workgroup's NEXT task is requested before the dependency edge resolves

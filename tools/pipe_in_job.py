@@ -1,4 +1,4 @@
-"""Why are software-pipelined launches slow INSIDE the 3-level job?  (finding 3.)
+"""Why are software-pipelined launches slow INSIDE the 3-level job?  (HISTORY.md section 4.2, finding 3.)
 
 One process, one GPU call: a short 3-level job (1b_lyrics, 16 samples, --seconds of audio, level pipeline, level 0 pipelined
 while it runs alone), then the job's own level-0 engine is timed in the state the job leaves the process in:

@@ -1,4 +1,4 @@
-// Micro-benchmark for SOFTWARE-PIPELINED LAUNCHES of a dependent kernel chain.
+// Micro-benchmark for SOFTWARE-PIPELINED LAUNCHES of a dependent kernel chain (HISTORY.md sections 4.2 / 4.4).
 //
 // The decode step is a chain of ~290 kernels; each costs ~6 us of which ~3.5 us do not depend on the producer (launch
 // boundary, wave start, the cold round trip of a weight stream whose addresses are known at capture time).  Here the

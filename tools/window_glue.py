@@ -1,4 +1,4 @@
-"""Where a level-0 window's non-decode time goes (DESIGN.md section 8: a window that runs alone is 4096 x the decode step
+"""Where a level-0 window's non-decode time goes (DESIGN.md section 6: a window that runs alone is 4096 x the decode step
 + ~0.5 s, of which the conditioner and the prefill micro-benchmarks explain 0.37 s).
 
 One process: the level-0 upsampler of 1b_lyrics with seeded random weights, 16 samples; windows of 4096 primed tokens +
