@@ -399,11 +399,13 @@ int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* str
  * enable makes a new one (milliseconds).  enable = 2 is enable = 1 with a fresh pair at the next decode.  The engine must
  * be idle in every case.  Replaces the same reference code as jb_engine_decode. */
 int jb_engine_pipeline(void* handle, int enable);
-/* The hand-off form of the pipelined launches, read when an engine's pair of graphs is captured: operand_order = 1 (default) --
- * the activation blocks between the launches in MFMA operand order ([k-tile][lane][8 channels] of 16 rows: a consumer wave's
- * fetch of a k-tile is one contiguous KiB, a producer's 16 x 16 tile two runs of 256 bytes) where the engine can (single head,
- * cfg.act_rows >= 16); 0 -- [row][channel] (16 half lines per wave request).  Measured on the upsampler step at 16 samples:
- * 1.407 against 1.522 ms.  Same arithmetic either way: tokens and logits stay bit-identical to the plain chain.  The reference
+/* The hand-off form of the decode step, read when an engine is created: operand_order = 1 (default) -- the activation blocks
+ * between the launches (x_a, x_b, mlp) in MFMA operand order ([k-tile][lane][8 channels] of 16 rows: a consumer wave's fetch of
+ * a k-tile is one contiguous KiB, a producer's 16 x 16 tile two runs of 256 bytes, 16-byte stores) where the engine can (the
+ * shapes jb_engine_pipeline accepts for a single head, cfg.act_rows >= 16): such an engine runs the SAME kernels as a plain
+ * chain (the kernel boundary is the hand-shake) and as software-pipelined launches (completion words).  0 -- [row][channel]
+ * and, for the plain chain, the plain kernels (16 half lines per wave request).  Measured on the upsampler step at 16 samples,
+ * pipelined launches: 1.407 against 1.522 ms.  Same arithmetic in every form: tokens and logits are bit-identical.  The reference
  * has no counterpart (its hand-off between two layers is a tensor in HBM: jukebox/transformer/transformer.py:62-66,82-86). */
 void jb_tune_pipeline(int operand_order);
 /* 1 while the engine's decode steps run as pipelined launches, else 0 (also after a fallback to the plain chain). */

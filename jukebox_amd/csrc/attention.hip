@@ -214,7 +214,9 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
             for (int e = 0; e < 8; ++e) qf[dt][e] = (cb < d && foff[dt] + e >= cb) ? qf[dt][e] : (f16)0;
         }
     }
-    const int t = *t_dev;
+    // (PIPE: behind jb_pipe_wait, read past the scalar cache like every other pipelined kernel's position -- not dependent on
+    // which launch's dispatch-time invalidate happened to follow the sampler's write)
+    const int t = PIPE ? (int)jb_ld_word(reinterpret_cast<const unsigned*>(t_dev)) : *t_dev;
     const KeySet ks = decode_key_set(func, t, bc, cap);
     f16* o = out + (int64_t)n * ldo + h * d;
     if (ks.count == 0) {
@@ -508,14 +510,22 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     __syncthreads();
     float m = -INFINITY;
     for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);
+    // the waves' weights exp(m_w - m), once (they scale the sums AND the channel partials; launches have <= 8 waves)
+    float ew[8];
     float lsum = 0.f;
-    for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] * expf(s_ml[2 * w] - m);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        ew[w] = w < nw ? expf(s_ml[2 * w] - m) : 0.f;
+        if (w < nw) lsum += s_ml[2 * w + 1] * ew[w];
+    }
     const float inv = 1.0f / lsum;
     if constexpr (PIPE) {
-        // every thread takes a channel (those past d a duplicate), four neighbours leave as one 8-byte write-through store
+        // every thread takes a channel (those past d a duplicate)
         const int ch = min((int)threadIdx.x, d - 1);
         float a = 0.f;
-        for (int w = 0; w < nw; ++w) a += s_o[w * d + ch] * expf(s_ml[2 * w] - m);
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            if (w < nw) a += s_o[w * d + ch] * ew[w];
         const float cp = jb_round<f16>(a * inv + jb_round<f16>(bias_e));
         const float v1 = jb_round<f16>((float)res_e + cp);
         // eight neighbours leave as ONE 16-byte write-through store: lanes 1, 2, 3 of the thread's quad, then the next quad's
@@ -533,7 +543,9 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     }
     if (threadIdx.x < d) {
         float a = 0.f;
-        for (int w = 0; w < nw; ++w) a += s_o[w * d + threadIdx.x] * expf(s_ml[2 * w] - m);
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            if (w < nw) a += s_o[w * d + threadIdx.x] * ew[w];
         // attn.c_proj's epilogue (bias, round) and the residual add of the block, as jb_gemv does them
         const float cp = jb_round<f16>(a * inv + jb_round<f16>(bias_e));
         o[och] = (f16)jb_round<f16>((float)res_e + cp);
@@ -762,7 +774,7 @@ int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const vo
     if (pipe) {
         JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30) && ldo % 8 == 0 && ((uintptr_t)x_out % 16) == 0,
                    "a pipelined launch of the wide-value attention takes d_head = 480, caches below 2 GiB and 16-byte aligned output rows");
-        JB_REQUIRE(pipe->proto < 1 || (int64_t)grid.x * grid.y >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
+        JB_REQUIRE(pipe->slot < 0 || pipe->proto < 1 || (int64_t)grid.x * grid.y >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
         if (lean)
             attn_decode_wide_kernel<15, true, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
                                                                              (const f16*)vcache_w, cache_cap, (const f16*)res, ldr,

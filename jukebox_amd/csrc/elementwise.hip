@@ -445,7 +445,7 @@ static int launch_sample(const float* logits, int n_batch, int bins, const jb_sa
     const size_t lds = (size_t)n2 * sizeof(float);
     if (pipe) {
         if (tail.x_dtype != JB_F16 || !tail.x_next) JB_UNSUPPORTED("a pipelined sampler launch takes the fp16 decode step's tail");
-        if (pipe->proto >= 1 && n_batch < 8) JB_UNSUPPORTED("completion protocol 1 needs launches of >= 8 workgroups (>= 8 samples)");
+        if (pipe->slot >= 0 && pipe->proto >= 1 && n_batch < 8) JB_UNSUPPORTED("completion protocol 1 needs launches of >= 8 workgroups (>= 8 samples)");
         sample_kernel<true><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds, preds_n_stride,
                                                             tail, *pipe);
     } else {

@@ -38,12 +38,14 @@ struct JbEngine {
     // software-pipelined launches (jb_engine_pipeline): the launches of a step alternate between two streams of the engine's
     // own, as two single-stream graphs that are replayed side by side
     bool pipelined = false;
+    bool operand_order = false;             // activation blocks of the decode step in operand order (decided at creation: the
+                                            // captured graphs and the embedding of a call's first position must agree)
     hipStream_t pstream[2] = {nullptr, nullptr};                   // the engine's own pair (setup_pipeline_streams)
     hipGraph_t pgraph[2] = {nullptr, nullptr};
     hipGraphExec_t pexec[2] = {nullptr, nullptr};
 };
 
-// Hand-off form of the pipelined launches, read when an engine's pair of graphs is captured (jb_tune_pipeline): activation blocks
+// Hand-off form of the decode step, read when an engine is CREATED (jb_tune_pipeline): activation blocks
 // between the launches in MFMA operand order (common.h: JB_FRAG_*; single-head engines whose decode buffers hold 16 rows,
 // jb_engine_cfg.act_rows) or as [row][channel].
 static int g_pipe_frag = 1;
@@ -58,6 +60,8 @@ __global__ void to_operand_order_kernel(const f16* __restrict__ src, f16* __rest
     *reinterpret_cast<f16x8*>(dst + jb_frag_el(row, col)) = *reinterpret_cast<const f16x8*>(src + (int64_t)row * width + col);
 }
 __global__ void inc_int_kernel(int* p) { *p += 1; }
+
+static bool decide_operand_order(const JbEngine* e);
 
 extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers, void** handle) {
     JB_REQUIRE(cfg && layers && handle, "null pointer");
@@ -106,6 +110,7 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
     JbEngine* e = new JbEngine();
     e->cfg = *cfg;
     e->layers.assign(layers, layers + cfg->n_layers);
+    e->operand_order = decide_operand_order(e);
     *handle = e;
     return JB_OK;
 }
@@ -217,18 +222,33 @@ static void fill_c_attn(jb_gemv_args& g, const jb_engine_cfg& c, const jb_layer&
     }
 }
 
+static bool pipe_operand_order(const JbEngine* e);
+// The embedding of position t0 into x_a, in the layout the step's first projection fetches: rows, or -- engines on operand-order
+// blocks -- re-laid through x_b, which is free until the first attention launch writes it.
 static int enqueue_embed(JbEngine* e, int t0, hipStream_t s) {
     const jb_engine_cfg& c = e->cfg;
-    return jb_embed(c.dtype, c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
-                    c.xc_n_stride, c.xc_t_stride, c.n_batch, c.width, t0, nullptr, 1, s);
+    const bool frag = pipe_operand_order(e);
+    JB_TRY(jb_embed(c.dtype, frag ? c.x_b : c.x_a, c.tokens, c.tok_stride, c.x_emb, c.pos_emb, c.start, c.start_stride, c.x_cond,
+                    c.xc_n_stride, c.xc_t_stride, c.n_batch, c.width, t0, nullptr, 1, s));
+    if (frag) {
+        const int pieces = c.n_batch * c.width / 8;
+        to_operand_order_kernel<<<(pieces + 255) / 256, 256, 0, s>>>((const f16*)c.x_b, (f16*)c.x_a, c.n_batch, c.width);
+        JB_CHECK_LAUNCH();
+    }
+    return JB_OK;
 }
 
 static bool pipeline_eligible_multi_head(const JbEngine* e);
-// Whether this engine's pipelined launches hand their activation blocks over in operand order (common.h): the single-head
-// wide-value form (every launch of its step is one of the four kernels that know the layout), decode buffers of 16 rows, whole
-// 32-channel k-tiles in width and MLP (pipeline_eligible), and the switch (jb_tune_pipeline).
-static bool pipe_operand_order(const JbEngine* e) {
-    return g_pipe_frag && e->cfg.act_rows >= 16 && e->cfg.n_batch <= 16 && e->cfg.dtype == JB_F16 && !pipeline_eligible_multi_head(e);
+static bool pipeline_eligible(const JbEngine* e);
+// Whether this engine's decode step hands its activation blocks over in operand order (common.h): the single-head wide-value
+// form whose every launch has a pipelined kernel form (pipeline_eligible: fp16, <= 16 samples, one 480-channel head, whole
+// 32-channel k-tiles in width and MLP), decode buffers of 16 rows, and the switch (jb_tune_pipeline).  Such an engine runs the
+// SAME kernels in both launch forms: software-pipelined launches synchronise through their completion words, the plain chain
+// launches them with JB_PIPE_NO_SYNC -- the kernel boundary is the hand-shake -- and keeps the operand-order blocks and the
+// 16-byte stores (round 6: the plain chain's fetch of the 61-KB block had the same 16-half-lines-per-request pattern).
+static bool pipe_operand_order(const JbEngine* e) { return e->operand_order; }
+static bool decide_operand_order(const JbEngine* e) {
+    return g_pipe_frag && e->cfg.act_rows >= 16 && !pipeline_eligible_multi_head(e) && pipeline_eligible(e);
 }
 
 // One decode step at position *t_dev (x_a already holds that position's embedding); everything position-dependent is
@@ -248,16 +268,19 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
               (getenv("JB_PIPE_TIMEOUT_MS") ? atoll(getenv("JB_PIPE_TIMEOUT_MS")) : 2000ll) * 100000ll,
               (c.pipe_words && getenv("JB_PIPE_DEBUG")) ? reinterpret_cast<long long*>(c.pipe_words + jb_pipe_words(n_slots)) : nullptr,
               c.n_batch >= 8 ? 1 : 0, 0};
-    const bool frag = parity >= 0 && pipe_operand_order(e);
-    // the pipeline slot of the next launch, or NULL for the plain chain; `mine`: this call enqueues it; `layout`: which of the
-    // launch's activation blocks (JB_FRAG_X operand, JB_FRAG_OUT output, JB_FRAG_RES residual) are in operand order
+    const bool frag = pipe_operand_order(e);
+    if (parity < 0) pp.dbg = nullptr;          // (stamps are per completion slot)
+    // the pipeline slot of the next launch -- for the plain chain NULL (the plain kernels), or, for an engine on operand-order
+    // blocks, the pipelined kernel form without its hand-shake (JB_PIPE_NO_SYNC); `mine`: this call enqueues it; `layout`: which
+    // of the launch's activation blocks (JB_FRAG_X operand, JB_FRAG_OUT output, JB_FRAG_RES residual) are in operand order
     bool mine = true;
     auto next = [&](int layout = 0) -> const JbPipe* {
         mine = parity < 0 || (slot & 1) == parity;
-        pp.slot = slot; pp.prev = slot == 0 ? n_slots - 1 : slot - 1;
+        pp.slot = parity < 0 ? JB_PIPE_NO_SYNC : slot;
+        pp.prev = slot == 0 ? n_slots - 1 : slot - 1;
         pp.frag = frag ? layout : 0;
         ++slot;
-        return parity < 0 ? nullptr : &pp;
+        return (parity < 0 && !frag) ? nullptr : &pp;
     };
     for (int l = 0; l < c.n_layers; ++l) {
         const jb_layer& L = e->layers[l];
@@ -495,15 +518,6 @@ static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s, bool use_gr
     JB_TRY(prepare_pipeline(e));
     // completion counts and tickets start from zero in every call
     JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));
-    if (pipe_operand_order(e)) {
-        // the first position's embedding (jb_engine_decode has just written it as rows) in the order the first projection fetches
-        // it; x_b is free until the first attention launch writes it
-        const jb_engine_cfg& c = e->cfg;
-        const int pieces = c.n_batch * c.width / 8;
-        to_operand_order_kernel<<<(pieces + 255) / 256, 256, 0, s>>>((const f16*)c.x_a, (f16*)c.x_b, c.n_batch, c.width);
-        JB_CHECK_LAUNCH();
-        JB_HIP(hipMemcpyAsync(c.x_a, c.x_b, (size_t)16 * c.width * sizeof(f16), hipMemcpyDeviceToDevice, s));
-    }
     JB_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < n_steps; ++i)
         for (int k = 0; k < 2; ++k) {
@@ -691,13 +705,18 @@ extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, voi
         for (int i = 0; i < reps; ++i)
             for (int l = 0; l < c.n_layers; ++l) {
                 const jb_layer& L = e->layers[l];
+                // (the kernel form the engine's own steps launch: operand-order blocks where it has them)
+                JbPipe pp{nullptr, nullptr, nullptr, JB_PIPE_NO_SYNC, -1, 0, nullptr, 0, 0};
+                const bool frag = pipe_operand_order(e);
                 jb_gemv_args g;
                 fill_c_attn(g, c, L);
-                JB_TRY(jb_gemv(&g, s));
+                pp.frag = JB_FRAG_X;
+                JB_TRY(jb_gemv_impl(&g, frag ? &pp : nullptr, s));
                 g = {};
                 fill_ln_proj(g, c, L, 1);
                 g.x = c.x_b; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
-                JB_TRY(jb_gemv(&g, s));
+                pp.frag = JB_FRAG_X | JB_FRAG_OUT;
+                JB_TRY(jb_gemv_impl(&g, frag ? &pp : nullptr, s));
             }
         return JB_OK;
     };

@@ -1961,7 +1961,7 @@ extern "C" int jb_gemv_ln_fold_supported(int dtype, int K, int J, int n_rows) {
 template <typename T, int MT, int NW>
 static int launch_gemv_lnf_nf(const GemvParams& p, int njt, int nf, hipStream_t s) {
     const size_t lds = (size_t)NW * MT * 64 * sizeof(f32x4) + (size_t)2 * NW * MT * 16 * sizeof(float);
-    if (p.pipe.slot >= 0) {
+    if (p.pipe.slot != -1) {
         if constexpr (MT == 1 && NW == 8 && sizeof(T) == 2) {
             if (nf == 8) { gemv_lnf_kernel<T, 1, 8, 8, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
         }
@@ -1985,7 +1985,7 @@ static int launch_gemv_lnf(const GemvParams& p, int njt, int nf, int nw, hipStre
         if constexpr (sizeof(T) == 2) {
             if (g_gemv_long && p.nkt <= 160) {          // 8 waves x 4 batches of 5 k-tiles
                 const size_t lds = (size_t)8 * 64 * sizeof(f32x4) + (size_t)2 * 8 * 16 * sizeof(float);
-                if (p.pipe.slot >= 0) gemv_long_kernel<T, 8, 5, 4, true, true><<<njt, 8 * 64, lds, s>>>(p);
+                if (p.pipe.slot != -1) gemv_long_kernel<T, 8, 5, 4, true, true><<<njt, 8 * 64, lds, s>>>(p);
                 else gemv_long_kernel<T, 8, 5, 4, true, false><<<njt, 8 * 64, lds, s>>>(p);
                 return JB_OK;
             }
@@ -2015,7 +2015,7 @@ static int launch_gemv_fast(const GemvParams& p, int njt, size_t lds, hipStream_
 
 template <typename T, int MT, int NW, bool LNS>
 static int launch_gemv_inst(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
-    if (p.pipe.slot >= 0) {
+    if (p.pipe.slot != -1) {
         if constexpr (MT == 1 && (NW == 8 || NW == 4) && !LNS) {
             if (p.fast) { gemv_kernel<T, 1, NW, false, true, 0, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
         }
@@ -2056,12 +2056,12 @@ static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
         if constexpr (sizeof(T) == 2) {
             if (g_gemv_long) {                          // 8 waves x 4 batches of 5 k-tiles
                 const size_t lds = (size_t)8 * 64 * sizeof(f32x4);
-                if (p.pipe.slot >= 0) gemv_long_kernel<T, 8, 5, 4, false, true><<<njt, 8 * 64, lds, s>>>(p);
+                if (p.pipe.slot != -1) gemv_long_kernel<T, 8, 5, 4, false, true><<<njt, 8 * 64, lds, s>>>(p);
                 else gemv_long_kernel<T, 8, 5, 4, false, false><<<njt, 8 * 64, lds, s>>>(p);
                 return JB_OK;
             }
         }
-        if (p.pipe.slot >= 0) {
+        if (p.pipe.slot != -1) {
             if constexpr (sizeof(T) == 2) {
                 gemv_kernel<T, 1, 16, false, true, 0, true><<<njt, 16 * 64, (size_t)16 * 64 * sizeof(f32x4), s>>>(p);
                 return JB_OK;
@@ -2137,7 +2137,7 @@ int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream) {
                "aligned rows (its outputs leave as 16-byte pieces)");
     // completion protocol 1 has a flag word per ticket shard (workgroup index mod 8): a launch of fewer than 8 workgroups would
     // leave flags that nobody writes, and every consumer would sit out its time-out on them
-    JB_REQUIRE(!pipe || pipe->proto < 1 || njt >= 8, "completion protocol 1 needs launches of >= 8 workgroups (J >= 128)");
+    JB_REQUIRE(!pipe || pipe->slot < 0 || pipe->proto < 1 || njt >= 8, "completion protocol 1 needs launches of >= 8 workgroups (J >= 128)");
     p.dbg = nullptr;
 #ifdef JB_TIMING
     p.dbg = jb_dbg_ptr;

@@ -241,7 +241,11 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, hea
     xc = torch.from_numpy((rng.standard_normal((N, seq, width)) * 0.1).astype(np.float32))
     prime = torch.from_numpy(rng.integers(0, bins, (N, 200))).cuda()
     outs = {}
-    for mode in ("chain", "pipelined"):
+    # "classic": the plain chain on the plain kernels and [row][channel] blocks (jb_tune_pipeline(0)); "chain": the plain chain as
+    # single-head engines run it since round 6 -- the pipelined kernel forms on operand-order blocks, the kernel boundary as the
+    # hand-shake --; "pipelined": the same kernels synchronised through their completion words
+    for mode in ("classic", "chain", "pipelined"):
+        L.lib().jb_tune_pipeline(0 if mode == "classic" else 1)          # (read when the engine is created)
         monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1" if mode == "pipelined" else "0")
         eng = PE(sd, "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=heads, attn_order=2, blocks=blocks,
                  y_cond=False, fp16=True, want_preds=True, chunk_cap=64)
@@ -264,10 +268,12 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, hea
         outs[mode] = res
         eng.close()
     L.lib().jb_tune_gemv_long(1)                  # the default
-    for (z0, p0), (z1, p1) in zip(outs["chain"], outs["pipelined"]):
-        assert np.array_equal(z0, z1), "tokens differ between the plain chain and pipelined launches"
-        assert np.array_equal(p0, p1), "logits differ between the plain chain and pipelined launches"
-    assert not np.array_equal(outs["chain"][0][0][:, 200:], np.zeros_like(outs["chain"][0][0][:, 200:]))
+    L.lib().jb_tune_pipeline(1)
+    for other in ("chain", "pipelined"):
+        for (z0, p0), (z1, p1) in zip(outs["classic"], outs[other]):
+            assert np.array_equal(z0, z1), f"tokens differ between the classic plain chain and {other}"
+            assert np.array_equal(p0, p1), f"logits differ between the classic plain chain and {other}"
+    assert not np.array_equal(outs["classic"][0][0][:, 200:], np.zeros_like(outs["classic"][0][0][:, 200:]))
 
 
 def test_a_released_pair_leaves_the_other_engines_plain_chains_alone(PE, monkeypatch):
