@@ -205,7 +205,7 @@ def projection_roofline(eng, t0, n_steps):
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected in
     # their own rocprofv3 runs on the same kernel/shapes (profiles/r01_pmc_dominant_kernel.json); null otherwise
     traffic, source = None, None
-    for name in ("r05_pmc_dominant_kernel_wide.json", "r04_pmc_dominant_kernel_wide.json", "r03_pmc_dominant_kernel_wide.json", "r02_pmc_dominant_kernel.json",
+    for name in ("r06_pmc_dominant_kernel_engine_form.json", "r05_pmc_dominant_kernel_wide.json", "r04_pmc_dominant_kernel_wide.json", "r03_pmc_dominant_kernel_wide.json", "r02_pmc_dominant_kernel.json",
                  "r01_pmc_dominant_kernel.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))

@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libjukebox_hip.so")
 # instead of the product library ONLY when a measurement tool asks for it (tools/phase_segments.py sets JB_LIB_SEGMENTS=1)
 if os.environ.get("JB_LIB_SEGMENTS") == "1":
     LIB_PATH = os.path.join(_HERE, "csrc", "libjukebox_hip_segments.so")
+if os.environ.get("JB_LIB_PATH"):       # A/B measurements of two builds in one GPU call (tools/): an explicit path, never a fallback
+    LIB_PATH = os.environ["JB_LIB_PATH"]
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
 // reads its B operands from there.  At <= 168 registers per lane a workgroup shares a compute unit with a WAITING projection
 // workgroup of a pipelined chain (8 waves at 88 registers): the fat form needs an EMPTY compute unit, which is why only one
 // engine of a process could run pipelined launches, and why a plain chain next to a pipelined engine starved (HISTORY.md section 4.2).
-template <int ND32, bool PIPE = false, bool QL = false>
+template <int ND32, int PIPE = 0, bool QL = false>
 __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f16* __restrict__ q, int64_t ldq,
                                                                const f16* __restrict__ kc, const f16* __restrict__ vw, int cap,
                                                                const f16* __restrict__ res, int64_t ldr,
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     const f16* qrow = q + (int64_t)n * ldq;
     f16* s_q = reinterpret_cast<f16*>(s_o + nw * d) + wave * d;      // QL: [nw][d] halves, one row per wave
     unsigned pipe_own = 0;
-    if constexpr (PIPE) pipe_own = jb_pipe_own(pipe);
+    if constexpr (PIPE == 1) pipe_own = jb_pipe_own(pipe);
     f16x8 qf[QL ? 1 : ND32];
     if constexpr (!PIPE) {
         if constexpr (QL) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     const int och = sl * d + min((int)threadIdx.x, d - 1);
     const float bias_e = bias[och];
     // (PIPE with operand-order hand-offs, common.h: the residual stream in and out is [k-tile][lane][8], 16 rows per block)
-    const bool frag_res = PIPE && (pipe.frag & JB_FRAG_RES), frag_out = PIPE && (pipe.frag & JB_FRAG_OUT);
+    const bool frag_res = PIPE != 0 && (pipe.frag & JB_FRAG_RES), frag_out = PIPE != 0 && (pipe.frag & JB_FRAG_OUT);
     const f16 res_e = res[frag_res ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldr + och];
     jb_issue_fence();
     // PIPE: the position was written by the previous step's last launch, which this stream has already seen complete
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
             }
         }
         jb_issue_fence();
-        jb_pipe_wait(pipe, pipe_own, (int)(blockDim.x >> 6) - 1);      // (the last wave: usually nothing of its own in flight)
+        if constexpr (PIPE == 1) jb_pipe_wait(pipe, pipe_own, (int)(blockDim.x >> 6) - 1);      // (the last wave: usually nothing of its own in flight)
         if constexpr (QL) {
             if (lane * 8 < d) *reinterpret_cast<f16x8*>(s_q + lane * 8) = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + lane * 8);
         } else {
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
         if (ks.count == 0) {      // zero rows -> attention output 0 -> c_proj gives its bias
             if (threadIdx.x < d) jb_st_sc1(out, frag_out ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldo + och,
                                            (f16)jb_round<f16>((float)res_e + jb_round<f16>(jb_round<f16>(bias_e))));
-            jb_pipe_publish(pipe, pipe_own);
+            if constexpr (PIPE == 1) jb_pipe_publish(pipe, pipe_own);
             return;
         }
         if (wave < ntiles) {
@@ -507,7 +507,9 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
 #pragma unroll
         for (int e = 0; e < 8; ++e) s_o[wave * d + lane * 8 + e] = of[e];
     }
+    if constexpr (PIPE) JB_SEG_LGKM(pipe, 6);
     __syncthreads();
+    if constexpr (PIPE) JB_SEG(pipe, 7);
     float m = -INFINITY;
     for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);
     // the waves' weights exp(m_w - m), once (they scale the sums AND the channel partials; launches have <= 8 waves)
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o8), jb_rsrc(out),
                                                    (int)((frag_out ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldo + och) * 2), 0, 16);
         }
-        jb_pipe_publish(pipe, pipe_own);
+        if constexpr (PIPE == 1) jb_pipe_publish(pipe, pipe_own);
         return;
     }
     if (threadIdx.x < d) {
@@ -775,19 +777,19 @@ int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const vo
         JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30) && ldo % 8 == 0 && ((uintptr_t)x_out % 16) == 0,
                    "a pipelined launch of the wide-value attention takes d_head = 480, caches below 2 GiB and 16-byte aligned output rows");
         JB_REQUIRE(pipe->slot < 0 || pipe->proto < 1 || (int64_t)grid.x * grid.y >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
-        if (lean)
-            attn_decode_wide_kernel<15, true, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
-                                                                             (const f16*)vcache_w, cache_cap, (const f16*)res, ldr,
-                                                                             bias, (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe);
-        else
-            attn_decode_wide_kernel<15, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
-                                                                       (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, bias,
-                                                                       (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe);
+#define JB_LAUNCH_DECW_PIPE(FORM, LEAN)                                                                                \
+    attn_decode_wide_kernel<15, FORM, LEAN><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,   \
+                                                                     (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, \
+                                                                     bias, (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe)
+        // (FORM 1: synchronised through the completion words; 2 = JB_PIPE_NO_SYNC: the same kernel form as a launch of a plain chain)
+        if (pipe->slot >= 0) { if (lean) JB_LAUNCH_DECW_PIPE(1, true); else JB_LAUNCH_DECW_PIPE(1, false); }
+        else { if (lean) JB_LAUNCH_DECW_PIPE(2, true); else JB_LAUNCH_DECW_PIPE(2, false); }
+#undef JB_LAUNCH_DECW_PIPE
         JB_CHECK_LAUNCH();
         return JB_OK;
     }
     if (lean) {
-        attn_decode_wide_kernel<15, false, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
+        attn_decode_wide_kernel<15, 0, true><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,
                                                                           (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, bias,
                                                                           (f16*)x_out, ldo, width, block_ctx, t_dev, nopipe);
         JB_CHECK_LAUNCH();

@@ -170,9 +170,10 @@ __device__ __forceinline__ float jb_load_any(const void* p, int dtype, int64_t i
 // second ticket + flag store -- 1.71 vs 1.59 ms per step: a word that is being polled must be written once, by a store.
 struct JbPipe {
     unsigned* runs; unsigned* tickets; unsigned* err;
-    int slot, prev;                                  // slot >= 0: a synchronised launch of a pipelined step; JB_PIPE_NO_SYNC (-2): the
-                                                     // pipelined KERNEL FORM (operand-order blocks, 16-byte stores) as a launch of a
-                                                     // plain chain -- the kernel boundary orders it, no poll, no ticket; -1: the plain kernels
+    int slot, prev;                                  // slot >= 0: a synchronised launch of a pipelined step (kernels' PIPE = 1);
+                                                     // JB_PIPE_NO_SYNC (-2): the pipelined KERNEL FORM (operand-order blocks, 16-byte
+                                                     // stores) as a launch of a plain chain -- the kernel boundary orders it, no poll,
+                                                     // no ticket (PIPE = 2: own / wait / publish compiled out); -1: the plain kernels
     long long timeout;                               // poll bound in ticks of the 100 MHz clock (engine: 2 s, JB_PIPE_TIMEOUT_MS)
     long long* dbg;                                  // optional [slot][4] stamps of the 100 MHz clock (JB_PIPE_DEBUG): poll
                                                      // entered, producer seen, own completion published
@@ -238,14 +239,16 @@ __device__ __forceinline__ void jb_st_sc1(f16* base, int64_t el, f16 v) {
 }
 
 // Own completion count: every thread asks for it next to its first requests (a broadcast load).
-__device__ __forceinline__ unsigned jb_pipe_own(const JbPipe& P) { return P.slot >= 0 ? jb_ld_word(P.runs + P.slot * JB_PIPE_PAD) : 0u; }
+// (Unconditional and early.  Round 6 first gave the no-sync form of the kernels runtime guards: `slot >= 0 ? load : 0` compiled
+// to a branch whose body ends in s_waitcnt vmcnt(0) -- a dependent round trip in FRONT of the weight requests, 1.425 against
+// 1.397 ms per pipelined step, profiles/r06c8_ab_two_builds.log; the forms are template instantiations now: PIPE = 1 / 2.)
+__device__ __forceinline__ unsigned jb_pipe_own(const JbPipe& P) { return jb_ld_word(P.runs + P.slot * JB_PIPE_PAD); }
 // Wait for the producer launch; ends in a workgroup barrier.
 // poll_wave: the wave that polls (the others wait at the barrier).  A poll is a vector load and returns IN ORDER behind
 // everything its wave has requested before: a wave with a long prefetch outstanding (the attention's K / v' rows: 245 KB per
 // workgroup, longer than its head start) learns of the flags only when that has landed, so the attention polls from its last
 // wave, which owns a 16-key tile only at the latest positions.
 __device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own, int poll_wave = 0) {
-    if (P.slot < 0) return;                                        // (JB_PIPE_NO_SYNC: a kernel boundary has ordered the producer)
     const int pt = (int)threadIdx.x - poll_wave * 64;              // lane of the polling wave (other waves: outside 0..63)
     if (P.proto >= 1) {
         // Protocol 1: the last arriver of each of the 8 ticket shards stores the run's number into the shard's own flag word
@@ -299,7 +302,6 @@ __device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own, int 
 }
 // After the last store of every thread: drain the write-through stores, count the workgroup in, the last one publishes.
 __device__ __forceinline__ void jb_pipe_publish(const JbPipe& P, unsigned own) {
-    if (P.slot < 0) return;                                        // (JB_PIPE_NO_SYNC: the end of the kernel publishes)
     if (P.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) P.dbg[P.slot * JB_PIPE_STAMPS + 3] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     JB_SEG(P, 8);

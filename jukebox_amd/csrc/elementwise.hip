@@ -258,7 +258,7 @@ struct SampleTail {
 // PIPE: the last launch of a software-pipelined decode step (common.h, JbPipe): the logits are the producer launch's (read
 // write-through after the wait); the next position's embedding and the counter are read by the FIRST launch of the next
 // step, which is already waiting on the other stream: stored write-through, published at the end.
-template <bool PIPE>
+template <int PIPE>
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int bins, int n2,
                                                      const jb_sample_params* __restrict__ params,
                                                      int64_t* __restrict__ tokens, int64_t tok_stride,
@@ -271,10 +271,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     __shared__ int s_pick, s_owner;
     const int n = blockIdx.x, tid = threadIdx.x;
     unsigned pipe_own = 0;
-    if constexpr (PIPE) pipe_own = jb_pipe_own(pipe);
+    if constexpr (PIPE == 1) pipe_own = jb_pipe_own(pipe);
     const int t = *t_dev;                                    // written by this launch slot's previous run: same stream
     const jb_sample_params P = *params;
-    if constexpr (PIPE) jb_pipe_wait(pipe, pipe_own);
+    if constexpr (PIPE == 1) jb_pipe_wait(pipe, pipe_own);
     const float* row = logits + (int64_t)n * bins;
     float* pr = preds ? preds + (int64_t)n * preds_n_stride + (int64_t)t * bins : nullptr;
     for (int i = tid; i < bins; i += 256) {
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
             if constexpr (PIPE) jb_st_word(reinterpret_cast<unsigned*>(tail.t_dev_w), (unsigned)(t + 1)); else *tail.t_dev_w = t + 1;
         }
     }
-    if constexpr (PIPE) jb_pipe_publish(pipe, pipe_own);
+    if constexpr (PIPE == 1) jb_pipe_publish(pipe, pipe_own);
 }
 
 static int launch_sample(const float* logits, int n_batch, int bins, const jb_sample_params* params, int64_t* tokens,
@@ -446,10 +446,13 @@ static int launch_sample(const float* logits, int n_batch, int bins, const jb_sa
     if (pipe) {
         if (tail.x_dtype != JB_F16 || !tail.x_next) JB_UNSUPPORTED("a pipelined sampler launch takes the fp16 decode step's tail");
         if (pipe->slot >= 0 && pipe->proto >= 1 && n_batch < 8) JB_UNSUPPORTED("completion protocol 1 needs launches of >= 8 workgroups (>= 8 samples)");
-        sample_kernel<true><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds, preds_n_stride,
-                                                            tail, *pipe);
+        // (1: synchronised through the completion words; 2 = JB_PIPE_NO_SYNC: the same kernel form as a launch of a plain chain)
+        if (pipe->slot >= 0)
+            sample_kernel<1><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds, preds_n_stride, tail, *pipe);
+        else
+            sample_kernel<2><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds, preds_n_stride, tail, *pipe);
     } else {
-        sample_kernel<false><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds,
+        sample_kernel<0><<<n_batch, 256, lds, stream>>>(logits, bins, n2, params, tokens, tok_stride, t_dev, preds,
                                                              preds_n_stride, tail, JbPipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr});
     }
     JB_CHECK_LAUNCH();

@@ -706,7 +706,7 @@ extern "C" int jb_engine_probe_projection(void* handle, int t0, int n_steps, voi
             for (int l = 0; l < c.n_layers; ++l) {
                 const jb_layer& L = e->layers[l];
                 // (the kernel form the engine's own steps launch: operand-order blocks where it has them)
-                JbPipe pp{nullptr, nullptr, nullptr, JB_PIPE_NO_SYNC, -1, 0, nullptr, 0, 0};
+                JbPipe pp{c.pipe_words, nullptr, nullptr, JB_PIPE_NO_SYNC, -1, 0, nullptr, 0, 0};      // (runs: a valid word, read and ignored)
                 const bool frag = pipe_operand_order(e);
                 jb_gemv_args g;
                 fill_c_attn(g, c, L);

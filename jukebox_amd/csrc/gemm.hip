@@ -1229,7 +1229,7 @@ struct EpiOperands {
     }
 };
 
-template <typename T, int MT, int NW, bool LNS, bool FAST, int NV, bool PIPE = false>
+template <typename T, int MT, int NW, bool LNS, bool FAST, int NV, int PIPE = 0>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     static_assert(!PIPE || (!LNS && FAST), "pipelined launches: plain fast path only");
     using V = typename Frag<T>::vec;
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
 
     JB_STAMP(0);
     unsigned pipe_own = 0;
-    if constexpr (PIPE) pipe_own = jb_pipe_own(p.pipe);
+    if constexpr (PIPE == 1) pipe_own = jb_pipe_own(p.pipe);
     // ---- everything this workgroup needs from memory is requested here ----
     V wf[WB];
 #pragma unroll
@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     // i = (mt, r, l) is element r of fragment lane l of tile mt) and, on the plain fast path, the activation fragments of
     // the first (usually only) batch: everything is in flight before anything is waited for.
     constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);      // elements per thread
-    EpiOperands<T, EPT, NW * 64, PIPE> eo;
+    EpiOperands<T, EPT, NW * 64, (PIPE != 0)> eo;
     eo.request(p, jt, MT);
     V xf0[(!LNS && FAST) ? WB : 1][MT];
     if constexpr (!LNS && FAST && !PIPE) {
@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
         }
     }
     jb_issue_fence();
-    if constexpr (PIPE) jb_pipe_wait(p.pipe, pipe_own);     // the weights (and the epilogue operands of older launches) are in flight
+    if constexpr (PIPE == 1) jb_pipe_wait(p.pipe, pipe_own);     // the weights (and the epilogue operands of older launches) are in flight
     int t = 0;
     if (p.epi.qkv_split || p.epi.add2) t = PIPE ? (int)jb_ld_word(reinterpret_cast<const unsigned*>(p.t_dev)) : *p.t_dev;
     float e_add2[EPT];
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
     for (int u = 0; u < EPT; ++u) {
         const int i = threadIdx.x + u * NW * 64;
         int emt, er, el;
-        epi_coords<PIPE>(i, emt, er, el);
+        epi_coords<(PIPE != 0)>(i, emt, er, el);
         const int row = emt * 16 + (el & 15), j = jt * 16 + (el >> 4) * 4 + er;
         const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
         e_add2[u] = p.epi.add2 ? p.epi.add2[(int64_t)rc * p.epi.add2_n + (int64_t)t * p.epi.add2_t + jc] : 0.f;
@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
             const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
             pipe_store8<T>(p.epi, xo, xo + e_add2[0], row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J, (p.pipe.frag & JB_FRAG_OUT) != 0);
         }
-        jb_pipe_publish(p.pipe, pipe_own);
+        if constexpr (PIPE == 1) jb_pipe_publish(p.pipe, pipe_own);
         return;
     }
     {
@@ -1555,7 +1555,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
 // whose diagonal is sum(x^2) (f16 products are exact in the fp32 accumulator).  The per-wave partial sums join the
 // partial tiles in the single LDS exchange before the epilogue, where mean / rstd meet the accumulators.
 // A wave keeps all of its k-tiles' fragments in registers: needs ceil(nkt / NW) <= NF.
-template <typename T, int MT, int NW, int NF, bool PIPE = false>
+template <typename T, int MT, int NW, int NF, int PIPE = 0>
 __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     using V = typename Frag<T>::vec;
     constexpr int E = Frag<T>::E, KT = Frag<T>::KT;
@@ -1574,7 +1574,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     // ---- every request of this workgroup, issued back to back ----
     V xf[NF][MT];
     unsigned pipe_own = 0;
-    if constexpr (PIPE) pipe_own = jb_pipe_own(p.pipe);
+    if constexpr (PIPE == 1) pipe_own = jb_pipe_own(p.pipe);
     if constexpr (!PIPE) {
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
@@ -1589,12 +1589,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
     for (int i = 0; i < NF; ++i)
         wf[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(wbase + (int64_t)min(kt0 + i, p.nkt - 1) * (64 * E)));
     constexpr int EPT = (MT * 256 + NW * 64 - 1) / (NW * 64);
-    EpiOperands<T, EPT, NW * 64, PIPE> eo;     // bias, column sums c1, residual: in flight with the weights
+    EpiOperands<T, EPT, NW * 64, (PIPE != 0)> eo;     // bias, column sums c1, residual: in flight with the weights
     eo.request(p, jt, MT);
     jb_issue_fence();
     if constexpr (PIPE) {
-        // the weight stream is in flight; the rows are the producer launch's: wait for it, then read them write-through
-        jb_pipe_wait(p.pipe, pipe_own);
+        // the weight stream is in flight; the rows are the producer launch's: wait for it (PIPE = 2: the kernel boundary has),
+        // then read them write-through
+        if constexpr (PIPE == 1) jb_pipe_wait(p.pipe, pipe_own);
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int k0 = min(kt0 + i, p.nkt - 1) * KT + g * E;
@@ -1658,7 +1659,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_lnf_kernel(GemvParams p) {
             const float xo = epilogue_value<T>(p.epi, v, eo.bias[0], eo.res[0]);
             pipe_store8<T>(p.epi, xo, xo, row, j, jt * 16, cache_row, row < p.n_rows && j < p.epi.J, (p.pipe.frag & JB_FRAG_OUT) != 0);
         }
-        jb_pipe_publish(p.pipe, pipe_own);
+        if constexpr (PIPE == 1) jb_pipe_publish(p.pipe, pipe_own);
         return;
     }
 #pragma unroll
@@ -1962,13 +1963,19 @@ template <typename T, int MT, int NW>
 static int launch_gemv_lnf_nf(const GemvParams& p, int njt, int nf, hipStream_t s) {
     const size_t lds = (size_t)NW * MT * 64 * sizeof(f32x4) + (size_t)2 * NW * MT * 16 * sizeof(float);
     if (p.pipe.slot != -1) {
+        const bool sync = p.pipe.slot >= 0;          // (else JB_PIPE_NO_SYNC: the same kernel form as a launch of a plain chain)
         if constexpr (MT == 1 && NW == 8 && sizeof(T) == 2) {
-            if (nf == 8) { gemv_lnf_kernel<T, 1, 8, 8, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+            if (nf == 8) {
+                if (sync) gemv_lnf_kernel<T, 1, 8, 8, 1><<<njt, NW * 64, lds, s>>>(p);
+                else gemv_lnf_kernel<T, 1, 8, 8, 2><<<njt, NW * 64, lds, s>>>(p);
+                return JB_OK;
+            }
         }
         if constexpr (MT == 1 && NW == 16 && sizeof(T) == 2) {       // 129 .. 160 k-tiles (5b_lyrics: K = 4800)
-            if (nf == 10) { gemv_lnf_kernel<T, 1, 16, 10, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+            if (nf == 10 && sync) { gemv_lnf_kernel<T, 1, 16, 10, 1><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
         }
-        jb_set_error("jb_gemv: a pipelined launch of the folded-LayerNorm projection takes fp16, <= 16 rows, 33..64 or 129..160 k-tiles");
+        jb_set_error("jb_gemv: a pipelined launch of the folded-LayerNorm projection takes fp16, <= 16 rows, 33..64 or 129..160 k-tiles "
+                     "(the form without a hand-shake: 33..64)");
         return JB_ERR_UNSUPPORTED;
     }
     if (nf == 8) gemv_lnf_kernel<T, MT, NW, 8><<<njt, NW * 64, lds, s>>>(p);
@@ -1985,7 +1992,7 @@ static int launch_gemv_lnf(const GemvParams& p, int njt, int nf, int nw, hipStre
         if constexpr (sizeof(T) == 2) {
             if (g_gemv_long && p.nkt <= 160) {          // 8 waves x 4 batches of 5 k-tiles
                 const size_t lds = (size_t)8 * 64 * sizeof(f32x4) + (size_t)2 * 8 * 16 * sizeof(float);
-                if (p.pipe.slot != -1) gemv_long_kernel<T, 8, 5, 4, true, true><<<njt, 8 * 64, lds, s>>>(p);
+                if (p.pipe.slot >= 0) gemv_long_kernel<T, 8, 5, 4, true, true><<<njt, 8 * 64, lds, s>>>(p);
                 else gemv_long_kernel<T, 8, 5, 4, true, false><<<njt, 8 * 64, lds, s>>>(p);
                 return JB_OK;
             }
@@ -2017,7 +2024,10 @@ template <typename T, int MT, int NW, bool LNS>
 static int launch_gemv_inst(const GemvParams& p, int njt, size_t lds, hipStream_t s) {
     if (p.pipe.slot != -1) {
         if constexpr (MT == 1 && (NW == 8 || NW == 4) && !LNS) {
-            if (p.fast) { gemv_kernel<T, 1, NW, false, true, 0, true><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+            if (p.fast && p.pipe.slot >= 0) { gemv_kernel<T, 1, NW, false, true, 0, 1><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+            if constexpr (NW == 8) {      // JB_PIPE_NO_SYNC: the same kernel form as a launch of a plain chain
+                if (p.fast) { gemv_kernel<T, 1, 8, false, true, 0, 2><<<njt, NW * 64, lds, s>>>(p); return JB_OK; }
+            }
         }
         jb_set_error("jb_gemv: a pipelined launch of the plain projection takes <= 16 rows, >= 32 whole k-tiles, aligned operands");
         return JB_ERR_UNSUPPORTED;
@@ -2056,15 +2066,17 @@ static int launch_gemv(GemvParams& p, int njt, bool ln, hipStream_t s) {
         if constexpr (sizeof(T) == 2) {
             if (g_gemv_long) {                          // 8 waves x 4 batches of 5 k-tiles
                 const size_t lds = (size_t)8 * 64 * sizeof(f32x4);
-                if (p.pipe.slot != -1) gemv_long_kernel<T, 8, 5, 4, false, true><<<njt, 8 * 64, lds, s>>>(p);
+                if (p.pipe.slot >= 0) gemv_long_kernel<T, 8, 5, 4, false, true><<<njt, 8 * 64, lds, s>>>(p);
                 else gemv_long_kernel<T, 8, 5, 4, false, false><<<njt, 8 * 64, lds, s>>>(p);
                 return JB_OK;
             }
         }
         if (p.pipe.slot != -1) {
             if constexpr (sizeof(T) == 2) {
-                gemv_kernel<T, 1, 16, false, true, 0, true><<<njt, 16 * 64, (size_t)16 * 64 * sizeof(f32x4), s>>>(p);
-                return JB_OK;
+                if (p.pipe.slot >= 0) {
+                    gemv_kernel<T, 1, 16, false, true, 0, 1><<<njt, 16 * 64, (size_t)16 * 64 * sizeof(f32x4), s>>>(p);
+                    return JB_OK;
+                }
             }
             jb_set_error("jb_gemv: a pipelined launch of the 16-wave projection takes fp16");
             return JB_ERR_UNSUPPORTED;
@@ -2138,6 +2150,8 @@ int jb_gemv_impl(const jb_gemv_args* a, const JbPipe* pipe, void* stream) {
     // completion protocol 1 has a flag word per ticket shard (workgroup index mod 8): a launch of fewer than 8 workgroups would
     // leave flags that nobody writes, and every consumer would sit out its time-out on them
     JB_REQUIRE(!pipe || pipe->slot < 0 || pipe->proto < 1 || njt >= 8, "completion protocol 1 needs launches of >= 8 workgroups (J >= 128)");
+    JB_REQUIRE(!pipe || pipe->slot >= 0 || (pipe->slot == JB_PIPE_NO_SYNC && p.nkt >= 32 && p.nkt <= 128 && a->n_rows <= 16),
+               "the pipelined kernel form without its hand-shake (JB_PIPE_NO_SYNC) exists for the 8-wave projections: 32..128 k-tiles");
     p.dbg = nullptr;
 #ifdef JB_TIMING
     p.dbg = jb_dbg_ptr;

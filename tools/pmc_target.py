@@ -7,6 +7,24 @@ import sys
 import torch
 from jukebox_amd import hip_ops as H, _lib as L
 
+if "--engine" in sys.argv:
+    # round 6: the dominant kernel in the form the engine's own steps launch it (operand-order activation blocks, 16-byte
+    # write-through stores: gemv_lnf_kernel<..., true> without its hand-shake) -- a back-to-back burst of the c_attn / c_fc
+    # launches of all 72 layers of the upsampler engine at 16 samples, every launch on its own cold weights
+    # (jb_engine_probe_projection: what bench.py's roofline object times)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_engine import CFGS, random_state
+    from jukebox_amd.engine import PriorEngine
+    cfg = CFGS["up"]
+    dev = torch.device("cuda:0")
+    eng = PriorEngine(random_state(cfg, dev), "", n_batch=16, fp16=True, chunk_cap=64, **cfg)
+    eng.set_cond(torch.randn(16, cfg["seq_len"], cfg["width"], device=dev) * 0.01, torch.randn(16, 1, cfg["width"], device=dev) * 0.01)
+    eng.set_sampling(temp=0.99, seed=1)
+    us, launches, abytes = eng.probe_projection(4096, 2)
+    print("launches", launches, "algorithmic bytes per launch (mean)", abytes, "avg us", us)
+    sys.exit(0)
+
 dev = torch.device("cuda:0")
 N, W = 16, 1920
 x = torch.randn(N, W, device=dev, dtype=torch.float16)
