@@ -6,6 +6,7 @@
 // 288 GB the full-length cache lets every pattern be a closed-form index set over one array
 // (SURVEY.md Appendix B): a contiguous tail (dense / block / prev / prime) or a stride-block_ctx
 // gather (transpose).
+#include <type_traits>
 #include "common.h"
 
 // Keeps the compiler from sinking the memory requests written above this point below it (nothing waits here): the decode
@@ -172,10 +173,16 @@ __global__ void attn_decode_kernel(int func, const T* __restrict__ q, int64_t ld
 // are zeroed, which removes their products whatever the key registers hold.  Heads start at odd multiples of 4 bytes,
 // so the 16-byte loads are only dword-aligned (global memory takes that).
 typedef f16x8 __attribute__((aligned(4))) f16x8_a4;
-// PIPE: one launch of a software-pipelined chain (common.h, JbPipe; multi-head engines): the query and this position's k / v rows
-// are the producer launch's (c_attn), so the launch waits first and then reads the query and EVERY cache row write-through (sc1)
-// -- simpler than the wide kernel's split into earlier rows (plain, before the wait) and the new row; what pipelining hides here
-// is the launch itself.  The output leaves write-through, then the workgroup publishes.
+// PIPE: one launch of a software-pipelined chain (common.h, JbPipe; multi-head engines).  As in the wide kernel below, what does
+// not depend on the producer launch (c_attn) is asked for BEFORE the wait: the position (written by the previous step's sampler,
+// which every launch but a step's first has seen complete through its stream predecessor), hence the key set, and the K fragments
+// and value rows of a wave's FIRST tile with plain loads (rows of earlier positions: this launch's L1 is cold, L2 is coherent for
+// write-through stores).  Behind the wait: the query, and position t's own row -- where it is a key it is the last one -- re-read
+// write-through into the same registers; tiles beyond the first round (key sets of more than 16 keys per wave: the lyric
+// cross-attention) are read write-through inside the loop.  The output leaves as 16-byte write-through pieces (eight neighbours'
+// channels gathered in the vector ALU), then the workgroup publishes.  Round 6: the first form waited FIRST and read everything
+// behind the wait with 2-byte stores at the end -- 9.0 us per phase of the 5b_lyrics step, inputs seen -> stores issued 6.6
+// (profiles/r06c12_bench_engine_5b_stamps.log); same tiles per wave, same arithmetic: bit-identical.
 template <int ND32, bool RAGGED, bool PIPE = false>
 __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f16* __restrict__ q, int64_t ldq,
                                                                const f16* __restrict__ kc, const f16* __restrict__ vc, int cap,
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
                                                                const int* __restrict__ t_dev, int d_head, JbPipe pipe) {
     const int d = RAGGED ? d_head : ND32 * 32;
     unsigned pipe_own = 0;
-    if constexpr (PIPE) { pipe_own = jb_pipe_own(pipe); jb_pipe_wait(pipe, pipe_own); }
+    if constexpr (PIPE) pipe_own = jb_pipe_own(pipe);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
     float* s_ml = smem;                      // [nw][2]
@@ -202,10 +209,63 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     for (int dt = 0; dt < ND32; ++dt) {
         const int cb = dt * 32 + g * 8;
         foff[dt] = RAGGED ? min(cb, d - 8) : cb;
-        if constexpr (PIPE) qf[dt] = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + h * d + foff[dt]);
-        else qf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(qrow + foff[dt]) : ld_frag<f16>(qrow + cb);
+        if constexpr (!PIPE) qf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(qrow + foff[dt]) : ld_frag<f16>(qrow + cb);
     }
     jb_issue_fence();
+    // (PIPE: read past the scalar cache like every other pipelined kernel's position -- not dependent on which launch's
+    // dispatch-time invalidate happened to follow the sampler's write; BEFORE the wait: an attention launch is never a step's first)
+    const int t = PIPE ? (int)jb_ld_word(reinterpret_cast<const unsigned*>(t_dev)) : *t_dev;
+    const KeySet ks = decode_key_set(func, t, bc, cap);
+    f16* o = out + (int64_t)n * ldo + h * d;
+    const float scale = 1.0f / sqrtf(sqrtf((float)d));
+    const float scale2 = scale * scale;
+    const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
+    const f16* vbase = vc + ((int64_t)n * cap) * S + h * d;
+    const int64_t kv0 = ((int64_t)n * cap) * S + h * d;       // (PIPE: element offset of this (sample, head)'s rows in either cache)
+    const int c0 = min(lane * 8, d - 8);     // this lane's value channels (lanes past d/8 compute unused duplicates)
+    const int ntiles = (ks.count + 15) >> 4;
+
+    // ---- requests of tile tt: K fragments of key (kbase_i + c), value rows kbase_i + 0..15 (plain, or write-through) ----
+    auto request_tile = [&](f16x8 (&kf)[ND32], f16x8 (&vv)[16], int tt, auto sc1_tag) {
+        constexpr bool SC1 = decltype(sc1_tag)::value;
+        const int kbase_i = tt * 16;
+        const int ki = min(kbase_i + c, max(ks.count - 1, 0));
+        const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * S;
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) {
+            if constexpr (SC1) kf[dt] = jb_ld_frag_sc1<f16>(kc, kv0 + (int64_t)(ks.start + ki * ks.stride) * S + foff[dt]);
+            else kf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(kr + foff[dt]) : ld_frag<f16>(kr + dt * 32 + g * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int vi = min(kbase_i + k, max(ks.count - 1, 0));
+            const f16* vr = vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0;
+            if constexpr (SC1) vv[k] = jb_ld_frag_sc1<f16>(vc, kv0 + (int64_t)(ks.start + vi * ks.stride) * S + c0);
+            else vv[k] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(vr) : ld_frag<f16>(vr);
+        }
+    };
+    f16x8 kf0[PIPE ? ND32 : 1], vv0[PIPE ? 16 : 1];          // PIPE: the wave's first tile, in flight across the wait
+    if constexpr (PIPE) {
+        if (wave < ntiles) request_tile(kf0, vv0, wave, std::false_type{});
+        jb_issue_fence();
+        jb_pipe_wait(pipe, pipe_own, (int)(blockDim.x >> 6) - 1);      // (the last wave: it owns a tile only for the longest key sets)
+#pragma unroll
+        for (int dt = 0; dt < ND32; ++dt) qf[dt] = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + h * d + foff[dt]);
+        if (wave < ntiles) {
+            const int last_pos = ks.start + (ks.count - 1) * ks.stride;      // == t when the query's own position is a key
+            if (last_pos == t && wave == ntiles - 1) {                       // wave-uniform: the tile holds the producer's row
+                const int kbase_i = wave * 16;
+                const int64_t trow = kv0 + (int64_t)t * S;
+                if (min(kbase_i + c, ks.count - 1) == ks.count - 1) {
+#pragma unroll
+                    for (int dt = 0; dt < ND32; ++dt) kf0[dt] = jb_ld_frag_sc1<f16>(kc, trow + foff[dt]);
+                }
+                const f16x8 fv = jb_ld_frag_sc1<f16>(vc, trow + c0);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) vv0[k] = (kbase_i + k >= ks.count - 1) ? fv : vv0[k];
+            }
+        }
+    }
     if constexpr (RAGGED) {
 #pragma unroll
         for (int dt = 0; dt < ND32; ++dt) {
@@ -214,11 +274,6 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
             for (int e = 0; e < 8; ++e) qf[dt][e] = (cb < d && foff[dt] + e >= cb) ? qf[dt][e] : (f16)0;
         }
     }
-    // (PIPE: behind jb_pipe_wait, read past the scalar cache like every other pipelined kernel's position -- not dependent on
-    // which launch's dispatch-time invalidate happened to follow the sampler's write)
-    const int t = PIPE ? (int)jb_ld_word(reinterpret_cast<const unsigned*>(t_dev)) : *t_dev;
-    const KeySet ks = decode_key_set(func, t, bc, cap);
-    f16* o = out + (int64_t)n * ldo + h * d;
     if (ks.count == 0) {
         for (int i = threadIdx.x; i < d; i += blockDim.x) {
             if constexpr (PIPE) jb_st_sc1(out, (int64_t)n * ldo + h * d + i, (f16)0); else o[i] = (f16)0;
@@ -226,12 +281,6 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
         if constexpr (PIPE) jb_pipe_publish(pipe, pipe_own);
         return;
     }
-    const float scale = 1.0f / sqrtf(sqrtf((float)d));
-    const float scale2 = scale * scale;
-    const f16* kbase = kc + ((int64_t)n * cap) * S + h * d;
-    const f16* vbase = vc + ((int64_t)n * cap) * S + h * d;
-    const int64_t kv0 = ((int64_t)n * cap) * S + h * d;       // (PIPE: element offset of this (sample, head)'s rows in either cache)
-    const int c0 = min(lane * 8, d - 8);     // this lane's value channels (lanes past d/8 compute unused duplicates)
 
     float m_w = -INFINITY, l_w = 0.f;
     float of[8];
@@ -239,26 +288,7 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     for (int e = 0; e < 8; ++e) of[e] = 0.f;
     float* pw = s_pw + 16 * wave;
 
-    const int ntiles = (ks.count + 15) >> 4;
-    for (int tt = wave; tt < ntiles; tt += nw) {
-        const int kbase_i = tt * 16;
-        // ---- requests: K fragments of key (kbase_i + c), value rows kbase_i + 0..15 ----
-        const int ki = min(kbase_i + c, ks.count - 1);
-        const f16* kr = kbase + (int64_t)(ks.start + ki * ks.stride) * S;
-        f16x8 kf[ND32];
-#pragma unroll
-        for (int dt = 0; dt < ND32; ++dt) {
-            if constexpr (PIPE) kf[dt] = jb_ld_frag_sc1<f16>(kc, kv0 + (int64_t)(ks.start + ki * ks.stride) * S + foff[dt]);
-            else kf[dt] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(kr + foff[dt]) : ld_frag<f16>(kr + dt * 32 + g * 8);
-        }
-        f16x8 vv[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int vi = min(kbase_i + k, ks.count - 1);
-            const f16* vr = vbase + (int64_t)(ks.start + vi * ks.stride) * S + c0;
-            if constexpr (PIPE) vv[k] = jb_ld_frag_sc1<f16>(vc, kv0 + (int64_t)(ks.start + vi * ks.stride) * S + c0);
-            else vv[k] = RAGGED ? *reinterpret_cast<const f16x8_a4*>(vr) : ld_frag<f16>(vr);
-        }
+    auto tile_math = [&](const f16x8 (&kf)[ND32], const f16x8 (&vv)[16], int kbase_i) {
         jb_issue_fence_before_use(qf[0]);        // K fragments AND value rows are in flight before the QK^T chain starts
         // ---- scores of keys g*4 + r (identical in all 16 columns) ----
         f32x4 sc = {0.f, 0.f, 0.f, 0.f};
@@ -299,6 +329,20 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
 #pragma unroll
             for (int e = 0; e < 8; ++e) of[e] += pr * (float)vv[k][e];
         }
+    };
+    if constexpr (PIPE) {
+        if (wave < ntiles) tile_math(kf0, vv0, wave * 16);
+        for (int tt = wave + nw; tt < ntiles; tt += nw) {      // (more than 16 keys per wave: the lyric cross-attention)
+            f16x8 kf[ND32], vv[16];
+            request_tile(kf, vv, tt, std::true_type{});
+            tile_math(kf, vv, tt * 16);
+        }
+    } else {
+        for (int tt = wave; tt < ntiles; tt += nw) {
+            f16x8 kf[ND32], vv[16];
+            request_tile(kf, vv, tt, std::false_type{});
+            tile_math(kf, vv, tt * 16);
+        }
     }
     if (lane == 0) { s_ml[2 * wave] = m_w; s_ml[2 * wave + 1] = l_w; }
     if (lane * 8 < d) {      // RAGGED: the last writing lane starts at d - 8 and re-writes channels its neighbour holds too (same values)
@@ -311,12 +355,36 @@ __global__ __launch_bounds__(512) void attn_decode_mfma_kernel(int func, const f
     float lsum = 0.f;
     for (int w = 0; w < nw; ++w) lsum += s_ml[2 * w + 1] * expf(s_ml[2 * w] - m);
     const float inv = 1.0f / lsum;
+    if constexpr (PIPE) {
+        // every thread takes a channel (blockDim.x >= d; those past d a duplicate); eight neighbours' channels leave as ONE
+        // write-through store: lanes 1, 2, 3 of the thread's quad, then the next quad's (row_shl:4), all in the vector ALU; heads
+        // start at multiples of 4 bytes and the last piece of a ragged head is 4, 8 or 12 bytes
+        const int ch = min((int)threadIdx.x, d - 1);
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += s_o[w * d + ch] * expf(s_ml[2 * w] - m);
+        const float v0 = (float)(f16)(a * inv);
+        const float a1 = jb_dpp<0x55>(v0), a2 = jb_dpp<0xAA>(v0), a3 = jb_dpp<0xFF>(v0);
+        const float a4 = jb_dpp<0x104>(v0), a5 = jb_dpp<0x104>(a1), a6 = jb_dpp<0x104>(a2), a7 = jb_dpp<0x104>(a3);
+        if ((int)threadIdx.x < d && (threadIdx.x & 7) == 0) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            const f16x8 o8 = {(f16)v0, (f16)a1, (f16)a2, (f16)a3, (f16)a4, (f16)a5, (f16)a6, (f16)a7};
+            const u32x4 w4 = __builtin_bit_cast(u32x4, o8);
+            const int off = (int)(((int64_t)n * ldo + h * d + (int)threadIdx.x) * 2), left = d - (int)threadIdx.x;
+            if (left >= 8) __builtin_amdgcn_raw_buffer_store_b128(w4, jb_rsrc(out), off, 0, 16);
+            else if (left >= 6) __builtin_amdgcn_raw_buffer_store_b96(u32x3{w4[0], w4[1], w4[2]}, jb_rsrc(out), off, 0, 16);
+            else if (left >= 4) __builtin_amdgcn_raw_buffer_store_b64(u32x2{w4[0], w4[1]}, jb_rsrc(out), off, 0, 16);
+            else __builtin_amdgcn_raw_buffer_store_b32(w4[0], jb_rsrc(out), off, 0, 16);
+        }
+        jb_pipe_publish(pipe, pipe_own);
+        return;
+    }
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
         float a = 0.f;
         for (int w = 0; w < nw; ++w) a += s_o[w * d + i] * expf(s_ml[2 * w] - m);
-        if constexpr (PIPE) jb_st_sc1(out, (int64_t)n * ldo + h * d + i, (f16)(a * inv)); else o[i] = (f16)(a * inv);
+        o[i] = (f16)(a * inv);
     }
-    if constexpr (PIPE) jb_pipe_publish(pipe, pipe_own);
 }
 
 // Wide-value variant for single-head layers (the upsamplers): the cache row of a key holds v' = v·Wp (W channels), the

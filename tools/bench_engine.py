@@ -62,9 +62,10 @@ def report_stamps(eng, indent="    "):
     st = eng.pipe_stamps().astype(np.float64) * 0.01          # us: poll entered, producer seen, published (last workgroup), stores issued
     n = st.shape[0]
     entered, seen, published, issued = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
-    kinds = ["c_attn", "attention", "c_fc", "c_proj"]
-    for k in range(4):
-        idx = np.arange(8 + k, n - 3, 4)
+    per = getattr(eng, "_launches_per_layer", 4)
+    kinds = ["c_attn", "attention", "c_fc", "c_proj"] if per == 4 else ["c_attn", "attention", "attn.c_proj", "c_fc", "mlp.c_proj"]
+    for k in range(per):
+        idx = np.arange(2 * per + k, n - 3, per)
         print(f"{indent}{kinds[k]:10s} consumer sees it - it saw its producer {np.mean(seen[idx + 1] - seen[idx]):6.2f} us = inputs seen -> "
               f"stores issued {np.mean(issued[idx] - seen[idx]):5.2f} + drain, tickets {np.mean(published[idx] - issued[idx]):5.2f} + "
               f"propagation {np.mean(seen[idx + 1] - published[idx]):5.2f} | poll entered {np.mean(seen[idx] - entered[idx]):5.2f} before the "
@@ -110,6 +111,7 @@ def main():
     if a.pipelined >= 0:
         eng.set_pipelined(bool(a.pipelined))
     torch.cuda.synchronize()
+    eng._launches_per_layer = (eng.launches_per_step - 2) // cfg["depth"]
     print(f"model={a.model} N={a.batch} dtype={'f32' if a.fp32 else 'f16'} weights={eng.weight_bytes() / 1e9:.2f} GB "
           f"kv={eng.cache_bytes() / 1e9:.2f} GB launches/step={eng.launches_per_step} pipelined={eng.pipelined}")
     noise = []
