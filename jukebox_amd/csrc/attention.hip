@@ -435,11 +435,19 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     const float bias_e = bias[och];
     // (PIPE with operand-order hand-offs, common.h: the residual stream in and out is [k-tile][lane][8], 16 rows per block)
     const bool frag_res = PIPE != 0 && (pipe.frag & JB_FRAG_RES), frag_out = PIPE != 0 && (pipe.frag & JB_FRAG_OUT);
-    const f16 res_e = res[frag_res ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldr + och];
+    const int64_t res_el = frag_res ? (int64_t)jb_frag_el(n, och) : (int64_t)n * ldr + och;
+    // (a synchronised launch reads the residual rows -- two launches old -- behind the wait, write-through: in the three-stream
+    // form of the step, engine.hip, their producer is not this stream's predecessor)
+    f16 res_e = PIPE == 1 ? (f16)0 : res[res_el];
     jb_issue_fence();
-    // PIPE: the position was written by the previous step's last launch, which this stream has already seen complete
-    // (an attention launch is never the first of a step): the key set is known before the wait.
-    const int t = *t_dev;
+    // PIPE: the position was written by the previous step's sampler.  An attention launch is never the first of a step, and in
+    // the two-stream form its stream has seen that launch complete; the attention stream of the three-stream form runs AHEAD of
+    // the sampler at the start of a step: its first launch waits for the previous step's last slot first (JB_PIPE_PRE_WAIT).
+    // Read past the scalar cache either way; the key set is known before the wait for the producer.
+    if constexpr (PIPE == 1) {
+        if (pipe.frag & JB_PIPE_PRE_WAIT) jb_pipe_wait_previous_step(pipe, pipe_own, (int)(blockDim.x >> 6) - 1);
+    }
+    const int t = PIPE == 1 ? (int)jb_ld_word(reinterpret_cast<const unsigned*>(t_dev)) : *t_dev;
     const KeySet ks = decode_key_set(func, t, bc, cap);
     f16* o = out + (int64_t)n * ldo;
     const float scale = 1.0f / sqrtf(sqrtf((float)d));
@@ -518,6 +526,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
         }
         jb_issue_fence();
         if constexpr (PIPE == 1) jb_pipe_wait(pipe, pipe_own, (int)(blockDim.x >> 6) - 1);      // (the last wave: usually nothing of its own in flight)
+        if constexpr (PIPE == 1) res_e = jb_ld_sc1(res, res_el);
         if constexpr (QL) {
             if (lane * 8 < d) *reinterpret_cast<f16x8*>(s_q + lane * 8) = jb_ld_frag_sc1<f16>(q, (int64_t)n * ldq + lane * 8);
         } else {

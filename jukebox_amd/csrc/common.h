@@ -179,6 +179,7 @@ struct JbPipe {
                                                      // entered, producer seen, own completion published
     int proto;                                       // completion protocol: 0 = two-level ticket + one flag, 1 = a flag word per shard
     int frag;                                        // JB_FRAG_*: which activation blocks of this launch are in OPERAND ORDER (below)
+    int last;                                        // the step's last slot (JB_PIPE_PRE_WAIT)
 };
 // Activation blocks of <= 16 rows handed from one pipelined launch to the next may be laid out in the order the consumer's MFMA
 // B operands want them -- [k-tile][lane = (channel / 8 mod 4) * 16 + row][8 channels], 1 KiB per k-tile -- instead of [row][channel]:
@@ -186,6 +187,10 @@ struct JbPipe {
 // lines 2 * width bytes apart, and a producer workgroup's 16 x 16 tile leaves as 2 runs of 256 bytes instead of 16 runs of 32.
 // The block always holds 16 rows (engines of fewer samples leave the others untouched).
 constexpr int JB_FRAG_X = 1, JB_FRAG_OUT = 2, JB_FRAG_RES = 4;
+// JbPipe.frag also carries: this launch is the first of its STREAM in a step and that stream's previous launch ran before the
+// previous step's sampler (the attention stream of the three-stream form, engine.hip): wait for the previous step's last slot
+// (JbPipe.timeout's neighbour `last`) before the position is read.
+constexpr int JB_PIPE_PRE_WAIT = 8;
 __host__ __device__ __forceinline__ int jb_frag_el(int row, int col) {      // element index of (row, channel) in operand order
     return (col >> 5) * 512 + ((((col >> 3) & 3) << 4) + row) * 8 + (col & 7);
 }
@@ -299,6 +304,12 @@ __device__ __forceinline__ void jb_pipe_wait(const JbPipe& P, unsigned own, int 
     }
     __syncthreads();
     JB_SEG(P, 4);
+}
+// JB_PIPE_PRE_WAIT: until the PREVIOUS step's last launch has completed (as slot 0 waits for it: `own` completions).
+__device__ __forceinline__ void jb_pipe_wait_previous_step(const JbPipe& P, unsigned own, int poll_wave = 0) {
+    JbPipe Q = P;
+    Q.slot = 0; Q.prev = P.last; Q.dbg = nullptr;
+    jb_pipe_wait(Q, own, poll_wave);
 }
 // After the last store of every thread: drain the write-through stores, count the workgroup in, the last one publishes.
 __device__ __forceinline__ void jb_pipe_publish(const JbPipe& P, unsigned own) {

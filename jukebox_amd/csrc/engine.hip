@@ -40,16 +40,20 @@ struct JbEngine {
     bool pipelined = false;
     bool operand_order = false;             // activation blocks of the decode step in operand order (decided at creation: the
                                             // captured graphs and the embedding of a call's first position must agree)
-    hipStream_t pstream[2] = {nullptr, nullptr};                   // the engine's own pair (setup_pipeline_streams)
-    hipGraph_t pgraph[2] = {nullptr, nullptr};
-    hipGraphExec_t pexec[2] = {nullptr, nullptr};
+    hipStream_t pstream[3] = {nullptr, nullptr, nullptr};          // the engine's own pair / triple (setup_pipeline_streams)
+    hipGraph_t pgraph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t pexec[3] = {nullptr, nullptr, nullptr};
+    int n_pstreams = 2;                     // 3: the attention launches on a stream of their own (pipe_streams)
 };
 
 // Hand-off form of the decode step, read when an engine is CREATED (jb_tune_pipeline): activation blocks
 // between the launches in MFMA operand order (common.h: JB_FRAG_*; single-head engines whose decode buffers hold 16 rows,
 // jb_engine_cfg.act_rows) or as [row][channel].
 static int g_pipe_frag = 1;
-extern "C" void jb_tune_pipeline(int operand_order) { g_pipe_frag = operand_order ? 1 : 0; }
+// bit 1 (value 2): the two-stream form of the pipelined step for engines that would run the three-stream form (read when the
+// streams are made: A/B measurements, tests)
+static int g_pipe_two_streams = 0;
+extern "C" void jb_tune_pipeline(int operand_order) { g_pipe_frag = (operand_order & 1) ? 1 : 0; g_pipe_two_streams = (operand_order >> 1) & 1; }
 
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 // [row][channel] -> operand order (common.h: jb_frag_el), n rows of `width` halves; rows n..15 of dst are left alone
@@ -120,13 +124,13 @@ extern "C" int jb_engine_create(const jb_engine_cfg* cfg, const jb_layer* layers
 // upper levels of every job after a process's first ran 3.8x / 1.8x slower), so nothing of it may outlive the phase that
 // uses it.  The pair is idle whenever no jb_engine_decode is in progress (a pipelined decode is host-synchronous).
 static void release_pipeline(JbEngine* e) {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         if (e->pstream[k]) (void)hipStreamSynchronize(e->pstream[k]);
         if (e->pexec[k]) (void)hipGraphExecDestroy(e->pexec[k]);
         if (e->pgraph[k]) (void)hipGraphDestroy(e->pgraph[k]);
         e->pexec[k] = nullptr; e->pgraph[k] = nullptr;
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         if (e->pstream[k]) (void)hipStreamDestroy(e->pstream[k]);
         e->pstream[k] = nullptr;
     }
@@ -255,6 +259,15 @@ static bool decide_operand_order(const JbEngine* e) {
 // read on the device.  Leaves the next position's embedding in x_a and *t_dev advanced.
 // parity < 0: every launch on `s` (the plain chain).  parity 0 / 1: software-pipelined step -- only the even / odd launches
 // are enqueued (on `s`), each with its completion slot; the other half goes to the other stream by a second call.
+// Three-stream form (e->n_pstreams == 3: single-head engines on wide-value layers, pipe_streams): the launches go to streams BY
+// KIND -- 0: c_attn, c_fc, the logits head; 1: mlp.c_proj, the sampler; 2: the attention -- and `parity` names the stream.  An
+// attention launch is then dispatched when the PREVIOUS layer's attention has finished, four phases ahead of its flags instead
+// of one: its K / v' rows of earlier positions (up to 245 KB per workgroup through one compute unit's memory pipe: the decode
+// step grew from 1.33 ms at position 64 to 1.49 ms at 7900 with the key count of the strided layers,
+// profiles/r06c20_step_vs_position.log) have landed when the query arrives.  What the kernels assumed of a two-stream step is
+// restated there: residual rows (two launches old) are read behind the wait, write-through; the attention stream's first launch
+// of a step waits for the previous step's last slot before it reads the position (JB_PIPE_PRE_WAIT).
+enum { K_C_ATTN = 0, K_ATTENTION, K_ATTN_PROJ, K_C_FC, K_MLP_PROJ, K_LOGITS, K_SAMPLE, K_PAD };
 static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
     const jb_engine_cfg& c = e->cfg;
     const int N = c.n_batch, W = c.width, S = c.n_state, M = c.n_mlp, H = c.n_head, d = S / H;
@@ -267,18 +280,22 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
               c.pipe_words ? c.pipe_words + jb_pipe_words(n_slots) - JB_PIPE_PAD : nullptr, 0, 0,
               (getenv("JB_PIPE_TIMEOUT_MS") ? atoll(getenv("JB_PIPE_TIMEOUT_MS")) : 2000ll) * 100000ll,
               (c.pipe_words && getenv("JB_PIPE_DEBUG")) ? reinterpret_cast<long long*>(c.pipe_words + jb_pipe_words(n_slots)) : nullptr,
-              c.n_batch >= 8 ? 1 : 0, 0};
+              c.n_batch >= 8 ? 1 : 0, 0, n_slots - 1};
     const bool frag = pipe_operand_order(e);
+    const bool by_kind = parity >= 0 && e->n_pstreams == 3;
+    static const int stream_of_kind[] = {0, 2, 1, 0, 1, 0, 1, 0};
+    bool attention_seen = false;
     if (parity < 0) pp.dbg = nullptr;          // (stamps are per completion slot)
     // the pipeline slot of the next launch -- for the plain chain NULL (the plain kernels), or, for an engine on operand-order
     // blocks, the pipelined kernel form without its hand-shake (JB_PIPE_NO_SYNC); `mine`: this call enqueues it; `layout`: which
     // of the launch's activation blocks (JB_FRAG_X operand, JB_FRAG_OUT output, JB_FRAG_RES residual) are in operand order
     bool mine = true;
-    auto next = [&](int layout = 0) -> const JbPipe* {
-        mine = parity < 0 || (slot & 1) == parity;
+    auto next = [&](int kind, int layout = 0) -> const JbPipe* {
+        mine = parity < 0 || (by_kind ? stream_of_kind[kind] : (slot & 1)) == parity;
         pp.slot = parity < 0 ? JB_PIPE_NO_SYNC : slot;
         pp.prev = slot == 0 ? n_slots - 1 : slot - 1;
         pp.frag = frag ? layout : 0;
+        if (by_kind && kind == K_ATTENTION && !attention_seen) { pp.frag |= JB_PIPE_PRE_WAIT; attention_seen = true; }
         ++slot;
         return (parity < 0 && !frag) ? nullptr : &pp;
     };
@@ -287,7 +304,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
         jb_gemv_args g;
         // a7/a8/a9: ln_0 + c_attn, k/v appended at *t_dev
         fill_c_attn(g, c, L);
-        { const JbPipe* pipe = next(JB_FRAG_X); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }      // (q and the cache rows stay [row][channel])
+        { const JbPipe* pipe = next(K_C_ATTN, JB_FRAG_X); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }      // (q and the cache rows stay [row][channel])
         // attention, then attn.c_proj + residual: x_b = x_a + a
         const int parts = layer_split_parts(c, L);
         g = {};
@@ -295,7 +312,7 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
         g.dtype = c.dtype; g.ldx = S; g.n_rows = N; g.W = L.w_proj; g.bias = L.b_proj; g.K = S; g.J = W;
         g.out = c.x_b; g.ldo = W; g.res = c.x_a; g.ldr = W;
         if (layer_wide(c, L)) {
-            const JbPipe* pipe = next(JB_FRAG_RES | JB_FRAG_OUT);
+            const JbPipe* pipe = next(K_ATTENTION, JB_FRAG_RES | JB_FRAG_OUT);
             if (mine) JB_TRY(jb_attn_decode_wide_impl(L.attn_func, c.q, S, L.kcache, L.vcache_w, L.cache_cap, c.x_a, W, L.b_proj, c.x_b,
                                                       W, N, S, W, c.block_ctx, c.t_dev, c.seq_len, pipe, s));
         } else if (parts > 0) {
@@ -303,25 +320,25 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
                 jb_set_error("jb_engine: the key-split attention has no pipelined form");
                 return JB_ERR_UNSUPPORTED;
             }
-            (void)next();
+            (void)next(K_ATTENTION);
             JB_TRY(jb_attn_decode_split(L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att_parts, c.att_ml, N, H, d,
                                         c.block_ctx, c.t_dev, layer_max_keys(c, L), parts, s));
             g.x_parts = c.att_parts; g.x_ml = c.att_ml; g.n_parts = parts; g.n_head = H; g.d_head = d;
         } else {
             // multi-head layers: attention into c.att (pitch att_ld, pad columns stay zero), then attn.c_proj + residual
-            const JbPipe* pipe = next();
+            const JbPipe* pipe = next(K_ATTENTION);
             if (mine) JB_TRY(jb_attn_decode_impl(c.dtype, L.attn_func, c.q, S, L.kcache, L.vcache, L.cache_cap, c.att, att_ld, N, H, d,
                                                  c.block_ctx, c.t_dev, c.seq_len, pipe, s));
             g.x = c.att; g.ldx = att_ld;
             const int KT = c.dtype == JB_F16 ? 32 : 16;
             if (att_ld % KT == 0 && att_ld - S < KT) g.K = att_ld;
         }
-        if (!layer_wide(c, L)) { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
+        if (!layer_wide(c, L)) { const JbPipe* pipe = next(K_ATTN_PROJ); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
         // ln_1 + mlp.c_fc + quick_gelu
         g = {};
         fill_ln_proj(g, c, L, 1);
         g.x = c.x_b; g.J = M; g.out = c.mlp; g.ldo = M; g.act = JB_ACT_QUICK_GELU;
-        { const JbPipe* pipe = next(JB_FRAG_X | JB_FRAG_OUT); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
+        { const JbPipe* pipe = next(K_C_FC, JB_FRAG_X | JB_FRAG_OUT); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
         // mlp.c_proj + residual: x_a = x_b + m   (h = x + a + m, transformer.py:82-83); the last layer also hands the
         // logits head xf = float(x_a) (+ cond[t], autoregressive.py:226-227)
         g = {};
@@ -331,20 +348,20 @@ static int enqueue_step(JbEngine* e, hipStream_t s, int parity = -1) {
             g.out2 = c.xf; g.ldo2 = W; g.t_dev = c.t_dev;
             if (c.add_cond_after && c.x_cond) { g.add2 = c.x_cond; g.add2_n_stride = c.xc_n_stride; g.add2_t_stride = c.xc_t_stride; }
         }
-        { const JbPipe* pipe = next(JB_FRAG_X | JB_FRAG_RES | JB_FRAG_OUT); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }   // (xf stays fp32 [row][channel])
+        { const JbPipe* pipe = next(K_MLP_PROJ, JB_FRAG_X | JB_FRAG_RES | JB_FRAG_OUT); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }   // (xf stays fp32 [row][channel])
     }
     jb_gemv_args g = {};
     g.dtype = JB_F32; g.x = c.xf; g.ldx = W; g.n_rows = N; g.W = c.x_out_packed; g.K = W; g.J = c.bins;
     g.out = c.logits; g.ldo = c.bins;
-    { const JbPipe* pipe = next(); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
+    { const JbPipe* pipe = next(K_LOGITS); if (mine) JB_TRY(jb_gemv_impl(&g, pipe, s)); }
     {
-        const JbPipe* pipe = next(JB_FRAG_OUT);
+        const JbPipe* pipe = next(K_SAMPLE, JB_FRAG_OUT);
         if (mine) JB_TRY(jb_sample_step_impl(c.logits, N, c.bins, c.sample_params, c.tokens, c.tok_stride, c.t_dev, c.preds,
                                              c.preds_n_stride, c.dtype, c.x_a, c.x_emb, c.pos_emb, c.x_cond, c.xc_n_stride,
                                              c.xc_t_stride, W, c.seq_len, c.ticket, pipe, s));
     }
     if (slot < n_slots) {                      // an odd number of launches: the pad launch makes the step's slots even (pipe_slots)
-        const JbPipe* pipe = next();
+        const JbPipe* pipe = next(K_PAD);
         if (pipe && mine) {
             pipe_pad_kernel<<<8, 64, 0, s>>>(*pipe);
             JB_CHECK_LAUNCH();
@@ -454,6 +471,10 @@ static int streams_overlap(hipStream_t a, hipStream_t b, unsigned* scratch /* de
 // with that mask: two masks that differ (each all compute units but one) are two queues of their own.  The
 // pair is still verified with the handshake above.  The caller's stream never waits on them: a pipelined decode drains the
 // caller's stream, runs on the pair and returns when the pair is done (decode_pipelined).
+// 3 where the step is four launches per layer on a single head (wide-value layers throughout: the 1b upsamplers), else 2.
+static int pipe_streams(const JbEngine* e) {
+    return (!g_pipe_two_streams && !pipeline_eligible_multi_head(e) && pipeline_eligible(e) && !getenv("JB_PIPE_TWO_STREAMS")) ? 3 : 2;
+}
 static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mutex
     unsigned* scratch = e->cfg.pipe_words + jb_pipe_words(pipe_slots(e)) - JB_PIPE_PAD + 8;
     // every pair of the process gets two masks nobody else has (each leaves out ONE compute unit): should the runtime key
@@ -468,31 +489,47 @@ static int setup_pipeline_streams(JbEngine* e) {       // caller holds g_pipe_mu
     JB_REQUIRE(n_cu >= 8 && n_cu <= 1024, "unexpected compute-unit count");
     const int usable = n_cu;
     std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32);
-    for (int k = 0; k < 2; ++k) {
+    e->n_pstreams = pipe_streams(e);
+    // Three streams: the attention launches own the LAST 72 of 256 compute units (mask bit i is compute unit i / 8 of XCD i mod 8:
+    // nine per XCD), the projections' two streams the first 184.  An attention workgroup (8 waves at ~200 registers) needs an
+    // EMPTY compute unit, and with the attention dispatched four phases ahead the two parked projection launches (120 + 120
+    // workgroups, one per unit) left it 16: the first 16 workgroups ran, the rest were never placed and the parked launches
+    // waited for them -- every wait of the step timed out (profiles/r06c22_three_streams_first_run.log).  180 projection
+    // workgroups still get a unit each.
+    const int att_lo = e->n_pstreams == 3 ? usable - (usable * 72 + 255) / 256 : 0;
+    for (int k = 0; k < e->n_pstreams; ++k) {
         std::fill(mask.begin(), mask.end(), 0u);
-        for (int b = 0; b < usable; ++b) mask[b >> 5] |= 1u << (b & 31);
-        const int bit = usable - 1 - (2 * pair + k) % usable;
+        const int lo = (e->n_pstreams == 3 && k == 2) ? att_lo : 0, hi = (e->n_pstreams == 3 && k < 2) ? att_lo : usable;
+        for (int b = lo; b < hi; ++b) mask[b >> 5] |= 1u << (b & 31);
+        // the unit a mask leaves out (masks differ: should the runtime key hardware queues by mask).  Two streams: another one for
+        // every pair of the process.  Three streams: FIXED ones -- workgroup b runs on XCD b mod 8, the 180 workgroups of the wide
+        // c_attn are 23 on each of XCDs 0..3 and 22 on XCDs 4..7, and the projections' region has 23 units per XCD: a unit taken
+        // from XCD 0..3 makes one workgroup of every c_attn wait for a slot (with the masks of the THIRD triple of a process the
+        // step went from 1.37 to 1.83 ms: profiles/r06c24_recreate.log), so the projections give up units of XCDs 7 and 6
+        const int bit = e->n_pstreams == 3 ? (k == 0 ? att_lo - 1 : (k == 1 ? att_lo - 2 : usable - 3)) : hi - 1 - (2 * pair + k) % (hi - lo);
         mask[bit >> 5] &= ~(1u << (bit & 31));
         JB_HIP(hipExtStreamCreateWithCUMask(&e->pstream[k], (uint32_t)mask.size(), mask.data()));
     }
-    const int ov = streams_overlap(e->pstream[0], e->pstream[1], scratch);
+    int ov = 1;
+    for (int a = 0; a < e->n_pstreams && ov == 1; ++a)
+        for (int b = a + 1; b < e->n_pstreams && ov == 1; ++b) ov = streams_overlap(e->pstream[a], e->pstream[b], scratch);
     if (ov != 1) {
-        for (int k = 0; k < 2; ++k) { (void)hipStreamDestroy(e->pstream[k]); e->pstream[k] = nullptr; }
+        for (int k = 0; k < 3; ++k) { if (e->pstream[k]) (void)hipStreamDestroy(e->pstream[k]); e->pstream[k] = nullptr; }
         if (ov < 0) return ov;
-        JB_UNSUPPORTED("the two streams of the pipelined launches share a hardware queue");
+        JB_UNSUPPORTED("the streams of the pipelined launches share a hardware queue");
     }
     return JB_OK;
 }
 
 // The engine's pair of streams and its two parity graphs (once).
 static int prepare_pipeline(JbEngine* e) {
-    if (e->pstream[0] && e->pexec[0] && e->pexec[1]) return JB_OK;
+    if (e->pstream[0] && e->pexec[0] && e->pexec[1] && (e->n_pstreams < 3 || e->pexec[2])) return JB_OK;
     // one engine at a time: the handshake synchronises, and another thread's synchronous calls must not fall into this
     // thread's capture
     std::lock_guard<std::mutex> lock(g_pipe_mutex);
     if (!e->pstream[0]) JB_TRY(setup_pipeline_streams(e));
     if (!e->capture_stream) JB_HIP(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < e->n_pstreams; ++k) {
         if (e->pexec[k]) continue;
         JB_HIP(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
         const int rc = enqueue_step(e, e->capture_stream, k);
@@ -520,11 +557,11 @@ static int decode_pipelined(JbEngine* e, int n_steps, hipStream_t s, bool use_gr
     JB_HIP(hipMemsetAsync(e->cfg.pipe_words, 0, (jb_pipe_words(n_slots) - JB_PIPE_PAD) * sizeof(unsigned), s));
     JB_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < n_steps; ++i)
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < e->n_pstreams; ++k) {
             if (use_graph) JB_HIP(hipGraphLaunch(e->pexec[k], e->pstream[k]));
             else JB_TRY(enqueue_step(e, e->pstream[k], k));        // diagnostics: the same launches without the graph executor
         }
-    for (int k = 0; k < 2; ++k) JB_HIP(hipStreamSynchronize(e->pstream[k]));
+    for (int k = 0; k < e->n_pstreams; ++k) JB_HIP(hipStreamSynchronize(e->pstream[k]));
     return JB_OK;
 }
 

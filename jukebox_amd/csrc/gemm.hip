@@ -1219,6 +1219,17 @@ struct EpiOperands {
         }
         (void)jt; (void)MT;
     }
+    // the residual of this thread's element again, write-through (EPT = 1: the pipelined forms)
+    __device__ __forceinline__ void request_res_sc1(const GemvParams& p) {
+        static_assert(EPT == 1 || !ALT, "pipelined forms hold one element per thread");
+        const T* res_p = p.epi.res ? (const T*)p.epi.res : reinterpret_cast<const T*>(p.W);
+        const int64_t ldr = p.epi.res ? p.epi.ldr : 0;
+        int emt, er, el;
+        epi_coords<ALT>(threadIdx.x, emt, er, el);
+        const int row = emt * 16 + (el & 15), j = blockIdx.x * 16 + (el >> 4) * 4 + er;
+        const int jc = min(j, p.epi.J - 1), rc = min(row, p.n_rows - 1);
+        res[0] = (float)jb_ld_sc1(res_p, ((p.pipe.frag & JB_FRAG_RES) && p.epi.res) ? (int64_t)jb_frag_el(rc, jc) : (int64_t)rc * ldr + jc);
+    }
     __device__ __forceinline__ void finish(const GemvParams& p) {      // after the sums are ready: drop what was not there
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
@@ -1278,7 +1289,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvParams p) {
         }
     }
     jb_issue_fence();
-    if constexpr (PIPE == 1) jb_pipe_wait(p.pipe, pipe_own);     // the weights (and the epilogue operands of older launches) are in flight
+    if constexpr (PIPE == 1) {
+        jb_pipe_wait(p.pipe, pipe_own);     // the weights and the constant epilogue operands are in flight
+        // the residual rows are two launches old: behind the wait and write-through (in the three-stream form of the step,
+        // engine.hip, their producer -- the attention -- is not this stream's predecessor)
+        eo.request_res_sc1(p);
+    }
     int t = 0;
     if (p.epi.qkv_split || p.epi.add2) t = PIPE ? (int)jb_ld_word(reinterpret_cast<const unsigned*>(p.t_dev)) : *p.t_dev;
     float e_add2[EPT];

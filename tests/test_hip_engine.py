@@ -244,13 +244,16 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, hea
     # "classic": the plain chain on the plain kernels and [row][channel] blocks (jb_tune_pipeline(0)); "chain": the plain chain as
     # single-head engines run it since round 6 -- the pipelined kernel forms on operand-order blocks, the kernel boundary as the
     # hand-shake --; "pipelined": the same kernels synchronised through their completion words
-    for mode in ("classic", "chain", "pipelined"):
-        L.lib().jb_tune_pipeline(0 if mode == "classic" else 1)          # (read when the engine is created)
-        monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1" if mode == "pipelined" else "0")
+    # "pipelined2": single-head engines run the step on THREE streams (the attention launches on one of their own, dispatched four
+    # phases ahead); jb_tune_pipeline(3) keeps them on the two-stream form, which multi-head engines run anyway
+    modes = ("classic", "chain", "pipelined") + (("pipelined2",) if heads == 1 else ())
+    for mode in modes:
+        L.lib().jb_tune_pipeline(0 if mode == "classic" else (3 if mode == "pipelined2" else 1))          # (read when the engine is created / its streams are made)
+        monkeypatch.setenv("JB_PIPELINE_LAUNCHES", "1" if mode.startswith("pipelined") else "0")
         eng = PE(sd, "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=heads, attn_order=2, blocks=blocks,
                  y_cond=False, fp16=True, want_preds=True, chunk_cap=64)
         eng.set_cond(xc, None)
-        assert eng.pipelined == (mode == "pipelined") and eng.launches_per_step == (4 if heads == 1 else 5) * depth + 2
+        assert eng.pipelined == mode.startswith("pipelined") and eng.launches_per_step == (4 if heads == 1 else 5) * depth + 2
         eng.set_sampling(temp=0.98, seed=5)
         res = []
         for window in range(2):
@@ -269,7 +272,7 @@ def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, hea
         eng.close()
     L.lib().jb_tune_gemv_long(1)                  # the default
     L.lib().jb_tune_pipeline(1)
-    for other in ("chain", "pipelined"):
+    for other in modes[1:]:
         for (z0, p0), (z1, p1) in zip(outs["classic"], outs[other]):
             assert np.array_equal(z0, z1), f"tokens differ between the classic plain chain and {other}"
             assert np.array_equal(p0, p1), f"logits differ between the classic plain chain and {other}"

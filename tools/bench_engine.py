@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--plain-first", type=int, default=0, help="run this many plain graph-replayed steps before switching the engine to pipelined launches")
     ap.add_argument("--noise-streams", type=int, default=0, help="touch this many extra torch streams first (hardware-queue pressure)")
     ap.add_argument("--pipelined", type=int, default=-1, help="1 / 0: software-pipelined launches on / off (default: the engine's choice)")
+    ap.add_argument("--two-streams", action="store_true", help="single-head engines: the two-stream form of the pipelined step (jb_tune_pipeline(3)), not the three-stream one")
     ap.add_argument("--long-rows", action="store_true", help="5b: projections over 129..160 k-tiles on the 8-wave two-stage kernel (jb_tune_gemv_long(1))")
     ap.add_argument("--fat-attention", action="store_true", help="the fat form of the 480-channel wide-value attention kernel (jb_tune_attn_decode_wide_lean(0))")
     a = ap.parse_args()
@@ -95,6 +96,8 @@ def main():
         L.lib().jb_tune_attn_decode_wide_lean(0)
     if a.long_rows:
         L.lib().jb_tune_gemv_long(1)
+    if a.two_streams:
+        L.lib().jb_tune_pipeline(3)
     sd = random_state(cfg, dev)
     eng = PriorEngine(sd, "", n_batch=a.batch, fp16=not a.fp32, chunk_cap=64, **cfg)
     y = torch.randn(a.batch, 1, cfg["width"], device=dev) * 0.01 if cfg["y_cond"] else None
