@@ -406,7 +406,11 @@ int jb_engine_pipeline(void* handle, int enable);
  * chain (the kernel boundary is the hand-shake) and as software-pipelined launches (completion words).  0 -- [row][channel]
  * and, for the plain chain, the plain kernels (16 half lines per wave request).  Measured on the upsampler step at 16 samples,
  * pipelined launches: 1.407 against 1.522 ms.  Same arithmetic in every form: tokens and logits are bit-identical.  The reference
- * has no counterpart (its hand-off between two layers is a tensor in HBM: jukebox/transformer/transformer.py:62-66,82-86). */
+ * has no counterpart (its hand-off between two layers is a tensor in HBM: jukebox/transformer/transformer.py:62-66,82-86).
+ * Bit 1 of the argument (value | 2), read when an engine's streams for pipelined launches are made: keep single-head engines
+ * on the TWO-stream form of the pipelined step (launches alternate by slot).  Default: three streams by kind of launch -- the
+ * attention launches on a stream of their own, dispatched four phases ahead of their flags, on compute units reserved by mask
+ * (DESIGN.md section 5): 1.370 against 1.405 ms per upsampler step at position 4096, 1.388 against 1.487 at 7900, bit-identical. */
 void jb_tune_pipeline(int operand_order);
 /* 1 while the engine's decode steps run as pipelined launches, else 0 (also after a fallback to the plain chain). */
 int jb_engine_pipelined(void* handle);
