@@ -341,6 +341,47 @@ def test_a_released_pair_leaves_the_other_engines_plain_chains_alone(PE, monkeyp
         e.close()
 
 
+def test_every_triple_of_streams_runs_like_the_first(PE, monkeypatch):
+    """The three-stream form of the pipelined step (single-head engines: the attention launches on a stream of their own, on
+    compute units reserved by mask) made, used and RELEASED five times in one process -- the job's life cycle: every timed job
+    of bench.py makes its own streams.  Round 6: while the unit each projection stream's mask leaves out moved with every triple,
+    the third triple of a process lost a unit of XCD 1 -- 22 units for the 23 workgroups the wide c_attn puts there -- and the
+    step went from 1.37 to 1.83 ms (profiles/r06c24_recreate.log); the units are fixed in XCDs 6 / 7 now.  Full upsampler width
+    and workgroup counts (depth 12): every later triple within 8 % of the first, no wait timed out, same tokens each time; and the
+    three-stream step is not slower than the two-stream form of the same engine (jb_tune_pipeline(3))."""
+    from jukebox_amd import _lib as L
+    monkeypatch.delenv("JB_PIPELINE_LAUNCHES", raising=False)
+    rng = np.random.default_rng(6)
+    width, depth, bins, seq, blocks, N = 1920, 12, 512, 2048, 32, 16
+    sd = to_dev(_random_sd(rng, width, depth, bins, seq, 2, scale=0.02))
+    xc = torch.from_numpy((rng.standard_normal((N, seq, width)) * 0.1).astype(np.float32))
+    e = PE(sd, "", n_batch=N, seq_len=seq, bins=bins, width=width, depth=depth, heads=1, attn_order=2, blocks=blocks,
+           y_cond=False, fp16=True, chunk_cap=64)
+    e.set_cond(xc, None)
+    e.set_sampling(temp=0.98, seed=5)
+    e.tokens[:, :1500] = torch.from_numpy(rng.integers(0, bins, (N, 1500))).cuda()
+    e.prefill(0, 1500)
+    ms, toks = [], None
+    try:
+        for cycle in range(6):
+            L.lib().jb_tune_pipeline(3 if cycle == 5 else 1)      # the last cycle: the two-stream form, for comparison
+            assert e.set_pipelined(True)
+            e.decode(1500, 16)
+            ms.append(e.timed_decode(1516, 256) * 1e3)
+            assert e.pipelined and e.pipeline_resident and e.pipe_error() == 0
+            if toks is None:
+                toks = e.tokens[:, 1500:1772].clone()
+            assert torch.equal(e.tokens[:, 1500:1772], toks), "every triple draws the same tokens"
+            assert e.set_pipelined(False) is False and not e.pipeline_resident
+    finally:
+        L.lib().jb_tune_pipeline(1)
+        e.close()
+    print("pipelined step, ms: three streams, triples 1..5 %s; two streams %.4f" % (["%.4f" % x for x in ms[:5]], ms[5]))
+    for x in ms[1:5]:
+        assert x < 1.08 * ms[0], ms
+    assert ms[0] < 1.03 * ms[5], ms
+
+
 def test_pipelined_timeout_is_recovered_on_the_plain_chain(monkeypatch):
     """ConditionalAutoregressive2D._run: when a pipelined launch gives up waiting for its producer (the engine's error word is
     set; bounded polls, no hang) the window's tokens are void -- the sampler decodes the window again on the plain launch
