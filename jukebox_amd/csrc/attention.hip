@@ -589,12 +589,16 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
     if constexpr (PIPE) JB_SEG(pipe, 7);
     float m = -INFINITY;
     for (int w = 0; w < nw; ++w) m = fmaxf(m, s_ml[2 * w]);
-    // the waves' weights exp(m_w - m), once (they scale the sums AND the channel partials; launches have <= 8 waves)
+    // the waves' weights exp(m_w - m), once (they scale the sums AND the channel partials; launches have <= 8 waves): lane l
+    // evaluates wave (l & 7)'s, the eight values are read back as scalars -- one expf per thread on the epilogue's dependent chain
+    // instead of eight (the same function of the same operands: bit-identical)
     float ew[8];
     float lsum = 0.f;
+    const int wl = lane & 7;
+    const float e_l = wl < nw ? expf(s_ml[2 * wl] - m) : 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
-        ew[w] = w < nw ? expf(s_ml[2 * w] - m) : 0.f;
+        ew[w] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e_l), w));
         if (w < nw) lsum += s_ml[2 * w + 1] * ew[w];
     }
     const float inv = 1.0f / lsum;
