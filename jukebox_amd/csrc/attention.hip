@@ -478,8 +478,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
             pv[r] = ok ? jb_round<f16>(jb_round<f16>(sc[r]) * scale2) : -INFINITY;
             mx = fmaxf(mx, pv[r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = jb_rows_reduce(mx, [](float a, float b) { return fmaxf(a, b); });
         const float m_new = fmaxf(m_w, mx);
         const float alpha = expf(m_w - m_new);
         float ps = 0.f;
@@ -488,8 +487,7 @@ __global__ __launch_bounds__(512) void attn_decode_wide_kernel(int func, const f
             pv[r] = (pv[r] == -INFINITY) ? 0.f : expf(pv[r] - m_new);
             ps += pv[r];
         }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
+        ps = jb_rows_reduce(ps, [](float a, float b) { return a + b; });
         l_w = l_w * alpha + ps;
         m_w = m_new;
         if (c == 0) *reinterpret_cast<f32x4*>(pw + g * 4) = f32x4{pv[0], pv[1], pv[2], pv[3]};

@@ -124,6 +124,20 @@ template <typename T> __device__ __forceinline__ float jb_apply_act(float v, int
     return v;
 }
 
+// op over the four 16-lane rows of a wave, per column -- what `x = op(x, __shfl_xor(x, 16)); x = op(x, __shfl_xor(x, 32))`
+// computes for a commutative op, bit for bit -- with gfx950's v_permlane16_swap / v_permlane32_swap (rows 1 / 3 of one copy against
+// rows 0 / 2 of another, then the upper half against the lower) instead of two ds_bpermute round trips through the LDS crossbar.
+template <typename Op> __device__ __forceinline__ float jb_rows_reduce(float x, Op op) {
+    // (inline assembly: ROCm 7.2's clang lowers BOTH results of __builtin_amdgcn_permlane16_swap / 32_swap to the first operand's
+    // register -- op(a, a), a silently wrong softmax; the s_nops are the wait states a VALU write needs before a permlane reads it)
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));      // {r0 r0 r2 r2}, {r1 r1 r3 r3}
+    const float y = op(a, b);
+    float c = y, d = y;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));      // {lo lo}, {hi hi}
+    return op(c, d);
+}
+
 // Wave-wide (64-lane) reductions without the LDS crossbar: four DPP steps reduce each 16-lane row in the VALU
 // (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row results are read with
 // v_readlane and combined.  A __shfl_xor butterfly is six dependent ds_bpermute round trips (~100+ cycles each).
