@@ -380,24 +380,26 @@ int jb_engine_prefill(void* handle, int t0, int n_t, void* stream);
  * plain chain's graph even while pipelined launches are switched on (the sampler's in-situ comparison of the two forms).
  * A pipelined decode is host-synchronous and must not be called on a stream that is being captured. */
 int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* stream);
-/* Software-pipelined launches of the decode step (graph replay only): the launches of a step alternate between two streams
- * of the engine's own (each on a hardware queue of its own), so launch j+1 is dispatched -- and requests its weight stream,
- * whose addresses never depend on activations -- while launch j still runs; what it reads from launch j it reads after
- * polling j's completion word, through write-through stores / L1-bypassing loads.  Same kernels' arithmetic in the same
+/* Software-pipelined launches of the decode step (graph replay only): the launches of a step go to streams of the engine's
+ * own (each on a hardware queue of its own) -- TWO, alternating by launch, for multi-head engines; THREE by kind of launch for
+ * single-head engines on wide-value layers (0: c_attn, c_fc, the logits head; 1: mlp.c_proj, the sampler; 2: the attention,
+ * dispatched four phases ahead of its flags on compute units reserved by mask: jb_tune_pipeline) --, so a
+ * launch is dispatched -- and requests its weight stream, whose addresses never depend on activations, the attention its K / v'
+ * rows of earlier positions -- while its producer still runs; what it reads from its producer it reads after polling the
+ * producer's completion words, through write-through stores / L1-bypassing loads.  Same kernels' arithmetic in the same
  * order: tokens and logits are bit-identical to the plain chain.  A pipelined jb_engine_decode is HOST-SYNCHRONOUS: it
- * drains the caller's stream, runs the steps on the pair and returns when they are done (no queue of the process holds a
+ * drains the caller's stream, runs the steps on its streams and returns when they are done (no queue of the process holds a
  * waiting packet meanwhile).  enable != 0 returns JB_ERR_UNSUPPORTED unless every launch of this engine's step has a
- * pipelined form (cfg.pipe_words given, fp16, <= 16 samples, every layer a wide-value layer of one 480-channel head, width
- * and n_mlp of 33..64 k-tiles: the 1b upsamplers), and while TWO other engines of the process have them on: a waiting launch
- * occupies compute units (two 8-wave projection workgroups fill one); the waiters of two engines leave half of >= 152 compute
- * units free, where the lean attention workgroups and the projections they wait for still fit; a third engine's could cover
- * the chip (one engine with jb_tune_attn_decode_wide_lean(0); enable = 0 or jb_engine_destroy releases the right).  The two streams must feed different hardware
- * queues; the first pipelined decode makes the pair, checks that with a two-kernel handshake and keeps the plain chain
- * otherwise (jb_engine_pipelined then reports 0).  enable = 0 RELEASES the pair -- streams, hardware queues, graphs --, so
- * that nothing of it outlives the phase that uses it (two more hardware queues in the process, even idle ones, slow every
- * plain launch chain next to them; the reference's loop leaves nothing behind either: jukebox/sample.py:90-121); the next
- * enable makes a new one (milliseconds).  enable = 2 is enable = 1 with a fresh pair at the next decode.  The engine must
- * be idle in every case.  Replaces the same reference code as jb_engine_decode. */
+ * pipelined form (cfg.pipe_words given, fp16, <= 16 samples; single head: every layer a wide-value layer of one 480-channel
+ * head, width and n_mlp of 33..64 k-tiles -- the 1b upsamplers; multi-head: folded LayerNorm, heads of 150 / 256 / 512
+ * channels), and while ANOTHER engine of the process has them on: a waiting launch occupies compute units, and the waiters
+ * of two engines can keep each other's producers from being placed (enable = 0 or jb_engine_destroy releases the right).
+ * The streams must feed different hardware queues; the first pipelined decode makes them, checks that pairwise with a
+ * two-kernel handshake and keeps the plain chain otherwise (jb_engine_pipelined then reports 0).  enable = 0 RELEASES them --
+ * streams, hardware queues, graphs --, so that nothing outlives the phase that uses it (more hardware queues in the process,
+ * even idle ones, slow every plain launch chain next to them; the reference's loop leaves nothing behind either:
+ * jukebox/sample.py:90-121); the next enable makes new ones (milliseconds).  enable = 2 is enable = 1 with fresh streams at
+ * the next decode.  The engine must be idle in every case.  Replaces the same reference code as jb_engine_decode. */
 int jb_engine_pipeline(void* handle, int enable);
 /* The hand-off form of the decode step, read when an engine is created: operand_order = 1 (default) -- the activation blocks
  * between the launches (x_a, x_b, mlp) in MFMA operand order ([k-tile][lane][8 channels] of 16 rows: a consumer wave's fetch of
