@@ -390,8 +390,8 @@ int jb_engine_decode(void* handle, int t0, int n_steps, int use_graph, void* str
  * order: tokens and logits are bit-identical to the plain chain.  A pipelined jb_engine_decode is HOST-SYNCHRONOUS: it
  * drains the caller's stream, runs the steps on its streams and returns when they are done (no queue of the process holds a
  * waiting packet meanwhile).  enable != 0 returns JB_ERR_UNSUPPORTED unless every launch of this engine's step has a
- * pipelined form (cfg.pipe_words given, fp16, <= 16 samples; single head: every layer a wide-value layer of one 480-channel
- * head, width and n_mlp of 33..64 k-tiles -- the 1b upsamplers; multi-head: folded LayerNorm, heads of 150 / 256 / 512
+ * pipelined form (cfg.pipe_words given, fp16, <= 16 samples; single head: every layer a wide-value layer of one 480- or
+ * 256-channel head, width and n_mlp of 32..64 k-tiles -- the 1b upsamplers, small_prior; multi-head: folded LayerNorm, heads of 150 / 256 / 512
  * channels), and while ANOTHER engine of the process has them on: a waiting launch occupies compute units, and the waiters
  * of two engines can keep each other's producers from being placed (enable = 0 or jb_engine_destroy releases the right).
  * The streams must feed different hardware queues; the first pipelined decode makes them, checks that pairwise with a

@@ -853,15 +853,23 @@ int jb_attn_decode_wide_impl(int attn_func, const void* q, int64_t ldq, const vo
     hipStream_t s = (hipStream_t)stream;
     const JbPipe nopipe{nullptr, nullptr, nullptr, -1, -1, 0, nullptr};
     if (pipe) {
-        JB_REQUIRE(d_head == 480 && (int64_t)n_batch * cache_cap * width < (1ll << 30) && ldo % 8 == 0 && ((uintptr_t)x_out % 16) == 0,
-                   "a pipelined launch of the wide-value attention takes d_head = 480, caches below 2 GiB and 16-byte aligned output rows");
+        JB_REQUIRE((d_head == 480 || d_head == 256) && (int64_t)n_batch * cache_cap * width < (1ll << 30) && ldo % 8 == 0 &&
+                       ((uintptr_t)x_out % 16) == 0,
+                   "a pipelined launch of the wide-value attention takes d_head = 480 or 256, caches below 2 GiB and 16-byte aligned output rows");
         JB_REQUIRE(pipe->slot < 0 || pipe->proto < 1 || (int64_t)grid.x * grid.y >= 8, "completion protocol 1 needs launches of >= 8 workgroups");
 #define JB_LAUNCH_DECW_PIPE(FORM, LEAN)                                                                                \
     attn_decode_wide_kernel<15, FORM, LEAN><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache,   \
                                                                      (const f16*)vcache_w, cache_cap, (const f16*)res, ldr, \
                                                                      bias, (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe)
         // (FORM 1: synchronised through the completion words; 2 = JB_PIPE_NO_SYNC: the same kernel form as a launch of a plain chain)
-        if (pipe->slot >= 0) { if (lean) JB_LAUNCH_DECW_PIPE(1, true); else JB_LAUNCH_DECW_PIPE(1, false); }
+        if (d_head == 256) {      // (small_prior / small_upsampler: one head of 256 channels on 1024)
+            if (pipe->slot >= 0)
+                attn_decode_wide_kernel<8, 1, false><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache, (const f16*)vcache_w,
+                                                                                cache_cap, (const f16*)res, ldr, bias, (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe);
+            else
+                attn_decode_wide_kernel<8, 2, false><<<grid, nw * 64, lds, s>>>(attn_func, (const f16*)q, ldq, (const f16*)kcache, (const f16*)vcache_w,
+                                                                                cache_cap, (const f16*)res, ldr, bias, (f16*)x_out, ldo, width, block_ctx, t_dev, *pipe);
+        } else if (pipe->slot >= 0) { if (lean) JB_LAUNCH_DECW_PIPE(1, true); else JB_LAUNCH_DECW_PIPE(1, false); }
         else { if (lean) JB_LAUNCH_DECW_PIPE(2, true); else JB_LAUNCH_DECW_PIPE(2, false); }
 #undef JB_LAUNCH_DECW_PIPE
         JB_CHECK_LAUNCH();

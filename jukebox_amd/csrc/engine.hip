@@ -392,8 +392,8 @@ static bool pipeline_eligible_multi_head(const JbEngine* e) {
 static bool pipeline_eligible(const JbEngine* e) {
     const jb_engine_cfg& c = e->cfg;
     if (pipeline_eligible_multi_head(e)) return true;
-    if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || c.n_head != 1 || c.n_state != 480 || !c.x_out_packed) return false;
-    if (c.width % 32 || c.n_mlp % 32 || c.width / 32 < 33 || c.width / 32 > 64 || c.n_mlp / 32 < 33 || c.n_mlp / 32 > 64) return false;
+    if (!c.pipe_words || c.dtype != JB_F16 || c.n_batch > 16 || c.n_head != 1 || (c.n_state != 480 && c.n_state != 256) || !c.x_out_packed) return false;
+    if (c.width % 32 || c.n_mlp % 32 || c.width / 32 < 32 || c.width / 32 > 64 || c.n_mlp / 32 < 32 || c.n_mlp / 32 > 64) return false;
     for (const jb_layer& L : e->layers)
         if (!layer_wide(c, L) || !L.w_fc_f || layer_max_keys(c, L) > 128) return false;     // one 16-key tile per attention wave
     return true;
@@ -403,8 +403,8 @@ extern "C" int jb_engine_pipeline(void* handle, int enable) {
     JB_REQUIRE(handle, "null engine");
     JbEngine* e = (JbEngine*)handle;
     if (enable && !pipeline_eligible(e)) JB_UNSUPPORTED("this engine's decode step has launches without a pipelined form (needs pipe_words, "
-                                                        "fp16, <= 16 samples, and either wide-value layers of one 480-channel head on "
-                                                        "33..64 k-tiles or folded-LayerNorm multi-head layers without key splits)");
+                                                        "fp16, <= 16 samples, and either wide-value layers of one 480- or 256-channel head on "
+                                                        "32..64 k-tiles or folded-LayerNorm multi-head layers without key splits)");
     // ONE pipelined engine per process.  A waiting launch holds up to 180 workgroup slots (8 waves at <= 96 registers per lane:
     // two such workgroups fill a compute unit) while it spins, and the producer it waits for must still find room -- the
     // wide-value attention workgroup needs an otherwise EMPTY compute unit, and the waiters of two engines can leave none (round

@@ -149,13 +149,13 @@ class ConditionalAutoregressive2D(nn.Module):
     @property
     def pipeline_candidate(self):
         """Whether this model's engines can run software-pipelined launches, from the geometry alone (the library decides for
-        an engine: jb_engine_pipeline's eligibility rule -- fp16, <= 16 samples, one 480-channel head on wide-value
-        attention, width and MLP of 33..64 k-tiles, key sets of <= 128 keys: the 1b upsamplers)."""
+        an engine: jb_engine_pipeline's eligibility rule -- fp16, <= 16 samples, one 480- or 256-channel head on wide-value
+        attention, width and MLP of 32..64 k-tiles, key sets of <= 128 keys: the 1b upsamplers, small_prior / small_upsampler)."""
         S, M = int(self.m_attn * self.width), int(self.m_mlp * self.width)
         bc = self.input_dims // self.blocks if self.blocks else 0
-        return (self.heads == 1 and S == 480 and not self.only_encode and self.attn_order == 2 and 0 < bc <= 128
-                and self.blocks <= 128 and self.width % 32 == 0 and M % 32 == 0 and 33 <= self.width // 32 <= 64
-                and 33 <= M // 32 <= 64)
+        return (self.heads == 1 and S in (480, 256) and not self.only_encode and self.attn_order == 2 and 0 < bc <= 128
+                and self.blocks <= 128 and self.width % 32 == 0 and M % 32 == 0 and 32 <= self.width // 32 <= 64
+                and 32 <= M // 32 <= 64)
 
     def _apply_pipeline(self, eng):
         """Software-pipelined launches as the sampler asks for them: `pipeline_launches` is None (leave the engine alone), a

@@ -223,7 +223,7 @@ def test_wide_value_engine_refuses_prefill_behind_decoded_positions(PE):
     assert int(eng.t_dev.item()) == 10
 
 
-@pytest.mark.parametrize("N,width,heads,long_rows", [(16, 1920, 1, 0), (9, 1920, 1, 0), (3, 1920, 1, 0), (3, 4800, 8, 0), (8, 4800, 8, 0), (16, 2048, 2, 0),
+@pytest.mark.parametrize("N,width,heads,long_rows", [(16, 1920, 1, 0), (9, 1920, 1, 0), (3, 1920, 1, 0), (16, 1024, 1, 0), (3, 4800, 8, 0), (8, 4800, 8, 0), (16, 2048, 2, 0),
                                                      (3, 4800, 8, 1), (8, 4800, 8, 1)])
 def test_pipelined_launches_equal_the_plain_chain(PE, monkeypatch, N, width, heads, long_rows):
     """Software-pipelined launches (jb_engine_pipeline: the launches of a step alternate between two streams, launch j+1
