@@ -637,16 +637,18 @@ def test_window_switches_to_pipelined_launches_when_the_upper_levels_finish():
 
 def test_pipeline_candidates_by_geometry():
     """ConditionalAutoregressive2D.pipeline_candidate mirrors the library's eligibility rule on the model's geometry: the 1b
-    upsamplers (one 480-channel head, width 1920, block_ctx 64, 128 blocks) are candidates; the top priors (2 / 8 heads), the
-    small prior (256-channel head) and an upsampler-shaped model whose transpose pattern would see > 128 keys are not."""
+    upsamplers (one 480-channel head, width 1920, block_ctx 64, 128 blocks) and -- since round 6 -- the small prior (one
+    256-channel head on 1024 channels: 32 k-tiles) are candidates; the top priors (2 / 8 heads), a single head of another size
+    (128 channels on 512) and an upsampler-shaped model whose transpose pattern would see > 128 keys are not."""
     from jukebox_amd.prior.autoregressive import ConditionalAutoregressive2D as AR
     with torch.device("meta"):
         up = AR((8192,), 2048, width=1920, depth=2, heads=1, attn_order=2, blocks=128, x_cond=True, y_cond=True)
         top = AR((6528,), 2127, width=2048, depth=2, heads=2, attn_order=12, blocks=64, x_cond=True, y_cond=True, prime_len=384)
         small = AR((8192,), 1024, width=1024, depth=2, heads=1, attn_order=2, blocks=64)
+        tiny = AR((8192,), 1024, width=512, depth=2, heads=1, attn_order=2, blocks=64)
         long_blocks = AR((16384,), 2048, width=1920, depth=2, heads=1, attn_order=2, blocks=256, x_cond=True, y_cond=True)
         enc = AR((512,), 80, width=1920, depth=2, heads=1, attn_order=2, blocks=8, only_encode=True)
-    assert up.pipeline_candidate and not top.pipeline_candidate and not small.pipeline_candidate
+    assert up.pipeline_candidate and small.pipeline_candidate and not top.pipeline_candidate and not tiny.pipeline_candidate
     assert not long_blocks.pipeline_candidate and not enc.pipeline_candidate
 
 
